@@ -1,0 +1,363 @@
+"""Generate tests/golden/*.npz by running the REFERENCE on CPU (test infrastructure).
+
+Run in the build container only (the reference never travels):
+
+    python oracle/gen_golden.py            # needs /root/reference
+
+The reference's ``segmentor/losses.py`` imports two packages that are not installed
+here and cannot be (no network): ``kornia`` (one call: nearest ``resize``,
+losses.py:126) and ``loguru`` (error logging only).  They are replaced in
+``sys.modules`` by in-memory stand-ins before the import:
+``resize -> F.interpolate(x, size, mode)`` and ``logger -> logging``.  The nearest
+resize is therefore the one call whose parity is NOT pinned by the reference itself.
+
+Weights and inputs are closed-form functions of (state_dict key, index) from
+``oracle/fill.py``, so a fixture only stores the reference's OUTPUTS and gradients.
+"""
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = os.environ.get("OCTA_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle.fill import fill_state_dict, hash_input  # noqa: E402
+
+
+def _install_standins():
+    k = types.ModuleType("kornia")
+    kg = types.ModuleType("kornia.geometry")
+    kt = types.ModuleType("kornia.geometry.transform")
+
+    def resize(x, size, interpolation="nearest"):
+        return F.interpolate(x, size=size, mode=interpolation)
+
+    kt.resize = resize
+    kg.transform = kt
+    k.geometry = kg
+    sys.modules.update({"kornia": k, "kornia.geometry": kg, "kornia.geometry.transform": kt})
+    lg = types.ModuleType("loguru")
+    lg.logger = logging.getLogger("reference")
+    sys.modules["loguru"] = lg
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()   # copy: buffers are updated in place by later calls
+
+
+def _grads(mod):
+    return {k: _np(p.grad) for k, p in mod.named_parameters() if p.grad is not None}
+
+
+def _buffers(mod):
+    return {k: _np(b) for k, b in mod.named_buffers()}
+
+
+def _save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays)")
+
+
+def block_fixture(tag, mod, x, d, extra_inputs=None):
+    """Run mod(x) in train mode, backward against a fixed cotangent, record everything."""
+    fill_state_dict(mod.state_dict(), salt=0)
+    mod.train()
+    x = x.clone().requires_grad_(True)
+    out = mod(x)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    loss = 0
+    for i, o in enumerate(outs):
+        g = hash_input(tuple(o.shape), seed=7000 + i, lo=-1.0, hi=1.0)
+        loss = loss + (o * g).sum()
+        d[f"{tag}/out{i}"] = _np(o)
+    loss.backward()
+    d[f"{tag}/grad_x"] = _np(x.grad)
+    for k, g in _grads(mod).items():
+        d[f"{tag}/grad/{k}"] = g
+    for k, b in _buffers(mod).items():
+        d[f"{tag}/buf/{k}"] = b
+
+
+def gen_blocks():
+    from architectures.extra.resnest import Bottleneck, ResNestDecoder, SplAtConv2d, Upsampling
+    from architectures.segmentor.blocks import AdversarialAttentionGate
+    from torch import nn
+    d = {}
+    # encoder-style SplAt: cardinality 1, no conv bias (resnest.py:199-206)
+    m = SplAtConv2d(16, 16, 3, padding=1, groups=1, bias=False, radix=2, norm_layer=nn.BatchNorm2d)
+    block_fixture("splat_enc", m, hash_input((3, 16, 6, 5), 11, -1, 1), d)
+    # decoder-style SplAt: cardinality 2, conv bias (resnest.py:27)
+    m = SplAtConv2d(32, 32, 3, padding=1, stride=1, groups=2, radix=2, norm_layer=nn.BatchNorm2d)
+    block_fixture("splat_dec", m, hash_input((3, 32, 5, 7), 12, -1, 1), d)
+    # strided bottleneck with avg-down shortcut (resnest.py:381-394, avd 188-190)
+    down = nn.Sequential(nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False),
+                         nn.Conv2d(32, 64, 1, bias=False), nn.BatchNorm2d(64))
+    m = Bottleneck(32, 16, stride=2, downsample=down, radix=2, cardinality=1, bottleneck_width=64,
+                   avd=True, avd_first=False, norm_layer=nn.BatchNorm2d)
+    block_fixture("bottleneck_s2", m, hash_input((3, 32, 8, 8), 13, -1, 1), d)
+    # identity-shortcut bottleneck
+    m = Bottleneck(64, 16, radix=2, cardinality=1, bottleneck_width=64, avd=True, avd_first=False,
+                   norm_layer=nn.BatchNorm2d)
+    block_fixture("bottleneck_id", m, hash_input((3, 64, 5, 5), 14, -1, 1), d)
+    m = ResNestDecoder(64, 32)
+    block_fixture("decoder", m, hash_input((3, 64, 6, 6), 15, -1, 1), d)
+    m = Upsampling(16, 8)
+    block_fixture("upsampling", m, hash_input((2, 16, 5, 3), 16, -1, 1), d)
+    m = AdversarialAttentionGate(32, 2)
+    block_fixture("aag", m, hash_input((2, 32, 7, 5), 17, -1, 1), d)
+    m = AdversarialAttentionGate(16, 3)
+    block_fixture("aag3", m, hash_input((2, 16, 4, 4), 18, -1, 1), d)
+    _save("blocks.npz", d)
+
+
+def gen_losses():
+    from architectures.discriminator.losses import LSDiscriminatorialLoss, LSGeneratorLoss
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence, WeightedPartialCE
+    d = {}
+    B, C, H, W = 3, 2, 16, 16
+
+    def probs(seed, shape=(B, C, H, W)):
+        return F.softmax(3.0 * hash_input(shape, seed, -1, 1), dim=1)
+
+    def scribble(seed, shape=(B, C, H, W), empty_class=None):
+        u = hash_input((shape[0], 1, shape[2], shape[3]), seed)
+        ys = torch.zeros(shape)
+        ys[:, 1:2] = (u < 0.08).float()
+        ys[:, 0:1] = ((u > 0.3) & (u < 0.4)).float()
+        if empty_class is not None:
+            ys[:, empty_class] = 0
+        return ys
+
+    wpce = WeightedPartialCE(num_classes=2, manual=True)
+    cases = {
+        "wpce_mean": dict(),
+        "wpce_sum": dict(reduction="sum"),
+        "wpce_full": dict(full=True),
+        "wpce_ignore_bg": dict(ignore_bg=True),
+    }
+    for tag, kw in cases.items():
+        p = probs(21).requires_grad_(True)
+        ys = scribble(22)
+        l = wpce(p, ys, **kw)
+        l.backward()
+        d[f"{tag}/loss"] = _np(l)
+        d[f"{tag}/grad"] = _np(p.grad)
+        d[f"{tag}/ys_after"] = _np(ys)
+    p = probs(21).requires_grad_(True)
+    ys = scribble(22, empty_class=1)       # ni = 0 for class 1 (eps path, losses.py:38)
+    l = wpce(p, ys)
+    l.backward()
+    d["wpce_empty/loss"] = _np(l)
+    d["wpce_empty/grad"] = _np(p.grad)
+
+    p = probs(23).requires_grad_(True)
+    t = scribble(24)
+    l = DiceLoss()(p, t)
+    l.backward()
+    d["dice/loss"] = _np(l)
+    d["dice/grad"] = _np(p.grad)
+    # dense target (fully-supervised use, octa.py:54)
+    p = probs(25).requires_grad_(True)
+    t = F.one_hot((hash_input((B, H, W), 26) > 0.7).long(), 2).permute(0, 3, 1, 2).float()
+    l = DiceLoss()(p, t)
+    l.backward()
+    d["dice_dense/loss"] = _np(l)
+    d["dice_dense/grad"] = _np(p.grad)
+
+    def pyramid(seed0, H0=32, n=6):
+        return [probs(seed0 + i, (B, C, H0 >> max(i - 1, 0), H0 >> max(i - 1, 0))).requires_grad_(True)
+                for i in range(n)]
+
+    kl_cases = {
+        "kl_default": (dict(), None),
+        "kl_stopgrad": (dict(stop_gradient=True), None),
+        "kl_weights": (dict(), [1, 0.5, 0, 2, 1]),
+        "kl_short_weights": (dict(), [1, 2, 3, 4, 5, 6, 7]),
+        "jsd": (dict(divergence="JSD"), None),
+    }
+    for tag, (kw, w) in kl_cases.items():
+        att = pyramid(30)
+        l = InterlayerDivergence(**kw)(att, w)
+        l.backward()
+        d[f"{tag}/loss"] = _np(l)
+        for i, a in enumerate(att):
+            d[f"{tag}/grad{i}"] = _np(a.grad) if a.grad is not None else np.zeros(tuple(a.shape), np.float32)
+
+    r = hash_input((4, 1), 41, -2, 2).requires_grad_(True)
+    f = hash_input((4, 1), 42, -2, 2).requires_grad_(True)
+    l = LSDiscriminatorialLoss()(r, f)
+    l.backward()
+    d["lsd/loss"], d["lsd/grad_real"], d["lsd/grad_fake"] = _np(l), _np(r.grad), _np(f.grad)
+    f2 = hash_input((4, 1), 43, -2, 2).requires_grad_(True)
+    l = LSGeneratorLoss()(f2)
+    l.backward()
+    d["lsg/loss"], d["lsg/grad"] = _np(l), _np(f2.grad)
+    _save("losses.npz", d)
+
+
+def gen_discriminator():
+    from architectures.discriminator.blocks import DiscriminatorBlock
+    d = {}
+    B, H = 2, 64
+    shape = torch.Size((B, 2, H, H))
+    m = DiscriminatorBlock(shape, is_training=True, depth=4, num_filters=8)
+    fill_state_dict(m.state_dict())
+    m.train()
+
+    def pyr(seed):
+        return [F.softmax(2 * hash_input((B, 2, H >> i, H >> i), seed + i, -1, 1), dim=1).requires_grad_(True)
+                for i in range(5)]
+    for call in range(2):
+        torch.manual_seed(100 + call)
+        noise = torch.normal(mean=0.0, std=0.2, size=(H, H))
+        uni = torch.FloatTensor(1).uniform_(0, 1)
+        torch.manual_seed(100 + call)            # replay: the forward consumes the same draws
+        ys = pyr(50 + 10 * call)
+        out = m(ys)
+        g = hash_input(tuple(out.shape), 60 + call, -1, 1)
+        m.zero_grad()
+        (out * g).sum().backward()
+        d[f"call{call}/noise"] = _np(noise)
+        d[f"call{call}/uniform"] = _np(uni)
+        d[f"call{call}/out"] = _np(out)
+        for i, y in enumerate(ys):
+            d[f"call{call}/grad_y{i}"] = _np(y.grad)
+        for k, gr in _grads(m).items():
+            d[f"call{call}/grad/{k}"] = gr
+        for k, b in _buffers(m).items():
+            d[f"call{call}/buf/{k}"] = b
+    # eval mode: no power iteration, but noise / label noise still drawn (blocks.py:149-170)
+    m.eval()
+    torch.manual_seed(7)
+    with torch.no_grad():
+        out = m([y.detach() for y in pyr(90)])
+    d["eval/out"] = _np(out)
+    torch.manual_seed(7)
+    d["eval/noise"] = _np(torch.normal(mean=0.0, std=0.2, size=(H, H)))
+    d["eval/uniform"] = _np(torch.FloatTensor(1).uniform_(0, 1))
+    _save("disc.npz", d)
+
+
+def gen_unet():
+    from architectures.models.octa import OctaScribbleNet
+    for H in (48, 64):
+        d = {}
+        B = 3
+        x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+        if H == 48:   # ResnestUNet.predict (compose.py:189-199) on its own instance: it runs a forward itself
+            net0 = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+            fill_state_dict(net0.state_dict())
+            net0.train()
+            d["onehot"] = _np(net0.segmentor.predict(x, "one-hot")[1]).astype(np.uint8)
+            d["sigmoid"] = _np(net0.segmentor.predict(x, "sigmoid")[1])
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+        fill_state_dict(net.state_dict())
+        net.train()
+        att, agg, x4 = net.segmentor(x)
+        d["agg"] = _np(agg)
+        d["x4"] = _np(x4)
+        for i, a in enumerate(att):
+            d[f"att{i}"] = _np(a)
+        # segmentor-only loss (BASELINE config 2): WPCE + Dice on softmax(agg)
+        from architectures.segmentor.losses import DiceLoss
+        u = hash_input((B, 1, H, H), 4321)
+        ys = torch.zeros(B, 2, H, H)
+        ys[:, 1:2] = (u < 0.05).float()
+        ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+        p = F.softmax(agg, dim=1)
+        loss = net.supervised_loss(p, ys) + DiceLoss()(p, ys)
+        loss.backward()
+        d["loss"] = _np(loss)
+        keep = ("encoder_0_1_2.0.0.weight", "encoder_0_1_2.1.weight", "encoder_1.0.conv2.conv.weight",
+                "encoder_1.0.conv2.fc1.weight", "encoder_1.0.conv2.fc2.bias", "encoder_2.0.downsample.1.weight",
+                "encoder_4.2.bn3.bias", "upsampling_4.up.bias", "upsampling_1.up.weight",
+                "decoder_0.conv.0.weight", "decoder_0.conv.3.conv.weight", "decoder_0.conv.3.conv.bias",
+                "decoder_1.downsample.0.weight", "aag_0.conv1.weight", "aag_3.conv1.bias", "fc.weight", "fc.bias")
+        for k, pr in net.segmentor.named_parameters():
+            if pr.grad is None:
+                continue
+            if k in keep:
+                d[f"grad/{k}"] = _np(pr.grad)
+            d[f"gradnorm/{k}"] = _np(pr.grad.double().norm())
+        nograd = [k for k, pr in net.segmentor.named_parameters() if pr.grad is None]
+        d["nograd_keys"] = np.array(nograd)
+        for k in ("encoder_0_1_2.1.running_mean", "encoder_0_1_2.1.running_var",
+                  "encoder_4.2.conv2.bn1.running_var", "decoder_0.conv.3.bn0.running_mean"):
+            d[f"buf/{k}"] = _np(dict(net.segmentor.named_buffers())[k])
+        _save(f"unet_{H}.npz", d)
+
+
+def gen_trainstep():
+    """One full adversarial step on the reference modules, B=2, 48x48, plain SGD-free:
+    records the two losses and gradient norms so the oracle's and the HIP path's step can be pinned."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
+    B, H = 2, 48
+    d = {}
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net.train()
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    u = hash_input((B, 1, H, H), 4321)
+    ys = torch.zeros(B, 2, H, H)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    dense = (hash_input((B, H, H), 999) > 0.8).long()
+    real = F.one_hot(dense, 2).permute(0, 3, 1, 2).float()
+    real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous() for i in range(5)]
+
+    torch.manual_seed(2024)
+    att, agg, _ = net.segmentor(x)
+    p = F.softmax(agg, dim=1)
+    l_seg = net.supervised_loss(p, ys) + DiceLoss()(p, ys) \
+        + 0.1 * InterlayerDivergence()([p, *att]) + 0.1 * net.generator_loss(net.discriminator(att))
+    net.zero_grad()
+    l_seg.backward()
+    d["l_seg"] = _np(l_seg)
+    for k, pr in net.segmentor.named_parameters():
+        if pr.grad is not None:
+            d[f"seg_gradnorm/{k}"] = _np(pr.grad.double().norm())
+    net.zero_grad()
+    l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
+    l_d.backward()
+    d["l_d"] = _np(l_d)
+    for k, pr in net.discriminator.named_parameters():
+        d[f"disc_gradnorm/{k}"] = _np(pr.grad.double().norm())
+        if pr.numel() <= 4096:
+            d[f"disc_grad/{k}"] = _np(pr.grad)
+    # RNG draws consumed, in order: 3 discriminator calls x (normal(H,W), uniform(1))
+    torch.manual_seed(2024)
+    for c in range(3):
+        d[f"noise{c}"] = _np(torch.normal(mean=0.0, std=0.2, size=(H, H)))
+        d[f"uniform{c}"] = _np(torch.FloatTensor(1).uniform_(0, 1))
+    _save("trainstep_48.npz", d)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit(f"reference not found at {REF}")
+    sys.path.insert(0, REF)
+    _install_standins()
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep"]
+    if "blocks" in which:
+        gen_blocks()
+    if "losses" in which:
+        gen_losses()
+    if "disc" in which:
+        gen_discriminator()
+    if "unet" in which:
+        gen_unet()
+    if "trainstep" in which:
+        gen_trainstep()
