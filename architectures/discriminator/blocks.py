@@ -1,0 +1,152 @@
+"""Mirror of reference architectures/discriminator/blocks.py: ``DiscriminatorBlock`` (ref :12-133),
+``InstanceNoise`` (:135-154), ``LabelNoise`` (:156-185) -- the multi-scale LS-GAN critic.
+
+Parity contract kept from the reference: every training-mode call draws, in this
+order, one ``torch.normal(size=(H, W))`` plane and one ``FloatTensor(1).uniform_`` from the GLOBAL
+CPU generator, and advances the four spectral-norm (u, v) pairs by one power iteration.
+"""
+from typing import List, Literal, Sequence
+
+import torch
+from torch import Size, Tensor, nn
+from torch.nn.init import kaiming_normal_, xavier_uniform_
+
+from architectures.utils import rand_uniform
+from octave_amd import functional as F_
+from octave_amd._lib import ACT_LEAKY02, ACT_SIGMOID, ACT_TANH
+from octave_amd.layers import Conv2d
+
+
+class SpectralConv2d(Conv2d):
+    """Conv2d under torch.nn.utils.spectral_norm(n_power_iterations=1): parameters ``weight_orig``,
+    buffers ``weight_u`` / ``weight_v`` (same state_dict keys as the reference's hook form)."""
+
+    def __init__(self, *args, eps: float = 1e-12, **kwargs):
+        super().__init__(*args, **kwargs)
+        w = self.weight
+        del self._parameters['weight']
+        self.register_parameter('weight_orig', nn.Parameter(w.data))
+        h, wdt = w.shape[0], w[0].numel()
+        with torch.no_grad():   # same draws as SpectralNorm.apply: u ~ N(0,1)^h, v ~ N(0,1)^w, normalised
+            u = nn.functional.normalize(w.new_empty(h).normal_(0, 1), dim=0, eps=eps)
+            v = nn.functional.normalize(w.new_empty(wdt).normal_(0, 1), dim=0, eps=eps)
+        self.register_buffer('weight_u', u)
+        self.register_buffer('weight_v', v)
+        self.sn_eps = eps
+
+    def forward(self, x):
+        w = F_.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, self.sn_eps)
+        return F_.conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.groups, self.act)
+
+
+class InstanceNoise(nn.Module):
+
+    def __init__(self, input_shape: Size, mean: float, std: float, clipping: bool, is_training: bool):
+        """Gaussian noise addition: ONE (H, W) plane per call, broadcast over batch and channels."""
+        super().__init__()
+        self.mean = mean
+        self.std = std
+        self.clipping = clipping
+        self.size = (input_shape[2], input_shape[3])
+        self.is_training = is_training
+        self.compute_dtype = None
+
+    def draw(self) -> Tensor:
+        return torch.normal(mean=self.mean, std=self.std, size=self.size)      # CPU generator, like ref :150
+
+    def forward(self, x: Tensor):
+        noise = self.draw()                      # drawn even when not added (ref :150-151)
+        if not self.clipping:
+            raise NotImplementedError("InstanceNoise without clipping is off the hot path")
+        nz = noise.to(x.device, non_blocking=True) if self.is_training else None
+        dtype = self.compute_dtype or torch.float32
+        return F_.NoiseClipFn.apply(x, nz, dtype)
+
+
+class LabelNoise(nn.Module):
+
+    def __init__(self, prob: float = 0.1, mode: Literal['sign', 'label'] = 'sign'):
+        """Label noise: with probability `prob` the whole logits tensor changes sign."""
+        super().__init__()
+        self.prob = prob
+        self.mode = mode
+
+    def draw_sign(self) -> float:
+        if self.mode != 'sign':
+            raise NotImplementedError("LabelNoise mode 'label' is off the hot path")
+        return -1.0 if bool(rand_uniform() < self.prob) else 1.0
+
+    def forward(self, x: Tensor):
+        return x * self.draw_sign()
+
+
+class DiscriminatorBlock(nn.Module):
+
+    def __init__(self, input_shape: Size, is_training: bool, depth: int = 3, num_filters: int = 64, instance_noise: bool = True,
+                 label_noise: bool = True):
+        """Multi-scale discriminator (design: Valvano et al.).  forward(y): y[0] is the full-resolution
+        class map, y[i] the map at 1/2**i; returns (B, 1) logits."""
+        super().__init__()
+        self.num_filters = num_filters
+        self.is_training = is_training
+        self.depth = depth
+        self.compute_dtype = None
+        in_channels = input_shape[1]
+        modules = []
+        if instance_noise:
+            modules.append(InstanceNoise(input_shape=input_shape, is_training=is_training, mean=.0, std=.2, clipping=True))
+        conv_0 = Conv2d(in_channels, num_filters, kernel_size=4, stride=2, padding=1, act=ACT_LEAKY02)
+        kaiming_normal_(conv_0.weight, nonlinearity='leaky_relu')
+        modules.append(conv_0)
+        modules.append(nn.LeakyReLU(negative_slope=0.2))        # fused into conv_0's epilogue; kept for indices
+        self.stack_0 = nn.Sequential(*modules)
+        self._has_noise = instance_noise
+
+        squeeze_stack, spectral_stack = dict(), dict()
+        for i in range(self.depth):
+            squeeze, spectral = self._discriminator(
+                in_channels=num_filters * (2 ** i), num_squeeze_filters=13, num_fake_channels=in_channels,
+                num_sn_filters=num_filters * 2 * (2 ** i), sn_kernel_size=4, num_sn_stride=2, sn_padding=1)
+            squeeze_stack[f'squeeze_{i}'] = squeeze
+            spectral_stack[f'spectral_{i}'] = spectral
+        self.squeeze_dict = nn.ModuleDict(squeeze_stack)
+        self.spectral_dict = nn.ModuleDict(spectral_stack)
+        h, w = [int(i) // (2 ** (self.depth + 1)) for i in input_shape[2:]]
+        fc = nn.Conv2d(num_filters * (2 ** self.depth), out_channels=1, kernel_size=(h, w), stride=1)   # parameters only
+        xavier_uniform_(fc.weight)
+        modules = [fc, nn.Flatten()]
+        if label_noise:
+            modules.append(LabelNoise(0.1, 'sign'))
+        self.out = nn.Sequential(*modules)
+        self._has_label_noise = label_noise
+
+    def _discriminator(self, in_channels, num_squeeze_filters: int, num_fake_channels: int, num_sn_filters: int, sn_kernel_size: int,
+                       num_sn_stride: int, sn_padding: int):
+        squeezed = nn.Sequential(Conv2d(in_channels, num_squeeze_filters, kernel_size=1, stride=1, act=ACT_SIGMOID), nn.Sigmoid())
+        spectral = nn.Sequential(
+            SpectralConv2d(num_squeeze_filters + num_fake_channels, num_sn_filters, kernel_size=sn_kernel_size, stride=num_sn_stride,
+                           padding=sn_padding, act=ACT_TANH),
+            nn.Tanh())
+        return squeezed, spectral
+
+    def forward(self, y: Sequence[Tensor]):
+        dtype = self.compute_dtype or torch.float32
+        if self._has_noise:
+            self.stack_0[0].compute_dtype = dtype
+            s = self.stack_0[0](y[0])
+            s = self.stack_0[1](s)
+        else:
+            s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype))
+        for i in range(self.depth):
+            try:
+                s = self.squeeze_dict[f'squeeze_{i}'][0](s)
+                s = F_.DiscCatFn.apply(s, y[i + 1])
+                s = self.spectral_dict[f'spectral_{i}'][0](s)
+            except Exception as e:
+                raise Exception(f'Exception raised in depth = {i}') from e
+        fc = self.out[0]
+        sign = self.out[2].draw_sign() if self._has_label_noise else 1.0
+        return F_.FullConvFn.apply(s, fc.weight, fc.bias, sign)
+
+    def predict(self, y: List[Tensor]):
+        return self.forward(y)

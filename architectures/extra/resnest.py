@@ -1,0 +1,241 @@
+"""ResNeSt-50 encoder blocks and U-Net decoder blocks on libocta_hip.so.
+
+Mirror of reference architectures/extra/resnest.py for the hot path: ``SplAtConv2d`` (ref :57-138),
+``Bottleneck`` (:170-267), ``ResNet`` (:277-449, resnest50 configuration), ``ResNestDecoder``
+(:18-43), ``Upsampling`` (:46-54), ``resnest50`` (:451-459).  Same constructor arguments, attribute
+names and state_dict keys.  The unreachable options of the reference (DropBlock, rectified conv,
+radix 1, dilation) raise NotImplementedError instead of being reproduced.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn.modules.utils import _pair
+
+from octave_amd import functional as F_
+from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU
+
+BN_MOMENTUM = 0.1
+
+
+class SplAtConv2d(nn.Module):
+    """Split-attention conv, radix 2: grouped 3x3 -> bn0 -> relu -> [radix-sum GAP -> fc1 -> bn1 ->
+    relu -> fc2 -> radix softmax -> weighted sum] (the bracket is one fused op, ``F_.splat_tail``).
+    As in the reference the radix softmax views fc2's output as (B, radix, C) with no cardinality
+    transpose (ref :125)."""
+
+    def __init__(self, in_channels, channels, kernel_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, bias=True,
+                 radix=2, reduction_factor=4, rectify=False, rectify_avg=False, norm_layer=None, dropblock_prob=0.0, **kwargs):
+        super().__init__()
+        if radix != 2 or rectify or dropblock_prob > 0.0 or norm_layer is None:
+            raise NotImplementedError("SplAtConv2d: only radix=2 with a norm layer, no rectify/dropblock (hot-path configuration)")
+        padding = _pair(padding)
+        inter_channels = max(in_channels * radix // reduction_factor, 32)
+        self.radix = radix
+        self.cardinality = groups
+        self.channels = channels
+        self.dropblock_prob = dropblock_prob
+        self.rectify = False
+        self.rectify_avg = rectify_avg
+        self.conv = Conv2d(in_channels, channels * radix, kernel_size, _pair(stride), padding, _pair(dilation), groups=groups * radix, bias=bias,
+                           **kwargs)
+        self.use_bn = True
+        self.bn0 = BatchNorm2d(channels * radix)
+        self.relu = ReLU(inplace=True)
+        self.fc1 = Conv2d(channels, inter_channels, 1, groups=self.cardinality)
+        self.bn1 = BatchNorm2d(inter_channels)
+        self.fc2 = Conv2d(inter_channels, channels * radix, 1, groups=self.cardinality)
+
+    def forward(self, x, relu_after: bool = False):
+        x = self.bn0(self.conv(x), relu=True)
+        bn1 = self.bn1
+        training = bn1.training
+        if training and bn1.num_batches_tracked is not None:
+            bn1.num_batches_tracked.add_(1)
+        return F_.splat_tail(x, self.fc1.weight, self.fc1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                             self.fc2.weight, self.fc2.bias, self.cardinality, bn1.momentum, bn1.eps, training, relu_after)
+
+
+class Bottleneck(nn.Module):
+    """ResNeSt bottleneck (ref :170-267): 1x1 -> bn -> relu -> SplAt -> [avd 3x3 avgpool] -> 1x1 -> bn
+    -> (+ shortcut) -> relu, the last three fused into one BatchNorm-apply kernel."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, radix=1, cardinality=1, bottleneck_width=64, avd=False,
+                 avd_first=False, dilation=1, is_first=False, rectified_conv=False, rectify_avg=False, norm_layer=None,
+                 dropblock_prob=0.0, last_gamma=False):
+        super().__init__()
+        if radix != 2 or rectified_conv or dropblock_prob > 0.0 or dilation != 1 or avd_first:
+            raise NotImplementedError("Bottleneck: resnest50 configuration only (radix 2, no dropblock/rectify/dilation/avd_first)")
+        group_width = int(planes * (bottleneck_width / 64.)) * cardinality
+        self.conv1 = Conv2d(inplanes, group_width, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm2d(group_width)
+        self.dropblock_prob = dropblock_prob
+        self.radix = radix
+        self.avd = avd and (stride > 1 or is_first)
+        self.avd_first = avd_first
+        if self.avd:
+            self.avd_stride = stride
+            stride = 1
+        self.conv2 = SplAtConv2d(group_width, group_width, kernel_size=3, stride=stride, padding=dilation, dilation=dilation,
+                                 groups=cardinality, bias=False, radix=radix, norm_layer=BatchNorm2d)
+        self.conv3 = Conv2d(group_width, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * 4)
+        if last_gamma:
+            nn.init.zeros_(self.bn3.weight)
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.dilation = dilation
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.conv2(out)
+        if self.avd:
+            out = F_.avg_pool(out, 3, self.avd_stride, 1)
+        out = self.conv3(out)
+        residual = self.downsample(x) if self.downsample is not None else x
+        return self.bn3(out, relu=True, residual=residual)
+
+
+class _AvgDown(nn.Module):
+    """nn.AvgPool2d(k, k, ceil_mode=True, count_include_pad=False) of the avg_down shortcut (ref :383-387);
+    parameter-free, so it occupies index 0 of the downsample Sequential like the reference's."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, x):
+        if self.k == 1:
+            return x
+        return F_.avg_pool(x, self.k, self.k, 0, ceil_mode=True, count_include_pad=False)
+
+
+class _ConvBN(nn.Sequential):
+    """Sequential whose forward threads the fused-ReLU flag into its trailing BatchNorm."""
+
+    def forward(self, x):
+        for m in self:
+            x = m(x)
+        return x
+
+
+class ResNet(nn.Module):
+    """ResNeSt backbone container (ref :277-449) for the deep-stem / avg_down / avd variant."""
+
+    def __init__(self, block, layers, radix=1, groups=1, bottleneck_width=64, num_classes=1000, dilated=False, dilation=1,
+                 deep_stem=False, stem_width=64, avg_down=False, rectified_conv=False, rectify_avg=False, avd=False,
+                 avd_first=False, final_drop=0.0, dropblock_prob=0, last_gamma=False, norm_layer=BatchNorm2d):
+        super().__init__()
+        if not deep_stem or not avg_down or dilated or dilation != 1 or rectified_conv or final_drop > 0.0 or dropblock_prob:
+            raise NotImplementedError("ResNet: resnest50 configuration only (deep stem, avg_down, no dilation/dropout)")
+        self.cardinality = groups
+        self.bottleneck_width = bottleneck_width
+        self.inplanes = stem_width * 2
+        self.avg_down = avg_down
+        self.last_gamma = last_gamma
+        self.radix = radix
+        self.avd = avd
+        self.avd_first = avd_first
+        self.conv1 = nn.Sequential(
+            Conv2d(3, stem_width, kernel_size=3, stride=2, padding=1, bias=False),
+            BatchNorm2d(stem_width),
+            ReLU(inplace=True),
+            Conv2d(stem_width, stem_width, kernel_size=3, stride=1, padding=1, bias=False),
+            BatchNorm2d(stem_width),
+            ReLU(inplace=True),
+            Conv2d(stem_width, stem_width * 2, kernel_size=3, stride=1, padding=1, bias=False),
+        )
+        self.bn1 = BatchNorm2d(self.inplanes)
+        self.relu = ReLU(inplace=True)
+        self.maxpool = MaxPool3s2()
+        self.layer1 = self._make_layer(block, 64, layers[0], is_first=False)
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)   # dropped by the U-Net (compose.py:40-73)
+        for m in self.modules():                                   # same init rule as ref :368-374
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1, is_first=True):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = _ConvBN(_AvgDown(stride), Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=1, bias=False),
+                                 BatchNorm2d(planes * block.expansion))
+        kw = dict(radix=self.radix, cardinality=self.cardinality, bottleneck_width=self.bottleneck_width, avd=self.avd,
+                  avd_first=self.avd_first, norm_layer=BatchNorm2d, last_gamma=self.last_gamma)
+        layers = [block(self.inplanes, planes, stride, downsample=downsample, dilation=1, is_first=is_first, **kw)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, dilation=1, **kw))
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        c = self.conv1
+        x = c[1](c[0](x), relu=True)
+        x = c[4](c[3](x), relu=True)
+        return self.bn1(c[6](x), relu=True)
+
+    def forward(self, x):
+        raise NotImplementedError("the classification forward of ResNet is off the hot path; the U-Net consumes its stages")
+
+
+class MaxPool3s2(nn.Module):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (ref :340)."""
+    kernel_size, stride, padding = 3, 2, 1
+
+    def forward(self, x):
+        return F_.max_pool3s2(x)
+
+
+class ResNestDecoder(nn.Module):
+    """relu( BN(1x1(x)) + relu(SplAt(relu(BN(3x3(x))))) ) (ref :18-43)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Sequential(
+            Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False),
+            BatchNorm2d(out_channels),
+            ReLU(inplace=True),
+            SplAtConv2d(out_channels, out_channels, kernel_size=3, padding=1, stride=1, groups=2, radix=2, norm_layer=BatchNorm2d),
+            ReLU(inplace=True),
+        )
+        self.downsample = nn.Sequential(
+            Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
+            BatchNorm2d(out_channels),
+        )
+        self.relu = ReLU(inplace=True)
+
+    def forward(self, x):
+        c = self.conv
+        out = c[1](c[0](x), relu=True)
+        out = c[3](out, relu_after=True)
+        # residual branch: BN(1x1(x)) + out, then ReLU -- one fused BatchNorm-apply
+        return self.downsample[1](self.downsample[0](x), relu=True, residual=out)
+
+
+class Upsampling(nn.Module):
+    """ConvTranspose2d(k=2, s=2) (ref :46-54)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.up = ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+
+    def forward(self, x):
+        return self.up(x)
+
+
+def resnest50(pretrained=False, **kwargs):
+    """ResNeSt-50 (ref :451-459).  `model_path` points at resnest50-528c19ca.pth when pretrained."""
+    model = ResNet(Bottleneck, [3, 4, 6, 3], radix=2, groups=1, bottleneck_width=64, deep_stem=True, stem_width=32, avg_down=True,
+                   avd=True, avd_first=False)
+    model_path = kwargs.get('model_path', './models/resnest50-528c19ca.pth')
+    if pretrained:
+        model.load_state_dict(torch.load(model_path))
+    return model

@@ -1,0 +1,23 @@
+"""Mirror of reference architectures/utils.py (only what the hot path uses)."""
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+
+def get_same_padding_conv(input_size: int, kernel_size: int, stride: int):
+    """Padding giving n_out == n_in for a square kernel (reference utils.py:8-13)."""
+    return math.ceil(((stride * (input_size - 1)) - input_size + kernel_size) / 2)
+
+
+def get_same_padding_transpose(input_size: int, kernel_size: int, stride: int):
+    """reference utils.py:16-18."""
+    return (stride - (input_size * (1 - stride)) + kernel_size) // 2
+
+
+def rand_uniform(x: Optional[Tensor] = None):
+    """One U[0,1) draw from the global CPU generator, as reference utils.py:20-22 (the order in
+    which the CPU generator is consumed is part of the parity contract)."""
+    rand = torch.FloatTensor(1).uniform_(0, 1)
+    return rand

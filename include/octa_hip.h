@@ -1,0 +1,261 @@
+/*
+ * octa_hip.h -- C ABI of libocta_hip.so: the MI355X (gfx950) kernels behind the OCTAve
+ * segmentor + discriminator training hot path.
+ *
+ * The reference (IoBT-VISTEC/OCTAve, /root/reference/architectures) has no native code: every
+ * entry point below replaces a chain of ATen calls issued by one of its nn.Module.forward
+ * methods (and the autograd backward of that chain).  The reference line(s) replaced are cited
+ * per function as  file:line  relative to  architectures/ .
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types.  All pointers are DEVICE pointers
+ *     unless the name ends in _host.
+ *   - activations are NHWC ("channels-last"): element (b,h,w,c) of a tensor with per-pixel
+ *     stride ld lives at ((b*H + h)*W + w)*ld + off + c.  ld/off let a kernel read or write a
+ *     channel slice of a wider buffer (U-Net skip concatenation without a copy).
+ *   - dtype is OCTA_F32 or OCTA_BF16 for activations / packed weights.  Parameters, their
+ *     gradients, BatchNorm statistics and all loss arithmetic are fp32.
+ *   - the caller owns every buffer (incl. workspaces); the library never allocates, frees or
+ *     retains device memory, never synchronises, and launches only on the stream passed in.
+ *   - return value: 0 = OK, negative = octa_status.  octa_last_error() gives a thread-local
+ *     message.  No C++ exception crosses the boundary.
+ */
+#ifndef OCTA_HIP_H
+#define OCTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* octa_stream_t; /* hipStream_t */
+
+enum octa_status { OCTA_OK = 0, OCTA_ERR_BAD_ARG = -1, OCTA_ERR_UNSUPPORTED = -2, OCTA_ERR_LAUNCH = -3 };
+enum octa_dtype { OCTA_F32 = 0, OCTA_BF16 = 1 };
+enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA_ACT_SIGMOID = 3, OCTA_ACT_TANH = 4 };
+
+int octa_version(void);
+const char* octa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution engine (implicit GEMM on MFMA).  Replaces every nn.Conv2d / nn.ConvTranspose2d
+ * call of the path: extra/resnest.py:24,33,50,83,89,92,181,222,325-334,388;
+ * segmentor/blocks.py:40; segmentor/compose.py:79,181; discriminator/blocks.py:46,91,97,69.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct octa_conv_desc {
+    int32_t B, H, W;       /* input  image: B x H x W                                         */
+    int32_t OH, OW;        /* output image (OH = (H + 2*pad - KH)/stride + 1)                  */
+    int32_t Cin, Cout;     /* logical channel counts (all groups)                             */
+    int32_t KH, KW, stride, pad, groups;
+    int32_t cin_g_pad;     /* Cin/groups rounded up to a multiple of 8: K granularity of the
+                              packed weight; the input buffer must be readable (finite) there  */
+    int32_t cout_g_pad;    /* Cout/groups rounded up to a multiple of 8 (dgrad packed weight)  */
+    int32_t ldx, xoff;     /* input  per-pixel stride / channel offset (elements, % 8 == 0)    */
+    int32_t ldy, yoff;     /* output per-pixel stride / channel offset                         */
+    int32_t dtype;         /* octa_dtype of x, y and the packed weights                        */
+    int32_t act;           /* octa_act fused into the forward epilogue                         */
+    int32_t upshuffle;     /* 1: ConvTranspose2d k2 s2 as a 1x1 GEMM whose output channel
+                              n = (di*2+dj)*Cout_t + co is scattered to pixel (2h+di, 2w+dj)   */
+} octa_conv_desc;
+
+/* OIHW-logical fp32 weight (any strides, given in elements) -> packed forward operand
+ * [groups][Cout/g][KH][KW][cin_g_pad] of `dtype` (zero padded). */
+int octa_pack_weight_fwd(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                         void* packed, int Cout, int Cin_g, int KH, int KW, int groups,
+                         int cin_g_pad, int dtype, octa_stream_t stream);
+/* ... -> packed data-gradient operand [groups][Cin/g][KH][KW][cout_g_pad] (zero padded). */
+int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                           void* packed, int Cout, int Cin_g, int KH, int KW, int groups,
+                           int cout_g_pad, int dtype, octa_stream_t stream);
+
+/* ConvTranspose2d k2 s2 weight (Cin_t, Cout_t, 2, 2), any strides -> up-shuffle GEMM operand
+ * [(di*2+dj)*Cout_t + co][ci < cin_pad]  (extra/resnest.py:50). */
+int octa_pack_weight_convT(const float* w, int64_t s_ci, int64_t s_co, int64_t s_h, int64_t s_w,
+                           void* packed, int CinT, int CoutT, int cin_pad, int dtype,
+                           octa_stream_t stream);
+
+/* y = act(conv(x, w) + bias).  bias: fp32 [Cout] or NULL. */
+int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                    void* y, octa_stream_t stream);
+/* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
+int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
+                      octa_stream_t stream);
+/* dw[o,i,kh,kw] += sum_pixels dy * x   (fp32 gradient of the OIHW-logical parameter, addressed
+ * through its element strides so OIHW-dense and channels-last storage both work; accumulated
+ * with atomics, so the caller zeroes it once per step). */
+int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, float* dw,
+                      const int64_t* dw_strides /* o,i,h,w element strides of dw */, octa_stream_t stream);
+/* out[c] += sum over rows of src[row*ld + off + c]  (bias gradients; fp32 accumulate). */
+int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out,
+                octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / copy helpers (compose.py:125-130 pad, 141-147 cat+crop, 155,162,169 cat).
+ * ---------------------------------------------------------------------------------------- */
+/* NCHW (strided, fp32) -> NHWC [B,H,W,ld] of dtype, channels [0,C) written, [C,cpad) zeroed. */
+int octa_nchw_to_nhwc(const float* src, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                      void* dst, int B, int C, int H, int W, int ld, int off, int cpad, int dtype,
+                      octa_stream_t stream);
+/* NHWC of dtype -> NCHW fp32 (dense), optionally accumulate (+=). */
+int octa_nhwc_to_nchw(const void* src, int ld, int off, int dtype, float* dst, int B, int C, int H,
+                      int W, int accumulate, octa_stream_t stream);
+/* dst[b, h, w, doff + c] = src[b, h, w, soff + c] for h < Hd, w < Wd (crop when smaller than the
+ * source image, zero-fill when larger = F.pad bottom/right); C % 8 == 0.  accumulate: += */
+int octa_copy_channels(const void* src, int Hs, int Ws, int lds, int soff, void* dst, int Hd, int Wd,
+                       int ldd, int doff, int B, int C, int dtype, int accumulate, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d, training mode (extra/resnest.py:25,34,86,90,182,224,338,393): batch statistics,
+ * running-stat update (momentum, unbiased variance), fused ReLU and residual add.
+ * ---------------------------------------------------------------------------------------- */
+/* workspace floats needed by octa_bn_stats / octa_bn_bwd_reduce for C channels, rows rows */
+size_t octa_bn_workspace_floats(int64_t rows, int C);
+/* mean[c], invstd[c] over rows = B*H*W; updates running_mean/var in place when non-NULL. */
+int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off, int dtype, float eps,
+                  float momentum, float* mean, float* invstd, float* running_mean,
+                  float* running_var, float* workspace, octa_stream_t stream);
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, const void* residual, int ldr, int roff,
+                  void* y, int ldy, int yoff, int64_t rows, int C, int dtype, int relu,
+                  octa_stream_t stream);
+/* backward.  y is the forward output (only read when relu != 0, for the mask).
+ * dgamma/dbeta are ACCUMULATED (+=).  dres (optional) receives the masked dy. */
+int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, int ldx, int xoff, const void* y,
+                int ldy, int yoff, const float* mean, const float* invstd, const float* gamma,
+                void* dx, int lddx, int dxoff, void* dres, int lddr, int droff, float* dgamma,
+                float* dbeta, int64_t rows, int C, int dtype, int relu, float* workspace,
+                octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling (compose.py:45 maxpool 3/2/1; resnest.py:189 avgpool 3/s/1 count_include_pad;
+ * resnest.py:383 avgpool s/s ceil_mode count_include_pad=False).
+ * ---------------------------------------------------------------------------------------- */
+int octa_maxpool3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int OH,
+                        int OW, int dtype, octa_stream_t stream);
+int octa_maxpool3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C,
+                        int OH, int OW, int dtype, octa_stream_t stream);
+int octa_avgpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int k,
+                     int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
+int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int OH, int OW, int k,
+                     int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Split attention (extra/resnest.py:106-138), radix 2.
+ * ---------------------------------------------------------------------------------------- */
+/* gap[b][c] = mean_hw( x[b,hw,c] + x[b,hw,C+c] )   (fp32 out; resnest.py:108-116) */
+int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, octa_stream_t stream);
+/* out[b,hw,c] = a0*x[b,hw,c] + a1*x[b,hw,C+c], (a0,a1) = softmax(logit[b][c], logit[b][C+c])
+ * (resnest.py:125-138; the view(B, radix, C) has no cardinality transpose).  relu: fuse the
+ * ReLU that follows SplAt in ResNestDecoder (resnest.py:29). */
+int octa_splat_apply(const void* x, const float* logits, void* out, int B, int HW, int C, int dtype,
+                     int relu, octa_stream_t stream);
+/* backward of gap+apply: given dout, x, logits, out (for the relu mask) and dgap (gradient
+ * arriving at gap through fc1), produce dx [B,HW,2C] and dlogits [B,2C] (fp32). */
+int octa_splat_bwd(const void* dout, const void* x, const float* logits, const void* out,
+                   const float* dgap, void* dx, float* dlogits, int B, int HW, int C, int dtype,
+                   int relu, int phase, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention gate / head (segmentor/blocks.py:38-46; compose.py:79,181): per-pixel K-class linear
+ * (K <= 8), channel softmax, x * sum_{c>=1} y_c.  Class maps are fp32 NCHW (user-facing).
+ *   mode 0: gate  -> masked (NHWC dtype) and y = softmax(logits) (NCHW fp32)
+ *   mode 1: head  -> y = logits (NCHW fp32), masked unused
+ * ---------------------------------------------------------------------------------------- */
+int octa_aag_fwd(const void* x, const float* w, const float* bias, void* masked, float* y, int64_t B,
+                 int HW, int C, int K, int dtype, int mode, octa_stream_t stream);
+/* dx = dmasked*mask + W^T dlogits; dw/dbias ACCUMULATED (fp32). dy may be NULL (no grad). */
+int octa_aag_bwd(const void* x, const float* w, const float* y, const void* dmasked, const float* dy,
+                 void* dx, float* dw, float* dbias, int64_t B, int HW, int C, int K, int dtype,
+                 int mode, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise activations (discriminator/blocks.py:51,94,110): backward from the OUTPUT.
+ * ---------------------------------------------------------------------------------------- */
+int octa_act_bwd(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype,
+                 octa_stream_t stream);
+int octa_relu_fwd(const void* x, void* y, int64_t n, int dtype, octa_stream_t stream);
+int octa_add(const void* a, const void* b, void* out, int64_t n, int dtype, octa_stream_t stream);
+int octa_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.  Class-probability maps are fp32 with arbitrary (b,c,h,w) element strides.
+ * ---------------------------------------------------------------------------------------- */
+/* WeightedPartialCE (manual=True) + DiceLoss on p = softmax(logits) or on given probabilities:
+ * segmentor/losses.py:26-61 and 70-74.  from_logits=1 fuses the nn.Softmax(dim=1) the caller
+ * applies (compose.py:192).  out[0] = wpce, out[1] = dice.  ws: >= octa_loss_workspace_floats. */
+size_t octa_loss_workspace_floats(int B, int K);
+int octa_wpce_dice_fwd(const float* in, const int64_t* in_strides, const float* ys,
+                       const int64_t* ys_strides, int B, int K, int H, int W, int from_logits,
+                       int full, int reduction_sum, float* out, float* ws, octa_stream_t stream);
+/* d(in) = g_wpce * dWPCE/d(in) + g_dice * dDice/d(in); g_* are device scalars (or NULL = 0). */
+int octa_wpce_dice_bwd(const float* in, const int64_t* in_strides, const float* ys,
+                       const int64_t* ys_strides, int B, int K, int H, int W, int from_logits,
+                       int full, int reduction_sum, const float* g_wpce, const float* g_dice,
+                       const float* ws, float* din, const int64_t* din_strides, octa_stream_t stream);
+
+/* InterlayerDivergence, KLD/mean (segmentor/losses.py:111-147), nearest up-sampling fused.
+ * basis: [B,K,H,W]; maps[i]: [B,K,H>>shift[i],W>>shift[i]] (dense NCHW fp32), weight[i] != 0.
+ * out[0] = loss, out[1] = NaN flag. */
+int octa_interlayer_kl_fwd(const float* basis, const float* const* maps_host, const int* shifts_host,
+                           const float* weights_host, int n_maps, float wsum, int B, int K, int H,
+                           int W, float* out, float* ws, octa_stream_t stream);
+/* dbasis (may be NULL when stop_gradient) and dmaps[i] (zero-initialised by the caller,
+ * accumulated with atomics) scaled by the device scalar g. */
+int octa_interlayer_kl_bwd(const float* basis, const float* const* maps_host, const int* shifts_host,
+                           const float* weights_host, int n_maps, float wsum, int B, int K, int H,
+                           int W, const float* g, float* dbasis, float* const* dmaps_host,
+                           octa_stream_t stream);
+
+/* LS-GAN losses (discriminator/losses.py:11-14, 22-24).  mode 0: 0.5*mean((f-1)^2) (generator);
+ * mode 1: 0.5*mean((r-1)^2) + 0.5*mean((f+1)^2).  Forward writes out[0]; backward writes
+ * d_real / d_fake scaled by device scalar g. */
+int octa_lsgan_fwd(const float* real, const float* fake, int n_real, int n_fake, int mode, float* out,
+                   octa_stream_t stream);
+int octa_lsgan_bwd(const float* real, const float* fake, int n_real, int n_fake, int mode,
+                   const float* g, float* d_real, float* d_fake, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminator pieces.
+ * ---------------------------------------------------------------------------------------- */
+/* InstanceNoise + clip (discriminator/blocks.py:149-154): dst[b,h,w,c] = clip(src[b,c,h,w] +
+ * noise[h,w], 0, 1) written NHWC of dtype with channels [C,cpad) zeroed; mask[b,c,h,w] = 1 where
+ * the clip passed the gradient.  noise may be NULL (is_training False). */
+int octa_noise_clip_fwd(const float* src, const int64_t* src_strides, const float* noise, void* dst,
+                        uint8_t* mask, int B, int C, int H, int W, int ld, int cpad, int dtype,
+                        octa_stream_t stream);
+/* dsrc[b,c,h,w] (dense NCHW fp32) = mask ? ddst[b,h,w,c] : 0 */
+int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask, float* dsrc, int B, int C,
+                        int H, int W, int dtype, octa_stream_t stream);
+/* Spectral norm (torch.nn.utils.spectral_norm, 1 power iteration; blocks.py:105-108).
+ * w: fp32 [Cout][K] dense (OIHW flattened).  Updates u,v in place when do_power_iter, writes
+ * sigma[0] and w_sn = w / sigma. */
+int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter,
+                           float eps, float* sigma, float* w_sn, octa_stream_t stream);
+/* dw += (dw_sn - (sum(dw_sn * w_sn)) u v^T) / sigma */
+int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v,
+                           const float* sigma, int Cout, int K, float* dw, float* ws,
+                           octa_stream_t stream);
+/* Full-extent conv = per-sample dot product (blocks.py:68-72): out[b] = x[b,:].w + bias.
+ * x NHWC [B, n] of dtype, w fp32 [n] in the same (h,w,c) order. */
+int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n,
+                      int dtype, float sign, octa_stream_t stream);
+int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw,
+                      float* dbias, int B, int64_t n, int dtype, float sign, octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: fused Adam over a flat fp32 parameter arena (train step a17).
+ * ---------------------------------------------------------------------------------------- */
+int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   octa_stream_t stream);
+
+/* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
+int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTA_HIP_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of libocta_hip.so (the C ABI declared in include/octa_hip.h).
+
+The product path has NO fallback: if the library is missing, fails to load, or lacks a symbol
+the header declares, importing this module's `lib()` raises.  Signatures are taken from the
+header itself so the binding cannot drift from the ABI.
+"""
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "octa_hip.h")
+LIB_PATH = os.environ.get("OCTA_HIP_LIB", os.path.join(_HERE, "libocta_hip.so"))
+
+OCTA_F32, OCTA_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "H", "W", "OH", "OW", "Cin", "Cout", "KH", "KW", "stride", "pad", "groups",
+        "cin_g_pad", "cout_g_pad", "ldx", "xoff", "ldy", "yoff", "dtype", "act", "upshuffle")]
+
+
+class OctaError(RuntimeError):
+    pass
+
+
+_SCALARS = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "size_t": ctypes.c_size_t, "octa_stream_t": ctypes.c_void_p,
+}
+
+
+def _ctype_of(decl: str):
+    d = decl.strip()
+    if "octa_conv_desc" in d and "*" in d:
+        return ctypes.POINTER(ConvDesc)
+    if "*" in d:
+        return ctypes.c_void_p
+    toks = [t for t in d.replace("const", " ").split() if t]
+    base = toks[0]
+    if base not in _SCALARS:
+        raise OctaError(f"octa_hip.h: cannot map C type in '{decl}'")
+    return _SCALARS[base]
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [argtypes])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(octa_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        res = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+        argtypes = [] if args in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        out[name] = (res, argtypes)
+    return out
+
+
+_lock = threading.Lock()
+_LIB = None
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise OctaError(
+                f"libocta_hip.so not found at {LIB_PATH}: build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (or octave_amd/csrc/build.sh). "
+                f"There is no fallback path.")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so both share ONE HIP runtime)
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.signatures = parse_header()
+        for name, (res, argtypes) in self.signatures.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise OctaError(f"libocta_hip.so lacks symbol {name} declared in octa_hip.h") from e
+            fn.restype = res
+            fn.argtypes = argtypes
+        self._dll.octa_last_error.restype = ctypes.c_char_p
+
+    def raw(self, name):
+        return getattr(self._dll, name)
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            msg = self._dll.octa_last_error()
+            raise OctaError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def __getattr__(self, name):
+        if name.startswith("octa_"):
+            fn = getattr(self._dll, name)
+            if self.signatures[name][0] is ctypes.c_int and name != "octa_version":
+                return lambda *a, _n=name: self.call(_n, *a)
+            return fn
+        raise AttributeError(name)
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        with _lock:
+            if _LIB is None:
+                _LIB = _Lib()
+    return _LIB

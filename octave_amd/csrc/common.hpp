@@ -1,0 +1,107 @@
+// Shared device/host helpers for libocta_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/octa_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+// ---------------------------------------------------------------- error reporting
+void octa_set_error(const char* fmt, ...);
+#define OCTA_FAIL(code, ...) do { octa_set_error(__VA_ARGS__); return (code); } while (0)
+#define OCTA_REQUIRE(cond, ...) do { if (!(cond)) { octa_set_error(__VA_ARGS__); return OCTA_ERR_BAD_ARG; } } while (0)
+#define OCTA_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+    octa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return OCTA_ERR_LAUNCH; } } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// unpack a 16-byte chunk into EPC floats / pack back
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& c, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& c, float* f) {
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& c, float* f) {
+    f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+    f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+    f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+    f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+    uint4 c;
+    c.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    c.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    c.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    c.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    return c;
+}
+
+// ---------------------------------------------------------------- reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide sum of NV values per thread; result valid in thread 0 (and broadcast via smem[0..NV))
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* smem /* >= NV * 16 floats */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[i * 16 + wid] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += smem[i * 16 + w];
+            v[i] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case OCTA_ACT_RELU: return v > 0.f ? v : 0.f;
+        case OCTA_ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+        case OCTA_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case OCTA_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}

@@ -1,0 +1,667 @@
+// Implicit-GEMM convolution engine on MFMA (gfx950): forward, data-gradient, weight-gradient.
+//
+// One tile format serves both dtypes: an LDS tile row is 64 bytes = 4 chunks of 16 B
+// (32 bf16 or 16 fp32 along K).  The MFMA operand fragment of lane (r = lane&15, q = lane>>4)
+// is chunk q of row r for both v_mfma_f32_16x16x32_bf16 (8 bf16, k = 8q+j) and four
+// v_mfma_f32_16x16x4_f32 steps (float j of the chunk is k-slot q of step j).
+// Chunk c of row r is stored at slot c ^ ((-(r>>2))&3): ds_read_b128 of a fragment is then
+// bank-conflict free without padding ("LDS image").
+#include "common.hpp"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+struct ConvArgs {
+    const void* x; const void* w; const float* bias; void* y;
+    int B, H, W;          // image of the gathered tensor
+    int OH, OW;           // image of the row space, M = B*OH*OW
+    int Cg;               // gathered channels per group, padded to a chunk multiple
+    int CgStride;         // real channels per group of the gathered tensor
+    int Ng;               // output channels per group
+    int KH, KW, stride, pad;
+    int ldx, xoff, ldy, yoff;
+    int M, Kc;            // Kc = KH*KW*Cg/EPC chunks
+    int act, mode;        // mode 0: forward gather, 1: data-gradient gather
+    int upshuffle, CoutT;
+    int vec_store;
+};
+
+__device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int A_CH = BM / 64;
+    constexpr int B_CH = (BN + 63) / 64;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ uint4 sA[2][BM * 4];
+    __shared__ uint4 sB[2][BN * 4];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + g * a.CgStride;
+    const size_t Kelem = (size_t)a.Kc * EPC;
+    const T* __restrict__ wg = (const T*)a.w + (size_t)g * a.Ng * Kelem;
+    const int CgC = a.Cg / EPC;
+    const int kc = t & 3;
+    const int trow = t >> 2;
+
+    int rb[A_CH], rh[A_CH], rw[A_CH];
+    bool rv[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + trow + i * 64;
+        rv[i] = m < a.M;
+        const int mm = rv[i] ? m : 0;
+        const int ow = mm % a.OW;
+        const int tq = mm / a.OW;
+        const int oh = tq % a.OH;
+        rb[i] = tq / a.OH;
+        if (a.mode == 0) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
+        else { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
+    }
+    const T* wrow[B_CH];
+    bool wv[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        const int nr = trow + j * 64;
+        const int n = n0 + nr;
+        wv[j] = (nr < BN) && (n < a.Ng);
+        wrow[j] = wg + (size_t)(wv[j] ? n : 0) * Kelem;
+    }
+    int kcg = kc;
+    int cc = kcg % CgC;
+    int tap = kcg / CgC;
+    int kh = tap / a.KW, kw = tap % a.KW;
+
+    uint4 ra[A_CH], rbv[B_CH];
+    auto load_tile = [&]() {
+        const bool kvalid = kcg < a.Kc;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (rv[i] && kvalid) {
+                int ih, iw;
+                bool ok;
+                if (a.mode == 0) {
+                    ih = rh[i] + kh; iw = rw[i] + kw;
+                    ok = ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+                } else {
+                    const int th = rh[i] - kh, tw = rw[i] - kw;
+                    if (a.stride == 1) { ih = th; iw = tw; ok = true; }
+                    else { ih = th / a.stride; iw = tw / a.stride; ok = (th >= 0) && (tw >= 0) && (ih * a.stride == th) && (iw * a.stride == tw); }
+                    ok = ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+                }
+                if (ok) v = *(const uint4*)(xg + ((size_t)(rb[i] * a.H + ih) * a.W + iw) * a.ldx + cc * EPC);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (wv[j] && kvalid) v = *(const uint4*)(wrow[j] + (size_t)kcg * EPC);
+            rbv[j] = v;
+        }
+    };
+    auto advance = [&]() {
+        kcg += 4; cc += 4;
+        while (cc >= CgC) { cc -= CgC; if (++kw == a.KW) { kw = 0; ++kh; } }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) { const int row = trow + i * 64; sA[buf][row * 4 + (kc ^ swz(row))] = ra[i]; }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) { const int row = trow + j * 64; if (row < BN) sB[buf][row * 4 + (kc ^ swz(row))] = rbv[j]; }
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = (a.Kc + 3) >> 2;
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { advance(); load_tile(); }
+        uint4 xf[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int row = (wm * TM + i) * 16 + r; xf[i] = sA[buf][row * 4 + (q ^ swz(row))]; }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) { const int row = (wn * TN + i) * 16 + r; wf[i] = sB[buf][row * 4 + (q ^ swz(row))]; }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, per (tn,tm), 4 consecutive output channels (rows of D) of pixel column r
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 16 + r;
+        if (m >= a.M) continue;
+        size_t pix = (size_t)m;
+        int ow = 0, oh = 0, bb = 0;
+        if (a.upshuffle) { ow = m % a.OW; const int tq = m / a.OW; oh = tq % a.OH; bb = tq / a.OH; }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = n0 + (wn * TN + i) * 16 + q * 4;
+            if (nb >= a.Ng) continue;
+            int chan = g * a.Ng + nb;
+            int bidx = chan;
+            if (a.upshuffle) {
+                const int dd = nb / a.CoutT;
+                chan = nb - dd * a.CoutT;
+                bidx = chan;
+                pix = ((size_t)(bb * 2 * a.OH + 2 * oh + (dd >> 1)) * (2 * a.OW) + 2 * ow + (dd & 1));
+            }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f = acc[i][j][e];
+                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
+                v[e] = act_apply(f, a.act);
+            }
+            T* dst = yb + pix * a.ldy + chan;
+            if (a.vec_store && nb + 3 < a.Ng) {
+                if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
+    dim3 block(256);
+    if (a.Ng > 64) {
+        dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
+        conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
+    } else if (a.Ng > 32) {
+        dim3 grid(cdiv(a.M, 256), 1, groups);
+        conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a);
+    } else if (a.Ng > 16) {
+        dim3 grid(cdiv(a.M, 256), 1, groups);
+        conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a);
+    } else {
+        dim3 grid(cdiv(a.M, 256), 1, groups);
+        conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a);
+    }
+    OCTA_CHECK_LAUNCH("conv_igemm");
+    return OCTA_OK;
+}
+
+static int check_desc(const octa_conv_desc* d, const char* who) {
+    OCTA_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    OCTA_REQUIRE(d->dtype == OCTA_F32 || d->dtype == OCTA_BF16, "%s: bad dtype %d", who, d->dtype);
+    OCTA_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0, "%s: bad image dims", who);
+    OCTA_REQUIRE(d->groups > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0, "%s: channels not divisible by groups", who);
+    OCTA_REQUIRE(d->cin_g_pad % 8 == 0 && d->cin_g_pad >= d->Cin / d->groups, "%s: cin_g_pad %d invalid", who, d->cin_g_pad);
+    OCTA_REQUIRE(d->ldx % 8 == 0 && d->xoff % 8 == 0, "%s: ldx/xoff must be multiples of 8 (got %d/%d)", who, d->ldx, d->xoff);
+    OCTA_REQUIRE(d->groups == 1 || (d->Cin / d->groups) % 8 == 0, "%s: grouped conv needs Cin/groups %% 8 == 0", who);
+    OCTA_REQUIRE(d->xoff + (d->groups - 1) * (d->Cin / d->groups) + d->cin_g_pad <= d->ldx, "%s: padded input channels exceed ldx", who);
+    OCTA_REQUIRE((int64_t)d->B * d->OH * d->OW < (1ll << 31) && (int64_t)d->B * d->H * d->W < (1ll << 31), "%s: too many pixels", who);
+    if (d->upshuffle) {
+        OCTA_REQUIRE(d->groups == 1 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cout % 4 == 0,
+                     "%s: upshuffle needs a 1x1 GEMM with Cout = 4*Cout_t", who);
+        OCTA_REQUIRE(d->OH == d->H && d->OW == d->W, "%s: upshuffle OH/OW are the GEMM row image", who);
+    } else {
+        OCTA_REQUIRE(d->OH == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                     "%s: OH/OW inconsistent with H/W/k/stride/pad", who);
+    }
+    return OCTA_OK;
+}
+
+extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, octa_stream_t stream) {
+    int rc = check_desc(d, "octa_conv2d_fwd");
+    if (rc) return rc;
+    OCTA_REQUIRE(x && w && y, "octa_conv2d_fwd: null pointer");
+    const int epc = d->dtype == OCTA_F32 ? 4 : 8;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW;
+    a.Cg = d->cin_g_pad; a.CgStride = d->Cin / d->groups; a.Ng = d->Cout / d->groups;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldx; a.xoff = d->xoff; a.ldy = d->ldy; a.yoff = d->yoff;
+    a.M = d->B * d->OH * d->OW; a.Kc = d->KH * d->KW * (a.Cg / epc);
+    a.act = d->act; a.mode = 0; a.upshuffle = d->upshuffle; a.CoutT = d->upshuffle ? d->Cout / 4 : 0;
+    a.vec_store = (a.Ng % 4 == 0) && (d->yoff % 4 == 0) && (d->ldy % 4 == 0) && (!d->upshuffle || a.CoutT % 4 == 0);
+    if (d->upshuffle) OCTA_REQUIRE(d->ldy >= a.CoutT + d->yoff, "octa_conv2d_fwd: ldy too small for upshuffle");
+    else OCTA_REQUIRE(d->ldy >= d->Cout + d->yoff, "octa_conv2d_fwd: ldy %d < yoff+Cout", d->ldy);
+    return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
+                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream);
+}
+
+extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
+    int rc = check_desc(d, "octa_conv2d_dgrad");
+    if (rc) return rc;
+    OCTA_REQUIRE(dy && wt && dx, "octa_conv2d_dgrad: null pointer");
+    OCTA_REQUIRE(!d->upshuffle, "octa_conv2d_dgrad: upshuffle has no dgrad form (use the k2 s2 forward conv)");
+    OCTA_REQUIRE(d->cout_g_pad % 8 == 0 && d->cout_g_pad >= d->Cout / d->groups, "octa_conv2d_dgrad: cout_g_pad invalid");
+    OCTA_REQUIRE(d->ldy % 8 == 0 && d->yoff % 8 == 0, "octa_conv2d_dgrad: ldy/yoff must be multiples of 8");
+    OCTA_REQUIRE(d->groups == 1 || (d->Cout / d->groups) % 8 == 0, "octa_conv2d_dgrad: grouped conv needs Cout/groups %% 8 == 0");
+    OCTA_REQUIRE(d->yoff + (d->groups - 1) * (d->Cout / d->groups) + d->cout_g_pad <= d->ldy, "octa_conv2d_dgrad: padded dy channels exceed ldy");
+    const int epc = d->dtype == OCTA_F32 ? 4 : 8;
+    ConvArgs a;
+    a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx;
+    a.B = d->B; a.H = d->OH; a.W = d->OW;      // gathered tensor = dy
+    a.OH = d->H; a.OW = d->W;                  // rows = dx pixels
+    a.Cg = d->cout_g_pad; a.CgStride = d->Cout / d->groups; a.Ng = d->Cin / d->groups;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldy; a.xoff = d->yoff; a.ldy = d->ldx; a.yoff = d->xoff;
+    a.M = d->B * d->H * d->W; a.Kc = d->KH * d->KW * (a.Cg / epc);
+    a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
+    a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
+    return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
+                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                                   T* __restrict__ out, int Cout_g, int Cin_g, int KH, int KW, int groups, int pad_to, int transposed) {
+    // forward : out[g][n=co][kh][kw][ci<pad_to]   ; data-grad: out[g][n=ci][kh][kw][co<pad_to]
+    const int rows = transposed ? Cin_g : Cout_g;
+    const int64_t total = (int64_t)groups * rows * KH * KW * pad_to;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int inner = (int)(idx % pad_to);
+        int64_t tq = idx / pad_to;
+        const int kw = (int)(tq % KW); tq /= KW;
+        const int kh = (int)(tq % KH); tq /= KH;
+        const int row = (int)(tq % rows);
+        const int g = (int)(tq / rows);
+        float v = 0.f;
+        if (!transposed) { if (inner < Cin_g) v = w[(int64_t)(g * Cout_g + row) * s_o + inner * s_i + kh * s_h + kw * s_w]; }
+        else { if (inner < Cout_g) v = w[(int64_t)(g * Cout_g + inner) * s_o + row * s_i + kh * s_h + kw * s_w]; }
+        DT<T>::st(out + idx, v);
+    }
+}
+
+static int pack_common(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, void* packed, int Cout, int Cin_g,
+                       int KH, int KW, int groups, int pad_to, int dtype, int transposed, hipStream_t st) {
+    OCTA_REQUIRE(w && packed, "octa_pack_weight: null pointer");
+    OCTA_REQUIRE(groups > 0 && Cout % groups == 0, "octa_pack_weight: Cout %% groups");
+    OCTA_REQUIRE(pad_to % 8 == 0 && pad_to >= (transposed ? Cout / groups : Cin_g), "octa_pack_weight: bad padded size %d", pad_to);
+    const int Cout_g = Cout / groups;
+    const int64_t total = (int64_t)groups * (transposed ? Cin_g : Cout_g) * KH * KW * pad_to;
+    const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    if (dtype == OCTA_F32) pack_weight_kernel<float><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (float*)packed, Cout_g, Cin_g, KH, KW, groups, pad_to, transposed);
+    else if (dtype == OCTA_BF16) pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (bf16_t*)packed, Cout_g, Cin_g, KH, KW, groups, pad_to, transposed);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_pack_weight: bad dtype %d", dtype);
+    OCTA_CHECK_LAUNCH("pack_weight");
+    return OCTA_OK;
+}
+extern "C" int octa_pack_weight_fwd(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, void* packed, int Cout,
+                                    int Cin_g, int KH, int KW, int groups, int cin_g_pad, int dtype, octa_stream_t stream) {
+    return pack_common(w, s_o, s_i, s_h, s_w, packed, Cout, Cin_g, KH, KW, groups, cin_g_pad, dtype, 0, (hipStream_t)stream);
+}
+extern "C" int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, void* packed, int Cout,
+                                      int Cin_g, int KH, int KW, int groups, int cout_g_pad, int dtype, octa_stream_t stream) {
+    return pack_common(w, s_o, s_i, s_h, s_w, packed, Cout, Cin_g, KH, KW, groups, cout_g_pad, dtype, 1, (hipStream_t)stream);
+}
+
+// ConvTranspose2d k2 s2 weight (Cin_t, Cout_t, 2, 2) -> GEMM operand [(di*2+dj)*Cout_t + co][ci < cin_pad]
+template <typename T>
+__global__ void pack_convT_kernel(const float* __restrict__ w, int64_t s_ci, int64_t s_co, int64_t s_h, int64_t s_w,
+                                  T* __restrict__ out, int CinT, int CoutT, int cin_pad) {
+    const int64_t total = (int64_t)4 * CoutT * cin_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % cin_pad);
+        const int64_t n = idx / cin_pad;
+        const int co = (int)(n % CoutT);
+        const int dd = (int)(n / CoutT);
+        float v = 0.f;
+        if (ci < CinT) v = w[ci * s_ci + co * s_co + (dd >> 1) * s_h + (dd & 1) * s_w];
+        DT<T>::st(out + idx, v);
+    }
+}
+extern "C" int octa_pack_weight_convT(const float* w, int64_t s_ci, int64_t s_co, int64_t s_h, int64_t s_w, void* packed,
+                                      int CinT, int CoutT, int cin_pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(w && packed && cin_pad % 8 == 0 && cin_pad >= CinT, "octa_pack_weight_convT: bad arguments");
+    const int64_t total = (int64_t)4 * CoutT * cin_pad;
+    const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    if (dtype == OCTA_F32) pack_convT_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_ci, s_co, s_h, s_w, (float*)packed, CinT, CoutT, cin_pad);
+    else if (dtype == OCTA_BF16) pack_convT_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_ci, s_co, s_h, s_w, (bf16_t*)packed, CinT, CoutT, cin_pad);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_pack_weight_convT: bad dtype");
+    OCTA_CHECK_LAUNCH("pack_convT");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: dW[n][k] += sum_m dy[m][n] * im2col(x)[m][k]
+// Both operands have the contraction index m as their SLOW memory axis, so the MFMA fragments
+// are read transposed from LDS: ds_read_b64_tr_b16 for bf16, plain ds_read_b32 for fp32.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const void* x; const void* dy; float* dw;
+    int B, H, W, OH, OW;
+    int Cg, CgReal, CgStride;   // gathered (x) channels per group: padded / real / group stride
+    int Ng;                     // dy channels per group
+    int KH, KW, stride, pad;
+    int ldx, xoff, ldy, yoff;
+    int M, Kpad;                // Kpad = KH*KW*Cg
+    int64_t s_o, s_i, s_h, s_w; // strides of the fp32 gradient tensor, OIHW-logical
+    int splitM, mPerSplit;
+};
+
+template <typename T> struct WgLds;
+template <> struct WgLds<bf16_t> {   // [32 m][128 cols] bf16, 256-B rows, 32-B pair XOR swizzle
+    static constexpr int MT = 32, ROWB = 256;
+    __device__ static __forceinline__ int chunk_off(int m, int c) {   // c: 16-B chunk index in row
+        const int f = (m & 3) | (((m >> 3) & 1) << 2);
+        return m * ROWB + ((((c >> 1) ^ f)) << 5) + ((c & 1) << 4);
+    }
+};
+template <> struct WgLds<float> {    // [16 m][128 cols] fp32, rows padded to 144 floats
+    static constexpr int MT = 16, ROWB = 576;
+    __device__ static __forceinline__ int chunk_off(int m, int c) { return m * ROWB + c * 16; }
+};
+
+template <typename T, int WN, int WK, int TN, int TK>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int MT = WgLds<T>::MT, ROWB = WgLds<T>::ROWB;
+    constexpr int BNn = WN * TN * 16, BKk = WK * TK * 16;
+    static_assert(WN * WK == 4 && BKk == 128, "tile shape");
+    constexpr int PCPR = BNn / EPC;            // P chunks per row
+    constexpr int QCPR = 128 / EPC;            // Q chunks per row
+    constexpr int P_CH = (MT * PCPR + 255) / 256;
+    constexpr int Q_CH = MT * QCPR / 256;      // 2
+    __shared__ __attribute__((aligned(16))) unsigned char sP[2][MT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[2][MT * ROWB];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wn = wave / WK, wk = wave % WK;
+    const int g = blockIdx.z / a.splitM, sp = blockIdx.z % a.splitM;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * BNn;
+    const int mbeg = sp * a.mPerSplit;
+    const int mend = min(a.M, mbeg + a.mPerSplit);
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + g * a.CgStride;
+    const T* __restrict__ dyg = (const T*)a.dy + a.yoff + g * a.Ng;
+
+    // Q: this thread's k-chunk is fixed for the whole block
+    const int qc = t % QCPR;
+    const int qrow0 = t / QCPR;                // rows qrow0 + i*(256/QCPR)
+    const int kq = k0 + qc * EPC;
+    const bool kq_ok = kq < a.Kpad;
+    const int qtap = kq / a.Cg, qcc = kq % a.Cg;
+    const int qkh = qtap / a.KW, qkw = qtap % a.KW;
+    // P
+    const int pc = t % PCPR;
+    const int prow0 = t / PCPR;
+    const bool pn_ok = (n0 + pc * EPC) < a.Ng;
+
+    uint4 rp[P_CH], rq[Q_CH];
+    auto load_tile = [&](int mt0) {
+#pragma unroll
+        for (int i = 0; i < P_CH; ++i) {
+            const int row = prow0 + i * (256 / PCPR);
+            const int m = mt0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < MT && m < mend && pn_ok) v = *(const uint4*)(dyg + (size_t)m * a.ldy + n0 + pc * EPC);
+            rp[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Q_CH; ++i) {
+            const int row = qrow0 + i * (256 / QCPR);
+            const int m = mt0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < mend && kq_ok) {
+                const int ow = m % a.OW;
+                const int tq = m / a.OW;
+                const int oh = tq % a.OH;
+                const int b = tq / a.OH;
+                const int ih = oh * a.stride - a.pad + qkh, iw = ow * a.stride - a.pad + qkw;
+                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                    v = *(const uint4*)(xg + ((size_t)(b * a.H + ih) * a.W + iw) * a.ldx + qcc);
+            }
+            rq[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < P_CH; ++i) {
+            const int row = prow0 + i * (256 / PCPR);
+            if (row < MT) *(uint4*)(sP[buf] + WgLds<T>::chunk_off(row, pc)) = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Q_CH; ++i) {
+            const int row = qrow0 + i * (256 / QCPR);
+            *(uint4*)(sQ[buf] + WgLds<T>::chunk_off(row, qc)) = rq[i];
+        }
+    };
+
+    f32x4_t acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int r = lane & 15, q = lane >> 4;
+    const int nt = (mend - mbeg + MT - 1) / MT;
+    if (nt > 0) {
+        load_tile(mbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nt) load_tile(mbeg + (it + 1) * MT);
+        if constexpr (sizeof(T) == 2) {
+            // transposed fragment: lane (i = r, group q) needs rows m = 8q..8q+7 of column (base + r)
+            uint4 pf[TN], qf[TK];
+            const int mrow = 8 * q + (r >> 2);
+            const int csub = 4 * (r & 3);
+            auto rd = [&](const unsigned char* base, int colbase) -> uint4 {
+                const int col = colbase + csub;
+                const int f1 = (mrow & 3) | (((mrow >> 3) & 1) << 2);
+                const int m2 = mrow + 4;
+                const int f2 = (m2 & 3) | (((m2 >> 3) & 1) << 2);
+                const int o1 = mrow * 256 + (((col >> 4) ^ f1) << 5) + (col & 15) * 2;
+                const int o2 = m2 * 256 + (((col >> 4) ^ f2) << 5) + (col & 15) * 2;
+                s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o1));
+                s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o2));
+                uint2 u1 = __builtin_bit_cast(uint2, v1), u2 = __builtin_bit_cast(uint2, v2);
+                return make_uint4(u1.x, u1.y, u2.x, u2.y);
+            };
+#pragma unroll
+            for (int i = 0; i < TN; ++i) pf[i] = rd(sP[buf], (wn * TN + i) * 16);
+#pragma unroll
+            for (int j = 0; j < TK; ++j) qf[j] = rd(sQ[buf], (wk * TK + j) * 16);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf[i]), __builtin_bit_cast(bf16x8_t, qf[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < MT / 4; ++s) {
+                float pf[TN], qf[TK];
+                const int mrow = 4 * s + q;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) pf[i] = *(const float*)(sP[buf] + mrow * ROWB + ((wn * TN + i) * 16 + r) * 4);
+#pragma unroll
+                for (int j = 0; j < TK; ++j) qf[j] = *(const float*)(sQ[buf] + mrow * ROWB + ((wk * TK + j) * 16 + r) * 4);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[i], qf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (it + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (nt <= 0) return;
+    // D[row = n (q*4+e)][col = k (r)]
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+        const int k = k0 + (wk * TK + j) * 16 + r;
+        if (k >= a.Kpad) continue;
+        const int tap = k / a.Cg, ci = k % a.Cg;
+        if (ci >= a.CgReal) continue;
+        const int kh = tap / a.KW, kw = tap % a.KW;
+        const int64_t koff = ci * a.s_i + kh * a.s_h + kw * a.s_w;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + (wn * TN + i) * 16 + q * 4 + e;
+                if (n < a.Ng) atomicAdd(a.dw + (int64_t)(g * a.Ng + n) * a.s_o + koff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
+    constexpr int MT = WgLds<T>::MT;
+    const int tilesK = cdiv(a.Kpad, 128);
+    const int bnn = a.Ng > 64 ? 128 : (a.Ng > 32 ? 64 : 32);
+    const int tilesN = cdiv(a.Ng, bnn);
+    const int base = tilesK * tilesN * groups;
+    int split = cdiv(1024, base);
+    const int maxsplit = max(1, a.M / (MT * 8));
+    if (split > maxsplit) split = maxsplit;
+    if (split < 1) split = 1;
+    int mps = cdiv(a.M, split);
+    mps = cdiv(mps, MT) * MT;
+    split = cdiv(a.M, mps);
+    a.splitM = split; a.mPerSplit = mps;
+    dim3 grid(tilesK, tilesN, groups * split), block(256);
+    if (bnn == 128) conv_wgrad_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
+    else if (bnn == 64) conv_wgrad_kernel<T, 1, 4, 4, 2><<<grid, block, 0, st>>>(a);
+    else conv_wgrad_kernel<T, 1, 4, 2, 2><<<grid, block, 0, st>>>(a);
+    OCTA_CHECK_LAUNCH("conv_wgrad");
+    return OCTA_OK;
+}
+
+extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, float* dw, const int64_t* dw_strides,
+                                 octa_stream_t stream) {
+    int rc = check_desc(d, "octa_conv2d_wgrad");
+    if (rc) return rc;
+    OCTA_REQUIRE(x && dy && dw && dw_strides, "octa_conv2d_wgrad: null pointer");
+    OCTA_REQUIRE(!d->upshuffle, "octa_conv2d_wgrad: use the adjoint k2 s2 conv for ConvTranspose2d");
+    const int Ng = d->Cout / d->groups;
+    const int ngpad = (Ng + 7) / 8 * 8;
+    OCTA_REQUIRE(d->ldy % 8 == 0 && d->yoff % 8 == 0, "octa_conv2d_wgrad: ldy/yoff must be multiples of 8");
+    OCTA_REQUIRE(d->groups == 1 || Ng % 8 == 0, "octa_conv2d_wgrad: grouped conv needs Cout/groups %% 8 == 0");
+    OCTA_REQUIRE(d->yoff + (d->groups - 1) * Ng + ngpad <= d->ldy, "octa_conv2d_wgrad: dy channel padding exceeds ldy");
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW;
+    a.Cg = d->cin_g_pad; a.CgReal = d->Cin / d->groups; a.CgStride = a.CgReal; a.Ng = Ng;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldx; a.xoff = d->xoff; a.ldy = d->ldy; a.yoff = d->yoff;
+    a.M = d->B * d->OH * d->OW; a.Kpad = d->KH * d->KW * a.Cg;
+    a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
+    return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
+                                : launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// column sum (bias gradients): out[c] += sum_rows src[row*ld + off + c]
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ src, int64_t rows, int C, int ld, int off, float* __restrict__ out, int rows_per_block) {
+    // blockDim = (64 channels, 4 row lanes)
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += 4) s += DT<T>::ld(src + r * ld + off + c);
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out, octa_stream_t stream) {
+    OCTA_REQUIRE(src && out && rows > 0 && C > 0, "octa_colsum: bad arguments");
+    int rpb = (int)cdiv64(rows, 512);
+    if (rpb < 64) rpb = 64;
+    dim3 grid(cdiv(C, 64), (unsigned)cdiv64(rows, rpb)), block(64, 4);
+    if (dtype == OCTA_F32) colsum_kernel<float><<<grid, block, 0, (hipStream_t)stream>>>((const float*)src, rows, C, ld, off, out, rpb);
+    else if (dtype == OCTA_BF16) colsum_kernel<bf16_t><<<grid, block, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, C, ld, off, out, rpb);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_colsum: bad dtype");
+    OCTA_CHECK_LAUNCH("colsum");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout probes (tests): raw MFMA fragment maps and the transposed LDS read
+// ------------------------------------------------------------------------------------------
+__global__ void probe_mfma_bf16(const bf16_t* A /*16x32 row-major*/, const bf16_t* Bm /*32x16 row-major (k,n)*/, float* D /*16x16*/) {
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    bf16_t av[8], bv[8];
+    for (int j = 0; j < 8; ++j) { av[j] = A[r * 32 + 8 * q + j]; bv[j] = Bm[(8 * q + j) * 16 + r]; }
+    uint4 a4 = make_uint4(av[0] | (av[1] << 16), av[2] | (av[3] << 16), av[4] | (av[5] << 16), av[6] | (av[7] << 16));
+    uint4 b4 = make_uint4(bv[0] | (bv[1] << 16), bv[2] | (bv[3] << 16), bv[4] | (bv[5] << 16), bv[6] | (bv[7] << 16));
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a4), __builtin_bit_cast(bf16x8_t, b4), c, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) D[(q * 4 + e) * 16 + r] = c[e];
+}
+__global__ void probe_mfma_f32(const float* A /*16x4*/, const float* Bm /*4x16*/, float* D) {
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * 4 + q], Bm[q * 16 + r], c, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) D[(q * 4 + e) * 16 + r] = c[e];
+}
+// D[n][k] = sum_m P[m][n] * Q[m][k], P,Q: 32 x 16 bf16 row-major, through the transposed read
+__global__ void probe_tr16(const bf16_t* P, const bf16_t* Q, float* D) {
+    __shared__ __attribute__((aligned(16))) bf16_t sP[32 * 16], sQ[32 * 16];
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    for (int i = lane; i < 512; i += 64) { sP[i] = P[i]; sQ[i] = Q[i]; }
+    __syncthreads();
+    const int mrow = 8 * q + (r >> 2), csub = 4 * (r & 3);
+    auto rd = [&](const bf16_t* base) -> uint4 {
+        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + mrow * 16 + csub));
+        s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + (mrow + 4) * 16 + csub));
+        uint2 u1 = __builtin_bit_cast(uint2, v1), u2 = __builtin_bit_cast(uint2, v2);
+        return make_uint4(u1.x, u1.y, u2.x, u2.y);
+    };
+    uint4 pf = rd(sP), qf = rd(sQ);
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, qf), c, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) D[(q * 4 + e) * 16 + r] = c[e];
+}
+extern "C" int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream) {
+    OCTA_REQUIRE(a && b && d, "octa_probe_mfma: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (which == 0) probe_mfma_bf16<<<1, 64, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, d);
+    else if (which == 1) probe_mfma_f32<<<1, 64, 0, st>>>((const float*)a, (const float*)b, d);
+    else if (which == 2) probe_tr16<<<1, 64, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, d);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_probe_mfma: unknown probe %d", which);
+    OCTA_CHECK_LAUNCH("probe");
+    return OCTA_OK;
+}

@@ -1,0 +1,318 @@
+// Loss kernels: fused (softmax +) WeightedPartialCE + Dice, interlayer KL with the nearest
+// up-sampling folded in, LS-GAN.  Algorithmic traffic = one read of each class map; sums are
+// wavefront shuffles -> block LDS -> per-block partials, finalised in double by one block.
+#include "common.hpp"
+
+#define KMAX 8
+
+struct Strides4 { int64_t b, c, h, w; };
+
+extern "C" size_t octa_loss_workspace_floats(int B, int K) {
+    // partials [B][NBLK_MAX][2K+2] + final block (2K weights/counts + 2B dice terms + 8)
+    return (size_t)B * 256 * (2 * KMAX + 2) + 4 * KMAX + 2 * (size_t)B + 16;
+}
+static inline float* loss_final(float* ws, int B) { return ws + (size_t)B * 256 * (2 * KMAX + 2); }
+static inline const float* loss_final(const float* ws, int B) { return ws + (size_t)B * 256 * (2 * KMAX + 2); }
+
+// per pixel: p = softmax(in) or in; partial sums per block:
+//   [0..K)  n_c   = sum ys_c
+//   [K..2K) S_c   = sum ys_c * log(p~_c + 1e-12),  p~ = p*ys (or p when full)
+//   [2K]    inter = sum p*ys      [2K+1] card = sum (p + ys)
+template <int K>
+__global__ __launch_bounds__(256) void wpce_dice_partial_kernel(const float* __restrict__ in, Strides4 si, const float* __restrict__ ys, Strides4 st,
+                                                                int H, int W, int from_logits, int full, float* __restrict__ partial, int nblk) {
+    __shared__ float red[(2 * K + 2) * 16];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    float acc[2 * K + 2];
+#pragma unroll
+    for (int i = 0; i < 2 * K + 2; ++i) acc[i] = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += nblk * 256) {
+        const int h = p / W, w = p % W;
+        float pv[K], tv[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pv[k] = in[b * si.b + k * si.c + h * si.h + w * si.w];
+            tv[k] = ys[b * st.b + k * st.c + h * st.h + w * st.w];
+            mx = fmaxf(mx, pv[k]);
+        }
+        if (from_logits) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { pv[k] = expf(pv[k] - mx); s += pv[k]; }
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int k = 0; k < K; ++k) pv[k] *= inv;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            acc[k] += tv[k];
+            const float pm = full ? pv[k] : pv[k] * tv[k];
+            acc[K + k] += tv[k] * logf(pm + 1e-12f);
+            acc[2 * K] += pv[k] * tv[k];
+            acc[2 * K + 1] += pv[k] + tv[k];
+        }
+    }
+    block_sum<2 * K + 2>(acc, red);
+    if (threadIdx.x == 0) {
+        float* dst = partial + ((size_t)b * nblk + blockIdx.x) * (2 * K + 2);
+#pragma unroll
+        for (int i = 0; i < 2 * K + 2; ++i) dst[i] = acc[i];
+    }
+}
+
+// final[0..K) = w_c ; final[K..2K) = n_c ; final[2K + 2b] = inter_b ; final[2K + 2b + 1] = card_b
+template <int K>
+__global__ void wpce_dice_final_kernel(const float* __restrict__ partial, int B, int nblk, int64_t npix, int reduction_sum, float* __restrict__ fin,
+                                       float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double n[K], S[K];
+    for (int k = 0; k < K; ++k) { n[k] = 0.0; S[k] = 0.0; }
+    double dice = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double inter = 0.0, card = 0.0;
+        for (int j = 0; j < nblk; ++j) {
+            const float* p = partial + ((size_t)b * nblk + j) * (2 * K + 2);
+            for (int k = 0; k < K; ++k) { n[k] += (double)p[k]; S[k] += (double)p[K + k]; }
+            inter += (double)p[2 * K]; card += (double)p[2 * K + 1];
+        }
+        fin[2 * K + 2 * b] = (float)inter;
+        fin[2 * K + 2 * b + 1] = (float)card;
+        dice += 1.0 - 2.0 * inter / (card + 1e-12);
+    }
+    double ntot = 0.0;
+    for (int k = 0; k < K; ++k) ntot += n[k];
+    double l = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const float wk = (float)ntot / ((float)n[k] + 1e-12f);   // fp32 like the reference (losses.py:38)
+        fin[k] = wk;
+        fin[K + k] = (float)n[k];
+        l -= (double)wk * S[k];
+    }
+    out[0] = (float)(reduction_sum ? l : l / (double)npix);
+    out[1] = (float)(dice / (double)B);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void wpce_dice_bwd_kernel(const float* __restrict__ in, Strides4 si, const float* __restrict__ ys, Strides4 st,
+                                                            int B, int H, int W, int from_logits, int full, int reduction_sum,
+                                                            const float* __restrict__ gw, const float* __restrict__ gd,
+                                                            const float* __restrict__ fin, float* __restrict__ din, Strides4 sd) {
+    const int64_t total = (int64_t)B * H * W;
+    const float g_w = gw ? gw[0] : 0.f, g_d = gd ? gd[0] : 0.f;
+    const float scale_w = reduction_sum ? g_w : g_w / (float)total;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int b = (int)(i / ((int64_t)W * H));
+        float pv[K], tv[K], g[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pv[k] = in[b * si.b + k * si.c + h * si.h + w * si.w];
+            tv[k] = ys[b * st.b + k * st.c + h * st.h + w * st.w];
+            mx = fmaxf(mx, pv[k]);
+        }
+        if (from_logits) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { pv[k] = expf(pv[k] - mx); s += pv[k]; }
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int k = 0; k < K; ++k) pv[k] *= inv;
+        }
+        const float inter = fin[2 * K + 2 * b], card = fin[2 * K + 2 * b + 1] + 1e-12f;
+        const float dscale = -g_d * 2.f / (float)B / (card * card);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // wpce: -w_k t_k d/dp log(p t + eps) = -w_k t_k t / (p t + eps)   (full: -w_k t / (p + eps))
+            const float den = full ? (pv[k] + 1e-12f) : (pv[k] * tv[k] + 1e-12f);
+            const float num = full ? tv[k] : tv[k] * tv[k];
+            g[k] = -scale_w * fin[k] * num / den + dscale * (tv[k] * card - inter);
+            dot += g[k] * pv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) din[b * sd.b + k * sd.c + h * sd.h + w * sd.w] = from_logits ? pv[k] * (g[k] - dot) : g[k];
+    }
+}
+
+#define LOSS_K_SWITCH(K, ...) switch (K) { case 2: { constexpr int KK = 2; __VA_ARGS__ } break; case 3: { constexpr int KK = 3; __VA_ARGS__ } break; \
+    case 4: { constexpr int KK = 4; __VA_ARGS__ } break; default: OCTA_FAIL(OCTA_ERR_UNSUPPORTED, "loss: num_classes %d not in 2..4", K); }
+
+extern "C" int octa_wpce_dice_fwd(const float* in, const int64_t* is, const float* ys, const int64_t* yst, int B, int K, int H, int W,
+                                  int from_logits, int full, int reduction_sum, float* out, float* ws, octa_stream_t stream) {
+    OCTA_REQUIRE(in && is && ys && yst && out && ws && B > 0 && H > 0 && W > 0, "octa_wpce_dice_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = cdiv(H * W, 256 * 4);
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    Strides4 si{is[0], is[1], is[2], is[3]}, sy{yst[0], yst[1], yst[2], yst[3]};
+    LOSS_K_SWITCH(K,
+        wpce_dice_partial_kernel<KK><<<dim3(nblk, B), 256, 0, st>>>(in, si, ys, sy, H, W, from_logits, full, ws, nblk);
+        OCTA_CHECK_LAUNCH("wpce_dice_partial");
+        wpce_dice_final_kernel<KK><<<1, 64, 0, st>>>(ws, B, nblk, (int64_t)B * H * W, reduction_sum, loss_final(ws, B), out);
+        OCTA_CHECK_LAUNCH("wpce_dice_final");)
+    return OCTA_OK;
+}
+extern "C" int octa_wpce_dice_bwd(const float* in, const int64_t* is, const float* ys, const int64_t* yst, int B, int K, int H, int W,
+                                  int from_logits, int full, int reduction_sum, const float* g_wpce, const float* g_dice, const float* ws,
+                                  float* din, const int64_t* ds, octa_stream_t stream) {
+    OCTA_REQUIRE(in && is && ys && yst && ws && din && ds, "octa_wpce_dice_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Strides4 si{is[0], is[1], is[2], is[3]}, sy{yst[0], yst[1], yst[2], yst[3]}, sd{ds[0], ds[1], ds[2], ds[3]};
+    const int64_t total = (int64_t)B * H * W;
+    int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    LOSS_K_SWITCH(K,
+        wpce_dice_bwd_kernel<KK><<<blocks, 256, 0, st>>>(in, si, ys, sy, B, H, W, from_logits, full, reduction_sum, g_wpce, g_dice, loss_final(ws, B), din, sd);
+        OCTA_CHECK_LAUNCH("wpce_dice_bwd");)
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ interlayer KL
+#define KL_MAX_MAPS 8
+struct KlMaps { const float* p[KL_MAX_MAPS]; float* d[KL_MAX_MAPS]; int shift[KL_MAX_MAPS]; float w[KL_MAX_MAPS]; int n; float wsum; };
+
+template <int K>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, float* __restrict__ partial) {
+    __shared__ float red[16];
+    const int64_t total = (int64_t)B * H * W;
+    float acc[1] = {0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int b = (int)(i / ((int64_t)W * H));
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float P = basis[(((int64_t)b * K + k) * H + h) * W + w];
+            float m = 0.f;
+            for (int j = 0; j < mp.n; ++j) {
+                const int s = mp.shift[j];
+                const int hs = H >> s, wsz = W >> s;
+                const float Q = mp.p[j][(((int64_t)b * K + k) * hs + (h >> s)) * wsz + (w >> s)];
+                m += logf(Q * mp.w[j] + 1e-12f);
+            }
+            acc[0] += P * (logf(P + 1e-12f) - m / mp.wsum);
+        }
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+__global__ void kl_final_kernel(const float* __restrict__ partial, int n, int64_t npix, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)partial[i];
+    const float l = (float)(s / (double)npix);
+    out[0] = l;
+    out[1] = (l != l) ? 1.f : 0.f;
+}
+extern "C" int octa_interlayer_kl_fwd(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
+                                      float wsum, int B, int K, int H, int W, float* out, float* ws, octa_stream_t stream) {
+    OCTA_REQUIRE(basis && maps && shifts && weights && out && ws && n_maps >= 1 && n_maps <= KL_MAX_MAPS, "octa_interlayer_kl_fwd: bad arguments");
+    KlMaps mp;
+    mp.n = n_maps; mp.wsum = wsum;
+    for (int j = 0; j < n_maps; ++j) {
+        OCTA_REQUIRE(maps[j] && shifts[j] >= 0 && ((H >> shifts[j]) << shifts[j]) == H && ((W >> shifts[j]) << shifts[j]) == W,
+                     "octa_interlayer_kl_fwd: map %d is not an integer power-of-two reduction of the basis", j);
+        mp.p[j] = maps[j]; mp.d[j] = nullptr; mp.shift[j] = shifts[j]; mp.w[j] = weights[j];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * H * W;
+    int blocks = (int)(cdiv64(total, 256 * 4) > 1024 ? 1024 : cdiv64(total, 256 * 4));
+    if (blocks < 1) blocks = 1;
+    LOSS_K_SWITCH(K, kl_fwd_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, ws); OCTA_CHECK_LAUNCH("kl_fwd");)
+    kl_final_kernel<<<1, 64, 0, st>>>(ws, blocks, total, out);
+    OCTA_CHECK_LAUNCH("kl_final");
+    return OCTA_OK;
+}
+
+// d basis: g/N * (log(P+eps) - m + P/(P+eps))
+template <int K>
+__global__ __launch_bounds__(256) void kl_bwd_basis_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, const float* __restrict__ g,
+                                                           float* __restrict__ dbasis) {
+    const int64_t total = (int64_t)B * K * H * W;
+    const float gs = g[0] / (float)((int64_t)B * H * W);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int64_t bk = i / ((int64_t)W * H);
+        const float P = basis[i];
+        float m = 0.f;
+        for (int j = 0; j < mp.n; ++j) {
+            const int s = mp.shift[j];
+            m += logf(mp.p[j][(bk * (H >> s) + (h >> s)) * (W >> s) + (w >> s)] * mp.w[j] + 1e-12f);
+        }
+        dbasis[i] = gs * (logf(P + 1e-12f) - m / mp.wsum + P / (P + 1e-12f));
+    }
+}
+// d map j (gather form, one thread per source pixel): -g/N * w/(w Q + eps)/wsum * sum_{block} P
+__global__ __launch_bounds__(256) void kl_bwd_map_kernel(const float* __restrict__ basis, const float* __restrict__ q, float wgt, float wsum, int shift,
+                                                         int64_t BK, int H, int W, int64_t npix, const float* __restrict__ g, float* __restrict__ dq) {
+    const int hs = H >> shift, wsz = W >> shift, f = 1 << shift;
+    const int64_t total = BK * hs * wsz;
+    const float gs = -g[0] / (float)npix / wsum;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % wsz);
+        const int h = (int)((i / wsz) % hs);
+        const int64_t bk = i / ((int64_t)wsz * hs);
+        float s = 0.f;
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) s += basis[(bk * H + (h << shift) + dy) * W + (w << shift) + dx];
+        dq[i] = gs * s * wgt / (q[i] * wgt + 1e-12f);
+    }
+}
+extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
+                                      float wsum, int B, int K, int H, int W, const float* g, float* dbasis, float* const* dmaps,
+                                      octa_stream_t stream) {
+    OCTA_REQUIRE(basis && maps && shifts && weights && g && dmaps && n_maps >= 1 && n_maps <= KL_MAX_MAPS, "octa_interlayer_kl_bwd: bad arguments");
+    KlMaps mp;
+    mp.n = n_maps; mp.wsum = wsum;
+    for (int j = 0; j < n_maps; ++j) { mp.p[j] = maps[j]; mp.d[j] = dmaps[j]; mp.shift[j] = shifts[j]; mp.w[j] = weights[j]; }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * K * H * W;
+    if (dbasis) {
+        int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+        LOSS_K_SWITCH(K, kl_bwd_basis_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, g, dbasis); OCTA_CHECK_LAUNCH("kl_bwd_basis");)
+    }
+    for (int j = 0; j < n_maps; ++j) {
+        if (!dmaps[j]) continue;
+        const int64_t tj = total >> (2 * shifts[j]);
+        int blocks = (int)(cdiv64(tj, 256) > 4096 ? 4096 : cdiv64(tj, 256));
+        if (blocks < 1) blocks = 1;
+        kl_bwd_map_kernel<<<blocks, 256, 0, st>>>(basis, maps[j], weights[j], wsum, shifts[j], (int64_t)B * K, H, W, (int64_t)B * H * W, g, dmaps[j]);
+        OCTA_CHECK_LAUNCH("kl_bwd_map");
+    }
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ LS-GAN
+__global__ void lsgan_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake, int nr, int nf, int mode, float* __restrict__ out) {
+    __shared__ float red[32];
+    float acc[2] = {0.f, 0.f};
+    if (mode == 1) for (int i = threadIdx.x; i < nr; i += blockDim.x) { const float d = real[i] - 1.f; acc[0] += d * d; }
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) { const float d = fake[i] + (mode == 1 ? 1.f : -1.f); acc[1] += d * d; }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) out[0] = (mode == 1 ? 0.5f * acc[0] / (float)nr : 0.f) + 0.5f * acc[1] / (float)nf;
+}
+__global__ void lsgan_bwd_kernel(const float* __restrict__ real, const float* __restrict__ fake, int nr, int nf, int mode, const float* __restrict__ g,
+                                 float* __restrict__ dr, float* __restrict__ df) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gs = g[0];
+    if (mode == 1 && dr && i < nr) dr[i] = gs * (real[i] - 1.f) / (float)nr;
+    if (df && i < nf) df[i] = gs * (fake[i] + (mode == 1 ? 1.f : -1.f)) / (float)nf;
+}
+extern "C" int octa_lsgan_fwd(const float* real, const float* fake, int n_real, int n_fake, int mode, float* out, octa_stream_t stream) {
+    OCTA_REQUIRE(fake && out && n_fake > 0 && (mode == 0 || (real && n_real > 0)), "octa_lsgan_fwd: bad arguments");
+    lsgan_fwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(real, fake, n_real, n_fake, mode, out);
+    OCTA_CHECK_LAUNCH("lsgan_fwd");
+    return OCTA_OK;
+}
+extern "C" int octa_lsgan_bwd(const float* real, const float* fake, int n_real, int n_fake, int mode, const float* g, float* d_real,
+                              float* d_fake, octa_stream_t stream) {
+    OCTA_REQUIRE(fake && g && n_fake > 0, "octa_lsgan_bwd: bad arguments");
+    const int n = n_real > n_fake ? n_real : n_fake;
+    lsgan_bwd_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(real, fake, n_real, n_fake, mode, g, d_real, d_fake);
+    OCTA_CHECK_LAUNCH("lsgan_bwd");
+    return OCTA_OK;
+}

@@ -1,0 +1,237 @@
+// Training-mode BatchNorm2d on NHWC activations: statistics, apply (+residual, +ReLU), backward.
+// HBM-bound: every kernel moves 16-byte chunks, consecutive lanes on consecutive chunks.
+#include "common.hpp"
+
+// thread t of a 256-thread block owns chunk column (blockIdx.x*TX + t%TX) and row lane t/TX
+struct ColMap { int TX, RY, gridx; };
+static ColMap col_map(int cpr) {
+    ColMap m;
+    if (cpr >= 256) m.TX = 256;
+    else if (256 % cpr == 0) m.TX = cpr;
+    else m.TX = 64;
+    m.RY = 256 / m.TX;
+    m.gridx = cdiv(cpr, m.TX);
+    return m;
+}
+static int rows_per_block(int64_t rows, int RY) {
+    int64_t rpb = cdiv64(rows, 1024);
+    if (rpb < (int64_t)RY * 16) rpb = (int64_t)RY * 16;
+    return (int)rpb;
+}
+
+extern "C" size_t octa_bn_workspace_floats(int64_t rows, int C) {
+    // partials [nby][2][C] with nby <= 1024 (+1 slack), then 2C finalised values
+    return (size_t)(1026) * 2 * (size_t)C + 4 * (size_t)C;
+}
+
+// partial[by][0][c] = sum a, partial[by][1][c] = sum b over the block's rows, where
+//   MODE 0 (stats): a = x, b = x*x
+//   MODE 1 (bwd)  : a = dy', b = dy' * xhat   (dy' = dy masked by y > 0 when relu)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, int ldx, int xoff, const T* __restrict__ dy, int lddy,
+                                                        int dyoff, const T* __restrict__ y, int ldy, int yoff,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                        int64_t rows, int C, int TX, int rpb, float* __restrict__ partial) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC][2]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx;
+    const int cpr = C / EPC;
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    float sa[EPC], sb[EPC], mu[EPC], is[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sa[e] = 0.f; sb[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; }
+    if (col < cpr) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { mu[e] = mean[col * EPC + e]; is[e] = invstd[col * EPC + e]; }
+        }
+        for (int64_t r = r0 + ry; r < r1; r += RY) {
+            float xv[EPC];
+            unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { sa[e] += xv[e]; sb[e] += xv[e] * xv[e]; }
+            } else {
+                float dv[EPC], yv[EPC];
+                unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
+                if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + col * EPC), yv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
+                    sa[e] += d; sb[e] += d * (xv[e] - mu[e]) * is[e];
+                }
+            }
+        }
+    }
+    float* myred = red + ((size_t)ry * TX + cx) * EPC * 2;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { myred[2 * e] = sa[e]; myred[2 * e + 1] = sb[e]; }
+    __syncthreads();
+    // threads 0 .. TX*EPC-1 finish one channel each
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a = 0.f, b = 0.f;
+        for (int yy = 0; yy < RY; ++yy) { a += red[((size_t)yy * TX * EPC + ch) * 2]; b += red[((size_t)yy * TX * EPC + ch) * 2 + 1]; }
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float eps, float momentum,
+                                         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nby; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    const double n = (double)rows;
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+    if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+}
+
+extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off, int dtype, float eps, float momentum, float* mean,
+                             float* invstd, float* running_mean, float* running_var, float* ws, octa_stream_t stream) {
+    OCTA_REQUIRE(x && mean && invstd && ws, "octa_bn_stats: null pointer");
+    OCTA_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && off % 8 == 0, "octa_bn_stats: C/ld/off must be multiples of 8 (C=%d ld=%d off=%d)", C, ld, off);
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_bn_stats: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    const ColMap cm = col_map(C / epc);
+    const int rpb = rows_per_block(rows, cm.RY);
+    const int nby = (int)cdiv64(rows, rpb);
+    dim3 grid(cm.gridx, nby);
+    const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
+    if (dtype == OCTA_F32)
+        bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
+    else
+        bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
+    OCTA_CHECK_LAUNCH("bn_reduce(stats)");
+    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, nby, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    OCTA_CHECK_LAUNCH("bn_stats_finalize");
+    return OCTA_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, int xoff, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const T* __restrict__ res, int ldr, int roff,
+                                                       T* __restrict__ y, int ldy, int yoff, int64_t rows, int cpr, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c0 = (int)(i - r * cpr) * EPC;
+        float v[EPC], rr[EPC];
+        unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), v);
+        if (res) unpack16<T>(*(const uint4*)(res + r * ldr + roff + c0), rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float sc = gamma[c0 + e] * invstd[c0 + e];
+            float o = (v[e] - mean[c0 + e]) * sc + beta[c0 + e];
+            if (res) o += rr[e];
+            if (relu) o = o > 0.f ? o : 0.f;
+            v[e] = o;
+        }
+        *(uint4*)(y + r * ldy + yoff + c0) = pack16<T>(v);
+    }
+}
+
+static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const void* residual, int ldr, int roff, void* y, int ldy, int yoff, int64_t rows,
+                             int C, int dtype, int relu, octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && mean && invstd && gamma && beta, "octa_bn_apply: null pointer");
+    OCTA_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && (!residual || (ldr % 8 == 0 && roff % 8 == 0)),
+                 "octa_bn_apply: C/ld/off must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32)
+        bn_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu);
+    else if (dtype == OCTA_BF16)
+        bn_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_bn_apply: bad dtype");
+    OCTA_CHECK_LAUNCH("bn_apply");
+    return OCTA_OK;
+}
+
+// ws layout after finalize: fin[0][c] = sum dy' / N ; fin[1][c] = sum dy' xhat / N
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float* __restrict__ fin,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nby; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] += (float)s;
+    if (dgamma) dgamma[c] += (float)ss;
+    fin[c] = (float)(s / (double)rows);
+    fin[C + c] = (float)(ss / (double)rows);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, int dyoff, const T* __restrict__ x, int ldx,
+                                                           int xoff, const T* __restrict__ y, int ldy, int yoff,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ fin,
+                                                           T* __restrict__ dx, int lddx, int dxoff, T* __restrict__ dres, int lddr,
+                                                           int droff, int64_t rows, int C, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c0 = (int)(i - r * cpr) * EPC;
+        float dv[EPC], xv[EPC], yv[EPC], o[EPC];
+        unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + c0), dv);
+        unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), xv);
+        if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + c0), yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
+            dv[e] = d;
+            const float is = invstd[c0 + e];
+            const float xh = (xv[e] - mean[c0 + e]) * is;
+            o[e] = gamma[c0 + e] * is * (d - fin[c0 + e] - xh * fin[C + c0 + e]);
+        }
+        *(uint4*)(dx + r * lddx + dxoff + c0) = pack16<T>(o);
+        if (dres) *(uint4*)(dres + r * lddr + droff + c0) = pack16<T>(dv);
+    }
+}
+
+extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
+                           const float* mean, const float* invstd, const float* gamma, void* dx, int lddx, int dxoff, void* dres,
+                           int lddr, int droff, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, int relu, float* ws,
+                           octa_stream_t stream) {
+    OCTA_REQUIRE(dy && x && mean && invstd && gamma && dx && ws, "octa_bn_bwd: null pointer");
+    OCTA_REQUIRE(!relu || y, "octa_bn_bwd: relu needs the forward output");
+    OCTA_REQUIRE(C % 8 == 0 && lddy % 8 == 0 && dyoff % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddx % 8 == 0 && dxoff % 8 == 0,
+                 "octa_bn_bwd: C/ld/off must be multiples of 8");
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_bn_bwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    const ColMap cm = col_map(C / epc);
+    const int rpb = rows_per_block(rows, cm.RY);
+    const int nby = (int)cdiv64(rows, rpb);
+    dim3 grid(cm.gridx, nby);
+    const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
+    float* fin = ws + (size_t)1026 * 2 * C;
+    if (dtype == OCTA_F32)
+        bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, rows, C, cm.TX, rpb, ws);
+    else
+        bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, rows, C, cm.TX, rpb, ws);
+    OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
+    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
+    OCTA_CHECK_LAUNCH("bn_bwd_finalize");
+    if (dtype == OCTA_F32)
+        bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
+    else
+        bn_bwd_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
+    OCTA_CHECK_LAUNCH("bn_bwd_apply");
+    return OCTA_OK;
+}

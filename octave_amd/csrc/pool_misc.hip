@@ -1,0 +1,362 @@
+// Pooling, layout conversion, channel copies, elementwise helpers, fused Adam.  All HBM-bound.
+#include "common.hpp"
+
+static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+#define DISPATCH_T(dtype, NAME, ...)                                                         \
+    if ((dtype) == OCTA_F32) { using T = float; __VA_ARGS__ }                                \
+    else if ((dtype) == OCTA_BF16) { using T = bf16_t; __VA_ARGS__ }                         \
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, NAME ": bad dtype %d", (int)(dtype));
+
+// ------------------------------------------------------------------------------------------ maxpool 3x3 s2 p1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ am, int B, int H,
+                                                          int W, int C, int OH, int OW) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = (int64_t)B * OH * OW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cpr) * EPC;
+        int64_t p = i / cpr;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        float best[EPC];
+        int bi[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+        // scan order kh, kw; first strict maximum wins (ATen max_pool2d CPU tie rule)
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[EPC];
+                unpack16<T>(*(const uint4*)(x + ((int64_t)(b * H + ih) * W + iw) * C + c0), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+                }
+            }
+        }
+        const int64_t o = ((int64_t)(b * OH + oh) * OW + ow) * C + c0;
+        *(uint4*)(y + o) = pack16<T>(best);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) am[o + e] = (uint8_t)bi[e];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ am, T* __restrict__ dx, int B,
+                                                          int H, int W, int C, int OH, int OW) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = (int64_t)B * H * W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cpr) * EPC;
+        int64_t p = i / cpr;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        // windows (oh, ow) with ih = 2*oh - 1 + kh
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = ih + 1 - kh;
+            if (th < 0 || (th & 1)) continue;
+            const int oh = th >> 1;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = iw + 1 - kw;
+                if (tw < 0 || (tw & 1)) continue;
+                const int ow = tw >> 1;
+                if (ow >= OW) continue;
+                const int64_t o = ((int64_t)(b * OH + oh) * OW + ow) * C + c0;
+                float d[EPC];
+                unpack16<T>(*(const uint4*)(dy + o), d);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (am[o + e] == kh * 3 + kw) acc[e] += d[e];
+            }
+        }
+        *(uint4*)(dx + ((int64_t)(b * H + ih) * W + iw) * C + c0) = pack16<T>(acc);
+    }
+}
+extern "C" int octa_maxpool3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int OH, int OW, int dtype,
+                                   octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && argmax && C % 8 == 0, "octa_maxpool3s2_fwd: bad arguments (C %% 8)");
+    OCTA_REQUIRE(OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "octa_maxpool3s2_fwd: OH/OW mismatch");
+    DISPATCH_T(dtype, "octa_maxpool3s2_fwd", maxpool_fwd_kernel<T><<<ew_blocks((int64_t)B * OH * OW * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, argmax, B, H, W, C, OH, OW);)
+    OCTA_CHECK_LAUNCH("maxpool_fwd");
+    return OCTA_OK;
+}
+extern "C" int octa_maxpool3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C, int OH, int OW, int dtype,
+                                   octa_stream_t stream) {
+    OCTA_REQUIRE(dy && dx && argmax && C % 8 == 0, "octa_maxpool3s2_bwd: bad arguments");
+    DISPATCH_T(dtype, "octa_maxpool3s2_bwd", maxpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, argmax, (T*)dx, B, H, W, C, OH, OW);)
+    OCTA_CHECK_LAUNCH("maxpool_bwd");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ avgpool (ATen divisor rules)
+__device__ __forceinline__ float avg_divisor(int o, int k, int s, int p, int L, int cip, int& lo, int& hi) {
+    int st = o * s - p;
+    int en = min(st + k, L + p);
+    const int pool = en - st;
+    lo = max(st, 0);
+    hi = min(en, L);
+    return (float)(cip ? pool : (hi - lo));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH, int OW,
+                                                          int k, int s, int p, int cip) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = (int64_t)B * OH * OW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cpr) * EPC;
+        int64_t q = i / cpr;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int b = (int)(q / OH);
+        int h0, h1, w0, w1;
+        const float dh = avg_divisor(oh, k, s, p, H, cip, h0, h1);
+        const float dw = avg_divisor(ow, k, s, p, W, cip, w0, w1);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int ih = h0; ih < h1; ++ih)
+            for (int iw = w0; iw < w1; ++iw) {
+                float v[EPC];
+                unpack16<T>(*(const uint4*)(x + ((int64_t)(b * H + ih) * W + iw) * C + c0), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += v[e];
+            }
+        const float inv = 1.f / (dh * dw);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] *= inv;
+        *(uint4*)(y + ((int64_t)(b * OH + oh) * OW + ow) * C + c0) = pack16<T>(acc);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW,
+                                                          int k, int s, int p, int cip) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = (int64_t)B * H * W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cpr) * EPC;
+        int64_t q = i / cpr;
+        const int iw = (int)(q % W); q /= W;
+        const int ih = (int)(q % H);
+        const int b = (int)(q / H);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        // windows containing (ih, iw): oh in [ceil((ih+p-k+1)/s), floor((ih+p)/s)]
+        const int oh_hi = min((ih + p) / s, OH - 1), ow_hi = min((iw + p) / s, OW - 1);
+        const int th = ih + p - k + 1, tw = iw + p - k + 1;
+        const int oh_lo = th > 0 ? (th + s - 1) / s : 0, ow_lo = tw > 0 ? (tw + s - 1) / s : 0;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            int h0, h1;
+            const float dh = avg_divisor(oh, k, s, p, H, cip, h0, h1);
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                int w0, w1;
+                const float dw = avg_divisor(ow, k, s, p, W, cip, w0, w1);
+                float d[EPC];
+                unpack16<T>(*(const uint4*)(dy + ((int64_t)(b * OH + oh) * OW + ow) * C + c0), d);
+                const float inv = 1.f / (dh * dw);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += d[e] * inv;
+            }
+        }
+        *(uint4*)(dx + ((int64_t)(b * H + ih) * W + iw) * C + c0) = pack16<T>(acc);
+    }
+}
+extern "C" int octa_avgpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                                int count_include_pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && C % 8 == 0 && k > 0 && stride > 0, "octa_avgpool_fwd: bad arguments");
+    DISPATCH_T(dtype, "octa_avgpool_fwd", avgpool_fwd_kernel<T><<<ew_blocks((int64_t)B * OH * OW * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, B, H, W, C, OH, OW, k, stride, pad, count_include_pad);)
+    OCTA_CHECK_LAUNCH("avgpool_fwd");
+    return OCTA_OK;
+}
+extern "C" int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                                int count_include_pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(dy && dx && C % 8 == 0 && k > 0 && stride > 0, "octa_avgpool_bwd: bad arguments");
+    DISPATCH_T(dtype, "octa_avgpool_bwd", avgpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)dx, B, H, W, C, OH, OW, k, stride, pad, count_include_pad);)
+    OCTA_CHECK_LAUNCH("avgpool_bwd");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ layout conversion
+// 32x32 LDS tile transpose between the (c, hw) planes of NCHW and the (hw, c) rows of NHWC.
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, T* __restrict__ dst,
+                                    int C, int H, int W, int ld, int off, int cpad) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int HW = H * W;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {        // read: x -> pixel (contiguous in NCHW)
+        const int c = c0 + j, p = p0 + threadIdx.x;
+        float v = 0.f;
+        if (c < C && p < HW) v = src[b * sb + c * sc + (int64_t)(p / W) * sh + (int64_t)(p % W) * sw];
+        tile[j][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {        // write: x -> channel (contiguous in NHWC)
+        const int p = p0 + j, c = c0 + threadIdx.x;
+        if (p < HW && c < cpad) DT<T>::st(dst + ((int64_t)b * HW + p) * ld + off + c, c < C ? tile[threadIdx.x][j] : 0.f);
+    }
+}
+extern "C" int octa_nchw_to_nhwc(const float* src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, void* dst, int B, int C, int H, int W,
+                                 int ld, int off, int cpad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(src && dst && B > 0 && C > 0 && cpad >= C && off + cpad <= ld, "octa_nchw_to_nhwc: bad arguments");
+    dim3 grid(cdiv(H * W, 32), cdiv(cpad, 32), B), block(32, 8);
+    DISPATCH_T(dtype, "octa_nchw_to_nhwc", nchw_to_nhwc_kernel<T><<<grid, block, 0, (hipStream_t)stream>>>(src, sb, sc, sh, sw, (T*)dst, C, H, W, ld, off, cpad);)
+    OCTA_CHECK_LAUNCH("nchw_to_nhwc");
+    return OCTA_OK;
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, int off, float* __restrict__ dst, int C, int HW, int accumulate) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (p < HW && c < C) ? DT<T>::ld(src + ((int64_t)b * HW + p) * ld + off + c) : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + threadIdx.x;
+        if (c < C && p < HW) {
+            float* d = dst + ((int64_t)b * C + c) * HW + p;
+            *d = accumulate ? (*d + tile[threadIdx.x][j]) : tile[threadIdx.x][j];
+        }
+    }
+}
+extern "C" int octa_nhwc_to_nchw(const void* src, int ld, int off, int dtype, float* dst, int B, int C, int H, int W, int accumulate,
+                                 octa_stream_t stream) {
+    OCTA_REQUIRE(src && dst && B > 0 && C > 0, "octa_nhwc_to_nchw: bad arguments");
+    dim3 grid(cdiv(H * W, 32), cdiv(C, 32), B), block(32, 8);
+    DISPATCH_T(dtype, "octa_nhwc_to_nchw", nhwc_to_nchw_kernel<T><<<grid, block, 0, (hipStream_t)stream>>>((const T*)src, ld, off, dst, C, H * W, accumulate);)
+    OCTA_CHECK_LAUNCH("nhwc_to_nchw");
+    return OCTA_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ src, int Hs, int Ws, int lds, int soff, T* __restrict__ dst,
+                                                            int Hd, int Wd, int ldd, int doff, int B, int cpr, int accumulate) {
+    constexpr int EPC = DT<T>::EPC;
+    const int64_t total = (int64_t)B * Hd * Wd * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cpr) * EPC;
+        int64_t q = i / cpr;
+        const int w = (int)(q % Wd); q /= Wd;
+        const int h = (int)(q % Hd);
+        const int b = (int)(q / Hd);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (h < Hs && w < Ws) v = *(const uint4*)(src + ((int64_t)(b * Hs + h) * Ws + w) * lds + soff + c0);
+        T* d = dst + ((int64_t)(b * Hd + h) * Wd + w) * ldd + doff + c0;
+        if (accumulate) {
+            float a[EPC], c[EPC];
+            unpack16<T>(v, a);
+            unpack16<T>(*(const uint4*)d, c);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a[e] += c[e];
+            v = pack16<T>(a);
+        }
+        *(uint4*)d = v;
+    }
+}
+extern "C" int octa_copy_channels(const void* src, int Hs, int Ws, int lds, int soff, void* dst, int Hd, int Wd, int ldd, int doff, int B,
+                                  int C, int dtype, int accumulate, octa_stream_t stream) {
+    OCTA_REQUIRE(src && dst && C % 8 == 0 && lds % 8 == 0 && soff % 8 == 0 && ldd % 8 == 0 && doff % 8 == 0, "octa_copy_channels: C/ld/off %% 8");
+    DISPATCH_T(dtype, "octa_copy_channels", copy_channels_kernel<T><<<ew_blocks((int64_t)B * Hd * Wd * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)src, Hs, Ws, lds, soff, (T*)dst, Hd, Wd, ldd, doff, B, C / DT<T>::EPC, accumulate);)
+    OCTA_CHECK_LAUNCH("copy_channels");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float yy = DT<T>::ld(y + i), d = DT<T>::ld(dy + i);
+        float g;
+        switch (act) {
+            case OCTA_ACT_RELU: g = yy > 0.f ? d : 0.f; break;
+            case OCTA_ACT_LEAKY02: g = yy > 0.f ? d : 0.2f * d; break;
+            case OCTA_ACT_SIGMOID: g = d * yy * (1.f - yy); break;
+            case OCTA_ACT_TANH: g = d * (1.f - yy * yy); break;
+            default: g = d;
+        }
+        DT<T>::st(dx + i, g);
+    }
+}
+extern "C" int octa_act_bwd(const void* y, const void* dy, void* dx, int64_t n, int act, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(y && dy && dx && n > 0, "octa_act_bwd: bad arguments");
+    DISPATCH_T(dtype, "octa_act_bwd", act_bwd_kernel<T><<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>((const T*)y, (const T*)dy, (T*)dx, n, act);)
+    OCTA_CHECK_LAUNCH("act_bwd");
+    return OCTA_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = DT<T>::ld(x + i);
+        DT<T>::st(y + i, v > 0.f ? v : 0.f);
+    }
+}
+extern "C" int octa_relu_fwd(const void* x, void* y, int64_t n, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && n > 0, "octa_relu_fwd: bad arguments");
+    DISPATCH_T(dtype, "octa_relu_fwd", relu_kernel<T><<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, n);)
+    OCTA_CHECK_LAUNCH("relu");
+    return OCTA_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) DT<T>::st(o + i, DT<T>::ld(a + i) + DT<T>::ld(b + i));
+}
+extern "C" int octa_add(const void* a, const void* b, void* out, int64_t n, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(a && b && out && n > 0, "octa_add: bad arguments");
+    DISPATCH_T(dtype, "octa_add", add_kernel<T><<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>((const T*)a, (const T*)b, (T*)out, n);)
+    OCTA_CHECK_LAUNCH("add");
+    return OCTA_OK;
+}
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) DT<D>::st(d + i, DT<S>::ld(s + i));
+}
+extern "C" int octa_cast(const void* src, int sd, void* dst, int dd, int64_t n, octa_stream_t stream) {
+    OCTA_REQUIRE(src && dst && n > 0, "octa_cast: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (sd == OCTA_F32 && dd == OCTA_BF16) cast_kernel<float, bf16_t><<<ew_blocks(n), 256, 0, st>>>((const float*)src, (bf16_t*)dst, n);
+    else if (sd == OCTA_BF16 && dd == OCTA_F32) cast_kernel<bf16_t, float><<<ew_blocks(n), 256, 0, st>>>((const bf16_t*)src, (float*)dst, n);
+    else if (sd == OCTA_F32 && dd == OCTA_F32) cast_kernel<float, float><<<ew_blocks(n), 256, 0, st>>>((const float*)src, (float*)dst, n);
+    else if (sd == OCTA_BF16 && dd == OCTA_BF16) cast_kernel<bf16_t, bf16_t><<<ew_blocks(n), 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_cast: bad dtypes");
+    OCTA_CHECK_LAUNCH("cast");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gg = g[i] * gs;
+        const float pp = p[i];
+        if (wd != 0.f) gg += wd * pp;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        const float denom = sqrtf(vv) / bc2s + eps;
+        p[i] = pp - (lr / bc1) * (mm / denom);
+    }
+}
+extern "C" int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale, octa_stream_t stream) {
+    OCTA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "octa_adam_step: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    OCTA_CHECK_LAUNCH("adam");
+    return OCTA_OK;
+}

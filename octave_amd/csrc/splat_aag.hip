@@ -1,0 +1,480 @@
+// Split-attention glue (radix 2) and the adversarial attention gate / 1x1 head.  HBM-bound streaming
+// kernels: 16-byte chunks, wavefront shuffles for the per-pixel and per-channel sums.
+#include "common.hpp"
+
+static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// =========================================================================================== SplAt
+// gap[b][c] += (1/HW) sum_hw (x[b,hw,c] + x[b,hw,C+c]);  grid (colblocks, hw splits, B)
+template <typename T>
+__global__ __launch_bounds__(256) void splat_gap_kernel(const T* __restrict__ x, float* __restrict__ gap, int HW, int C, int TX, int rpb) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    if (col < cpr) {
+        const T* base = x + (int64_t)b * HW * 2 * C + col * EPC;
+        for (int r = r0 + ry; r < r1; r += RY) {
+            float u[EPC], v[EPC];
+            unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C), u);
+            unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C + C), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += u[e] + v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[((size_t)ry * TX + cx) * EPC + e] = s[e];
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a = 0.f;
+        for (int yy = 0; yy < RY; ++yy) a += red[(size_t)yy * TX * EPC + ch];
+        atomicAdd(gap + (int64_t)b * C + c, a * inv);
+    }
+}
+static void splat_map(int cpr, int& TX, int& gridx) {
+    if (cpr >= 256) TX = 256; else if (256 % cpr == 0) TX = cpr; else TX = 64;
+    gridx = cdiv(cpr, TX);
+}
+extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(x && gap && B > 0 && HW > 0 && C % 8 == 0, "octa_splat_gap: bad arguments (C %% 8)");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(gap, 0, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_gap: memset failed");
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int rpb = cdiv(HW, 64);
+    if (rpb < RY * 8) rpb = RY * 8;
+    dim3 grid(gx, cdiv(HW, rpb), B);
+    const size_t sh = (size_t)256 * epc * sizeof(float);
+    if (dtype == OCTA_F32) splat_gap_kernel<float><<<grid, 256, sh, st>>>((const float*)x, gap, HW, C, TX, rpb);
+    else if (dtype == OCTA_BF16) splat_gap_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, gap, HW, C, TX, rpb);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_splat_gap: bad dtype");
+    OCTA_CHECK_LAUNCH("splat_gap");
+    return OCTA_OK;
+}
+
+// out = a0*x[:, :C] + a1*x[:, C:]; grid (hw blocks, B); attention for the sample staged in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void splat_apply_kernel(const T* __restrict__ x, const float* __restrict__ logits, T* __restrict__ out, int HW,
+                                                          int C, int relu, int rpb) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float a0s[];   // [C]
+    const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float l0 = logits[(int64_t)b * 2 * C + c], l1 = logits[(int64_t)b * 2 * C + C + c];
+        a0s[c] = 1.f / (1.f + expf(l1 - l0));
+    }
+    __syncthreads();
+    const int cpr = C / EPC;
+    const int r0 = blockIdx.x * rpb, r1 = min(HW, r0 + rpb);
+    const int64_t total = (int64_t)(r1 - r0) * cpr;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int r = r0 + (int)(i / cpr);
+        const int c0 = (int)(i % cpr) * EPC;
+        float u[EPC], v[EPC];
+        const T* px = x + ((int64_t)b * HW + r) * 2 * C + c0;
+        unpack16<T>(*(const uint4*)px, u);
+        unpack16<T>(*(const uint4*)(px + C), v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float a0 = a0s[c0 + e];
+            float o = a0 * u[e] + (1.f - a0) * v[e];
+            if (relu) o = o > 0.f ? o : 0.f;
+            u[e] = o;
+        }
+        *(uint4*)(out + ((int64_t)b * HW + r) * C + c0) = pack16<T>(u);
+    }
+}
+extern "C" int octa_splat_apply(const void* x, const float* logits, void* out, int B, int HW, int C, int dtype, int relu,
+                                octa_stream_t stream) {
+    OCTA_REQUIRE(x && logits && out && C % 8 == 0 && C <= 8192, "octa_splat_apply: bad arguments");
+    int rpb = cdiv(HW, 128);
+    if (rpb < 8) rpb = 8;
+    dim3 grid(cdiv(HW, rpb), B);
+    const size_t sh = (size_t)C * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) splat_apply_kernel<float><<<grid, 256, sh, st>>>((const float*)x, logits, (float*)out, HW, C, relu, rpb);
+    else if (dtype == OCTA_BF16) splat_apply_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, logits, (bf16_t*)out, HW, C, relu, rpb);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_splat_apply: bad dtype");
+    OCTA_CHECK_LAUNCH("splat_apply");
+    return OCTA_OK;
+}
+
+// phase 0a: da[b][r*C+c] += sum_hw dout' * x_r   (dout' masked by out > 0 when relu)
+template <typename T>
+__global__ __launch_bounds__(256) void splat_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ outp,
+                                                               float* __restrict__ da, int HW, int C, int TX, int rpb, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC][2]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    float s0[EPC], s1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (col < cpr) {
+        for (int r = r0 + ry; r < r1; r += RY) {
+            float d[EPC], o[EPC], u[EPC], v[EPC];
+            const int64_t po = ((int64_t)b * HW + r) * C + col * EPC;
+            unpack16<T>(*(const uint4*)(dout + po), d);
+            if (relu) unpack16<T>(*(const uint4*)(outp + po), o);
+            const T* px = x + ((int64_t)b * HW + r) * 2 * C + col * EPC;
+            unpack16<T>(*(const uint4*)px, u);
+            unpack16<T>(*(const uint4*)(px + C), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                s0[e] += dd * u[e]; s1[e] += dd * v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[(((size_t)ry * TX + cx) * EPC + e) * 2] = s0[e]; red[(((size_t)ry * TX + cx) * EPC + e) * 2 + 1] = s1[e]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a = 0.f, bb = 0.f;
+        for (int yy = 0; yy < RY; ++yy) { a += red[((size_t)yy * TX * EPC + ch) * 2]; bb += red[((size_t)yy * TX * EPC + ch) * 2 + 1]; }
+        atomicAdd(da + (int64_t)b * 2 * C + c, a);
+        atomicAdd(da + (int64_t)b * 2 * C + C + c, bb);
+    }
+}
+// phase 0b: radix-2 softmax backward in place: dl0 = a0 a1 (da0 - da1), dl1 = -dl0
+__global__ void splat_softmax_bwd_kernel(const float* __restrict__ logits, float* __restrict__ da, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    const float l0 = logits[(int64_t)b * 2 * C + c], l1 = logits[(int64_t)b * 2 * C + C + c];
+    const float a0 = 1.f / (1.f + expf(l1 - l0));
+    const float g = a0 * (1.f - a0) * (da[(int64_t)b * 2 * C + c] - da[(int64_t)b * 2 * C + C + c]);
+    da[(int64_t)b * 2 * C + c] = g;
+    da[(int64_t)b * 2 * C + C + c] = -g;
+}
+// phase 1: dx_r = a_r * dout' + dgap / HW
+template <typename T>
+__global__ __launch_bounds__(256) void splat_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outp, const float* __restrict__ logits,
+                                                              const float* __restrict__ dgap, T* __restrict__ dx, int HW, int C, int relu,
+                                                              int rpb) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float sm[];   // a0[C], dg[C]
+    float* a0s = sm;
+    float* dgs = sm + C;
+    const int b = blockIdx.y;
+    const float inv = 1.f / (float)HW;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float l0 = logits[(int64_t)b * 2 * C + c], l1 = logits[(int64_t)b * 2 * C + C + c];
+        a0s[c] = 1.f / (1.f + expf(l1 - l0));
+        dgs[c] = dgap ? dgap[(int64_t)b * C + c] * inv : 0.f;
+    }
+    __syncthreads();
+    const int cpr = C / EPC;
+    const int r0 = blockIdx.x * rpb, r1 = min(HW, r0 + rpb);
+    const int64_t total = (int64_t)(r1 - r0) * cpr;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int r = r0 + (int)(i / cpr);
+        const int c0 = (int)(i % cpr) * EPC;
+        const int64_t po = ((int64_t)b * HW + r) * C + c0;
+        float d[EPC], o[EPC], u[EPC], v[EPC];
+        unpack16<T>(*(const uint4*)(dout + po), d);
+        if (relu) unpack16<T>(*(const uint4*)(outp + po), o);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+            const float a0 = a0s[c0 + e];
+            u[e] = a0 * dd + dgs[c0 + e];
+            v[e] = (1.f - a0) * dd + dgs[c0 + e];
+        }
+        T* px = dx + ((int64_t)b * HW + r) * 2 * C + c0;
+        *(uint4*)px = pack16<T>(u);
+        *(uint4*)(px + C) = pack16<T>(v);
+    }
+}
+extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logits, const void* out, const float* dgap, void* dx,
+                              float* dlogits, int B, int HW, int C, int dtype, int relu, int phase, octa_stream_t stream) {
+    OCTA_REQUIRE(dout && logits && C % 8 == 0 && C <= 4096, "octa_splat_bwd: bad arguments");
+    OCTA_REQUIRE(!relu || out, "octa_splat_bwd: relu needs the forward output");
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_splat_bwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    if (phase == 0) {
+        OCTA_REQUIRE(x && dlogits, "octa_splat_bwd(phase 0): null pointer");
+        if (hipMemsetAsync(dlogits, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bwd: memset failed");
+        int TX, gx;
+        splat_map(C / epc, TX, gx);
+        const int RY = 256 / TX;
+        int rpb = cdiv(HW, 64);
+        if (rpb < RY * 8) rpb = RY * 8;
+        dim3 grid(gx, cdiv(HW, rpb), B);
+        const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
+        if (dtype == OCTA_F32) splat_bwd_reduce_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, (const float*)out, dlogits, HW, C, TX, rpb, relu);
+        else splat_bwd_reduce_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)out, dlogits, HW, C, TX, rpb, relu);
+        OCTA_CHECK_LAUNCH("splat_bwd_reduce");
+        splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
+        OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    } else {
+        OCTA_REQUIRE(dx, "octa_splat_bwd(phase 1): null pointer");
+        int rpb = cdiv(HW, 128);
+        if (rpb < 8) rpb = 8;
+        dim3 grid(cdiv(HW, rpb), B);
+        const size_t sh = (size_t)2 * C * sizeof(float);
+        if (dtype == OCTA_F32) splat_bwd_apply_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)out, logits, dgap, (float*)dx, HW, C, relu, rpb);
+        else splat_bwd_apply_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, logits, dgap, (bf16_t*)dx, HW, C, relu, rpb);
+        OCTA_CHECK_LAUNCH("splat_bwd_apply");
+    }
+    return OCTA_OK;
+}
+
+// =========================================================================================== AAG / head
+// LPP lanes cooperate on one pixel; each lane owns CPL chunks (channels (lp + j*LPP)*EPC ..).
+template <typename T, int K, int CPL>
+__global__ __launch_bounds__(256) void aag_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      T* __restrict__ masked, float* __restrict__ y, int64_t npix, int HW, int C, int LPP, int mode) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float ws[];   // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int lp = threadIdx.x % LPP;
+    const int ppb = 256 / LPP;          // pixels per block iteration
+    const int cpr = C / EPC;
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / LPP; pix < npix + ppb; pix += (int64_t)gridDim.x * ppb) {
+        const bool live = pix < npix;   // keep whole waves in the shuffles
+        float xv[CPL][EPC];
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int ch = lp + j * LPP;
+            if (live && ch < cpr) {
+                unpack16<T>(*(const uint4*)(x + pix * C + ch * EPC), xv[j]);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[k] += xv[j][e] * ws[k * C + ch * EPC + e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) xv[j][e] = 0.f;
+            }
+        }
+        for (int o = LPP >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+        if (!live) continue;
+        float l[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { l[k] = acc[k] + bias[k]; mx = fmaxf(mx, l[k]); }
+        const int64_t b = pix / HW, hw = pix % HW;
+        if (mode == 1) {
+            if (lp == 0)
+#pragma unroll
+                for (int k = 0; k < K; ++k) y[(b * K + k) * HW + hw] = l[k];
+            continue;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { l[k] = expf(l[k] - mx); s += l[k]; }
+        const float inv = 1.f / s;
+        float mask = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { l[k] *= inv; if (k >= 1) mask += l[k]; }
+        if (lp == 0)
+#pragma unroll
+            for (int k = 0; k < K; ++k) y[(b * K + k) * HW + hw] = l[k];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int ch = lp + j * LPP;
+            if (ch < cpr) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) xv[j][e] *= mask;
+                *(uint4*)(masked + pix * C + ch * EPC) = pack16<T>(xv[j]);
+            }
+        }
+    }
+}
+
+template <typename T, int K, int CPL>
+__global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ y,
+                                                      const T* __restrict__ dmasked, const float* __restrict__ dy, T* __restrict__ dx,
+                                                      float* __restrict__ dw, float* __restrict__ dbias, int64_t npix, int HW, int C, int LPP,
+                                                      int mode) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float sm[];   // ws[K][C] then dwred[K][C]
+    float* ws = sm;
+    float* dwred = sm + K * C;
+    for (int i = threadIdx.x; i < K * C; i += 256) { ws[i] = w[i]; dwred[i] = 0.f; }
+    __syncthreads();
+    const int lp = threadIdx.x % LPP;
+    const int ppb = 256 / LPP;
+    const int cpr = C / EPC;
+    float dwa[K][CPL][EPC];
+    float dba[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        dba[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) dwa[k][j][e] = 0.f;
+    }
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / LPP; pix < npix + ppb; pix += (int64_t)gridDim.x * ppb) {
+        const bool live = pix < npix;
+        float xv[CPL][EPC], dm[CPL][EPC];
+        float dmask = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int ch = lp + j * LPP;
+            if (live && ch < cpr) {
+                unpack16<T>(*(const uint4*)(x + pix * C + ch * EPC), xv[j]);
+                if (mode == 0) {
+                    unpack16<T>(*(const uint4*)(dmasked + pix * C + ch * EPC), dm[j]);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) dmask += dm[j][e] * xv[j][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { xv[j][e] = 0.f; dm[j][e] = 0.f; }
+            }
+        }
+        if (mode == 0)
+            for (int o = LPP >> 1; o > 0; o >>= 1) dmask += __shfl_xor(dmask, o, 64);
+        if (!live) continue;
+        const int64_t b = pix / HW, hw = pix % HW;
+        float dl[K];
+        float mask = 1.f;
+        if (mode == 1) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) dl[k] = dy ? dy[(b * K + k) * HW + hw] : 0.f;
+        } else {
+            float yk[K], g[K];
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                yk[k] = y[(b * K + k) * HW + hw];
+                g[k] = (dy ? dy[(b * K + k) * HW + hw] : 0.f) + (k >= 1 ? dmask : 0.f);
+                dot += yk[k] * g[k];
+            }
+            mask = 1.f - yk[0];
+#pragma unroll
+            for (int k = 0; k < K; ++k) dl[k] = yk[k] * (g[k] - dot);
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int ch = lp + j * LPP;
+            if (ch < cpr) {
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float v = mode == 0 ? dm[j][e] * mask : 0.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { v += dl[k] * ws[k * C + ch * EPC + e]; dwa[k][j][e] += dl[k] * xv[j][e]; }
+                    o[e] = v;
+                }
+                *(uint4*)(dx + pix * C + ch * EPC) = pack16<T>(o);
+            }
+        }
+        if (lp == 0)
+#pragma unroll
+            for (int k = 0; k < K; ++k) dba[k] += dl[k];
+    }
+    // block reduction of the weight gradient through LDS atomics, then one global atomic per element
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int ch = lp + j * LPP;
+        if (ch < cpr)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) atomicAdd(&dwred[k * C + ch * EPC + e], dwa[k][j][e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw + i, dwred[i]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(dba[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dbias + k, s);
+    }
+}
+
+static int aag_lpp(int cpr, int& cpl) {
+    int lpp = 1;
+    while (lpp < cpr && lpp < 64) lpp <<= 1;
+    cpl = cdiv(cpr, lpp);
+    return lpp;
+}
+
+template <typename T, int K>
+static int aag_fwd_launch(const void* x, const float* w, const float* bias, void* masked, float* y, int64_t npix, int HW, int C, int mode,
+                          hipStream_t st) {
+    int cpl;
+    const int lpp = aag_lpp(C / DT<T>::EPC, cpl);
+    const int ppb = 256 / lpp;
+    int64_t nb = cdiv64(npix, ppb);
+    if (nb > 4096) nb = 4096;
+    const size_t sh = (size_t)K * C * sizeof(float);
+#define AAG_F(CPLV) aag_fwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, bias, (T*)masked, y, npix, HW, C, lpp, mode)
+    if (cpl <= 1) AAG_F(1); else if (cpl <= 2) AAG_F(2); else if (cpl <= 4) AAG_F(4);
+    else OCTA_FAIL(OCTA_ERR_UNSUPPORTED, "octa_aag_fwd: C=%d too large", C);
+#undef AAG_F
+    OCTA_CHECK_LAUNCH("aag_fwd");
+    return OCTA_OK;
+}
+template <typename T, int K>
+static int aag_bwd_launch(const void* x, const float* w, const float* y, const void* dmasked, const float* dy, void* dx, float* dw, float* dbias,
+                          int64_t npix, int HW, int C, int mode, hipStream_t st) {
+    int cpl;
+    const int lpp = aag_lpp(C / DT<T>::EPC, cpl);
+    const int ppb = 256 / lpp;
+    int64_t nb = cdiv64(npix, (int64_t)ppb * 16);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    const size_t sh = (size_t)2 * K * C * sizeof(float);
+#define AAG_B(CPLV) aag_bwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, y, (const T*)dmasked, dy, (T*)dx, dw, dbias, npix, HW, C, lpp, mode)
+    if (cpl <= 1) AAG_B(1); else if (cpl <= 2) AAG_B(2); else if (cpl <= 4) AAG_B(4);
+    else OCTA_FAIL(OCTA_ERR_UNSUPPORTED, "octa_aag_bwd: C=%d too large", C);
+#undef AAG_B
+    OCTA_CHECK_LAUNCH("aag_bwd");
+    return OCTA_OK;
+}
+
+extern "C" int octa_aag_fwd(const void* x, const float* w, const float* bias, void* masked, float* y, int64_t B, int HW, int C, int K, int dtype,
+                            int mode, octa_stream_t stream) {
+    OCTA_REQUIRE(x && w && bias && y && (mode == 1 || masked), "octa_aag_fwd: null pointer");
+    OCTA_REQUIRE(C % 8 == 0 && K >= 2 && K <= 4, "octa_aag_fwd: needs C %% 8 == 0 and 2 <= num_classes <= 4 (got C=%d K=%d)", C, K);
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_aag_fwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t npix = B * HW;
+#define AAG_K(KV) (dtype == OCTA_F32 ? aag_fwd_launch<float, KV>(x, w, bias, masked, y, npix, HW, C, mode, st) \
+                                     : aag_fwd_launch<bf16_t, KV>(x, w, bias, masked, y, npix, HW, C, mode, st))
+    if (K == 2) return AAG_K(2);
+    if (K == 3) return AAG_K(3);
+    return AAG_K(4);
+#undef AAG_K
+}
+extern "C" int octa_aag_bwd(const void* x, const float* w, const float* y, const void* dmasked, const float* dy, void* dx, float* dw,
+                            float* dbias, int64_t B, int HW, int C, int K, int dtype, int mode, octa_stream_t stream) {
+    OCTA_REQUIRE(x && w && dx && dw && dbias && (mode == 1 || (y && dmasked)), "octa_aag_bwd: null pointer");
+    OCTA_REQUIRE(C % 8 == 0 && K >= 2 && K <= 4, "octa_aag_bwd: needs C %% 8 == 0 and 2 <= num_classes <= 4");
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_aag_bwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t npix = B * HW;
+#define AAG_K(KV) (dtype == OCTA_F32 ? aag_bwd_launch<float, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, st) \
+                                     : aag_bwd_launch<bf16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, st))
+    if (K == 2) return AAG_K(2);
+    if (K == 3) return AAG_K(3);
+    return AAG_K(4);
+#undef AAG_K
+}

@@ -1,0 +1,921 @@
+"""Host side of the hot path: raw wrappers over the C ABI and the torch.autograd.Functions built
+on them.  PyTorch provides device memory, streams and the autograd tape only; every FLOP below
+runs in libocta_hip.so.  Activations are torch tensors of logical shape (B, C, H, W) whose MEMORY
+is NHWC (channels-last) with a per-pixel stride `ld` that is a multiple of 8.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, OCTA_BF16, OCTA_F32, ConvDesc,
+                   OctaError, lib)
+
+Tensor = torch.Tensor
+_I64x4 = ctypes.c_int64 * 4
+
+
+# ----------------------------------------------------------------------------- basics
+def _dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return OCTA_F32
+    if d == torch.bfloat16:
+        return OCTA_BF16
+    raise OctaError(f"unsupported activation dtype {d} (float32 or bfloat16)")
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(t: Tensor):
+    if not t.is_cuda:
+        raise OctaError("octave_amd ops run on the MI355X only: got a CPU tensor (there is no CPU fallback)")
+
+
+def _strides4(t: Tensor):
+    return _I64x4(*t.stride())
+
+
+def round8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def nhwc_empty(B: int, C: int, H: int, W: int, dtype, device, zero: bool = False) -> Tensor:
+    """(B,C,H,W)-shaped tensor with NHWC memory, ld = round8(C); padded channels are zeroed."""
+    ld = round8(C)
+    mk = torch.zeros if (zero or ld != C) else torch.empty
+    buf = mk((B, H, W, ld), dtype=dtype, device=device)
+    t = buf.permute(0, 3, 1, 2)
+    return t if ld == C else t[:, :C]
+
+
+def nhwc_ld(t: Tensor) -> Optional[int]:
+    """Per-pixel stride if `t` (B,C,H,W) is NHWC-strided and chunk-aligned, else None."""
+    if t.dim() != 4:
+        return None
+    B, C, H, W = t.shape
+    s = t.stride()
+    if C > 1 and s[1] != 1:
+        return None
+    if W > 1:
+        ld = s[3]
+    elif H > 1:
+        ld = s[2]
+    elif B > 1:
+        ld = s[0]
+    else:
+        ld = round8(C)
+    if ld < C or ld % 8 != 0:
+        return None
+    if H > 1 and s[2] != W * ld:
+        return None
+    if B > 1 and s[0] != H * W * ld:
+        return None
+    if t.data_ptr() % 16 != 0:
+        return None
+    return ld
+
+
+def to_nhwc(x: Tensor, dtype=None, cpad: Optional[int] = None) -> Tensor:
+    """Any (B,C,H,W) tensor -> NHWC-strided tensor of `dtype` whose buffer holds >= cpad channels
+    (extra channels zero).  No-op when it already qualifies."""
+    _require_gpu(x)
+    dtype = dtype or x.dtype
+    B, C, H, W = x.shape
+    cpad = cpad or C
+    ld = nhwc_ld(x)
+    if ld is not None and x.dtype == dtype and ld >= cpad:
+        return x
+    src = x if x.dtype == torch.float32 else x.float()
+    out = nhwc_empty(B, max(cpad, C), H, W, dtype, x.device, zero=True)
+    base = out if out.shape[1] == C else out[:, :C]
+    ldo = round8(max(cpad, C))
+    lib().octa_nchw_to_nhwc(_p(src), src.stride(0), src.stride(1), src.stride(2), src.stride(3), _p(base), B, C, H, W,
+                            ldo, 0, C, _dt(dtype), _st())
+    return base
+
+
+def to_nchw_f32(x: Tensor) -> Tensor:
+    """NHWC-strided activation -> dense NCHW fp32 tensor."""
+    ld = nhwc_ld(x)
+    if ld is None:
+        return x.float().contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    lib().octa_nhwc_to_nchw(_p(x), ld, 0, _dt(x), _p(out), B, C, H, W, 0, _st())
+    return out
+
+
+def dense_nhwc(x: Tensor) -> Tensor:
+    """NHWC tensor with ld == C (copy when it is a channel slice of a wider buffer)."""
+    x = to_nhwc(x)
+    B, C, H, W = x.shape
+    ld = nhwc_ld(x)
+    if ld == C:
+        return x
+    if C % 8 != 0:
+        raise OctaError(f"dense_nhwc: C={C} is not a multiple of 8")
+    out = nhwc_empty(B, C, H, W, x.dtype, x.device)
+    lib().octa_copy_channels(_p(x), H, W, ld, 0, _p(out), H, W, C, 0, B, C, _dt(x), 0, _st())
+    return out
+
+
+# ----------------------------------------------------------------------------- packed weights
+_WEIGHT_EPOCH = 0
+_PACK_CACHE = {}
+
+
+def bump_weight_epoch():
+    """Call after parameters were modified outside autograd's version counter (fused optimiser)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+    _PACK_CACHE.clear()
+
+
+def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
+    key = (w.data_ptr(), kind, dtype, groups, pad_to)
+    tag = (w._version, _WEIGHT_EPOCH, tuple(w.shape), tuple(w.stride()))
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    L = lib()
+    wd = w.detach()
+    if wd.dtype != torch.float32:
+        wd = wd.float()
+    O, Ig, KH, KW = wd.shape
+    s = wd.stride()
+    if kind == "fwd":
+        # already [O][KH][KW][Ig] fp32 with Ig % 8 == 0 -> use the parameter storage itself
+        if (dtype == torch.float32 and pad_to == Ig and s[1] == 1 and (KW == 1 or s[3] == Ig) and (KH == 1 or s[2] == KW * Ig)
+                and s[0] == KH * KW * Ig and wd.data_ptr() % 16 == 0):
+            out = wd
+        else:
+            out = torch.empty((O * KH * KW * pad_to,), dtype=dtype, device=w.device)
+            L.octa_pack_weight_fwd(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, groups, pad_to, _dt(dtype), _st())
+    elif kind == "dgrad":
+        out = torch.empty((groups * Ig * KH * KW * pad_to,), dtype=dtype, device=w.device)
+        L.octa_pack_weight_dgrad(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, groups, pad_to, _dt(dtype), _st())
+    elif kind == "convT":      # w: (CinT, CoutT, 2, 2)
+        out = torch.empty((4 * Ig * pad_to,), dtype=dtype, device=w.device)
+        L.octa_pack_weight_convT(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, pad_to, _dt(dtype), _st())
+    else:
+        raise ValueError(kind)
+    _PACK_CACHE[key] = (tag, out)
+    return out
+
+
+# ----------------------------------------------------------------------------- raw conv ops
+def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dtype, act=ACT_NONE, upshuffle=0) -> ConvDesc:
+    d = ConvDesc()
+    d.B, d.H, d.W, d.OH, d.OW = B, H, W, OH, OW
+    d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.groups = Cin, Cout, KH, KW, stride, pad, groups
+    d.cin_g_pad = round8(Cin // groups)
+    d.cout_g_pad = round8(Cout // groups)
+    d.ldx, d.xoff, d.ldy, d.yoff = ldx, 0, ldy, 0
+    d.dtype, d.act, d.upshuffle = _dt(dtype), act, upshuffle
+    return d
+
+
+def _conv_geometry(x: Tensor, w: Tensor, stride: int, pad: int):
+    B, Cin, H, W = x.shape
+    Cout, Cin_g, KH, KW = w.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    return B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW
+
+
+def _conv_input(x: Tensor, cin_g_pad: int, groups: int) -> Tuple[Tensor, int]:
+    """NHWC view of x whose buffer is readable for the padded channel count."""
+    need = cin_g_pad if groups == 1 else x.shape[1]
+    x = to_nhwc(x, cpad=need)
+    ld = nhwc_ld(x)
+    if ld < need:
+        x = to_nhwc(x.contiguous(), cpad=need)
+        ld = nhwc_ld(x)
+    return x, ld
+
+
+def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, groups: int, act: int = ACT_NONE,
+                 out: Optional[Tensor] = None) -> Tensor:
+    B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
+    if Cin != Cin_g * groups:
+        raise OctaError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
+    x, ldx = _conv_input(x, round8(Cin_g), groups)
+    y = out if out is not None else nhwc_empty(B, Cout, OH, OW, x.dtype, x.device)
+    ldy = nhwc_ld(y)
+    d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
+    wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
+    lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+    return y
+
+
+def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int) -> Tensor:
+    B, Cin, H, W = xshape
+    Cout, Cin_g, KH, KW = w.shape
+    OH, OW = dy.shape[2], dy.shape[3]
+    need = round8(Cout // groups) if groups == 1 else Cout
+    dy = to_nhwc(dy, cpad=need)
+    ldy = nhwc_ld(dy)
+    if ldy < need:
+        dy = to_nhwc(dy.contiguous(), cpad=need)
+        ldy = nhwc_ld(dy)
+    dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device)
+    d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
+    wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
+    lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
+    return dx
+
+
+def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, groups: int, dw: Optional[Tensor] = None) -> Tensor:
+    B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
+    x, ldx = _conv_input(x, round8(Cin_g), groups)
+    need = round8(Cout // groups) if groups == 1 else Cout
+    dy = to_nhwc(dy, dtype=x.dtype, cpad=need)
+    ldy = nhwc_ld(dy)
+    if dw is None:
+        dw = torch.zeros_like(w, dtype=torch.float32)
+    d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
+    lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _st())
+    return dw
+
+
+def raw_colsum(t: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """sum over (B,H,W) of an NHWC tensor -> fp32 [C]."""
+    t = to_nhwc(t)
+    B, C, H, W = t.shape
+    if out is None:
+        out = torch.zeros((C,), dtype=torch.float32, device=t.device)
+    lib().octa_colsum(_p(t), B * H * W, C, nhwc_ld(t), 0, _dt(t), _p(out), _st())
+    return out
+
+
+def raw_act_bwd(y: Tensor, dy: Tensor, act: int) -> Tensor:
+    y = dense_or_same(y)
+    dy = to_nhwc(dy, dtype=y.dtype)
+    if nhwc_ld(dy) != nhwc_ld(y):
+        dy = _match_ld(dy, nhwc_ld(y))
+    B, C, H, W = y.shape
+    ld = nhwc_ld(y)
+    dx = nhwc_empty(B, C, H, W, y.dtype, y.device)
+    lib().octa_act_bwd(_p(y), _p(dy), _p(dx), B * H * W * ld, act, _dt(y), _st())
+    return dx
+
+
+def dense_or_same(t: Tensor) -> Tensor:
+    return to_nhwc(t)
+
+
+def _match_ld(t: Tensor, ld: int) -> Tensor:
+    """Copy an NHWC tensor into a fresh buffer with per-pixel stride `ld` (pad zeroed)."""
+    B, C, H, W = t.shape
+    out = torch.zeros((B, H, W, ld), dtype=t.dtype, device=t.device).permute(0, 3, 1, 2)[:, :C]
+    src = to_nchw_f32(t)
+    lib().octa_nchw_to_nhwc(_p(src), src.stride(0), src.stride(1), src.stride(2), src.stride(3), _p(out), B, C, H, W, ld, 0, C,
+                            _dt(t), _st())
+    return out
+
+
+# ----------------------------------------------------------------------------- raw BN
+def _bn_ws(rows: int, C: int, device) -> Tensor:
+    n = lib().octa_bn_workspace_floats(rows, C)
+    return torch.empty((n,), dtype=torch.float32, device=device)
+
+
+def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv: Optional[Tensor], momentum: float, eps: float,
+               training: bool, relu: bool, residual: Optional[Tensor] = None):
+    x = to_nhwc(x)
+    B, C, H, W = x.shape
+    rows = B * H * W
+    L = lib()
+    if training:
+        if rows <= 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        L.octa_bn_stats(_p(x), rows, C, nhwc_ld(x), 0, _dt(x), eps, momentum, _p(mean), _p(invstd), _p(rm), _p(rv),
+                        _p(_bn_ws(rows, C, x.device)), _st())
+    else:
+        mean = rm.float()
+        invstd = torch.rsqrt(rv.float() + eps)
+    y = nhwc_empty(B, C, H, W, x.dtype, x.device)
+    res = None
+    if residual is not None:
+        res = to_nhwc(residual, dtype=x.dtype)
+    L.octa_bn_apply(_p(x), nhwc_ld(x), 0, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
+                    _p(y), nhwc_ld(y), 0, rows, C, _dt(x), int(relu), _st())
+    return y, mean, invstd, x
+
+
+def raw_bn_bwd(dy: Tensor, x: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
+               want_dres: bool, dgamma: Tensor, dbeta: Tensor):
+    B, C, H, W = x.shape
+    rows = B * H * W
+    dy = to_nhwc(dy, dtype=x.dtype)
+    dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
+    dres = nhwc_empty(B, C, H, W, x.dtype, x.device) if want_dres else None
+    lib().octa_bn_bwd(_p(dy), nhwc_ld(dy), 0, _p(x), nhwc_ld(x), 0, _p(y), nhwc_ld(y) if y is not None else 0, 0, _p(mean), _p(invstd),
+                      _p(gamma), _p(dx), nhwc_ld(dx), 0, _p(dres), nhwc_ld(dres) if dres is not None else 0, 0, _p(dgamma), _p(dbeta),
+                      rows, C, _dt(x), int(relu), _p(_bn_ws(rows, C, x.device)), _st())
+    return dx, dres
+
+
+# ============================================================================= autograd Functions
+class Conv2dFn(Function):
+    """nn.Conv2d (+ fused activation).  Weight OIHW-logical fp32 parameter, any strides."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, groups, act):
+        _require_gpu(x)
+        y = raw_conv_fwd(x, w, bias, stride, pad, groups, act)
+        ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, groups, act, xshape = ctx.cfg
+        if act != ACT_NONE:
+            dy = raw_act_bwd(y, dy, act)
+        dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups) if ctx.needs_input_grad[0] else None
+        dw = raw_conv_wgrad(x, dy, w, stride, pad, groups) if ctx.needs_input_grad[1] else None
+        db = raw_colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE):
+    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act)
+
+
+class ConvTranspose2x2Fn(Function):
+    """nn.ConvTranspose2d(k=2, s=2) + bias as an up-shuffle GEMM (extra/resnest.py:50)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_gpu(x)
+        B, Cin, H, W = x.shape
+        CinT, CoutT = w.shape[0], w.shape[1]
+        if Cin != CinT or tuple(w.shape[2:]) != (2, 2):
+            raise OctaError("conv_transpose2x2: weight must be (Cin, Cout, 2, 2)")
+        x, ldx = _conv_input(x, round8(Cin), 1)
+        y = nhwc_empty(B, CoutT, 2 * H, 2 * W, x.dtype, x.device)
+        d = _desc(B, H, W, H, W, Cin, 4 * CoutT, 1, 1, 1, 0, 1, ldx, nhwc_ld(y), x.dtype, ACT_NONE, upshuffle=1)
+        wp = _packed(w, "convT", x.dtype, 1, d.cin_g_pad)
+        lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        # the adjoint is a plain conv k2 s2 p0 from the (2H,2W,CoutT) image to (H,W,CinT) whose OIHW weight is w itself
+        dx = raw_conv_fwd(dy, w, None, 2, 0, 1) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1)
+        db = raw_colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, w, bias):
+    return ConvTranspose2x2Fn.apply(x, w, bias)
+
+
+class BatchNormFn(Function):
+    """Training/eval BatchNorm2d with fused ReLU and residual add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, momentum, eps, training, relu, residual):
+        _require_gpu(x)
+        y, mean, invstd, xn = raw_bn_fwd(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual)
+        ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
+        ctx.save_for_backward(xn, y if relu else None, mean, invstd, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        if not ctx.training:
+            raise OctaError("BatchNorm backward in eval mode is not part of the hot path")
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(gamma)
+        dx, dres = raw_bn_bwd(dy, x, y, mean, invstd, gamma, ctx.relu, ctx.has_res and ctx.needs_input_grad[9], dgamma, dbeta)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+
+
+def batch_norm(x, gamma, beta, rm, rv, momentum=0.1, eps=1e-5, training=True, relu=False, residual=None):
+    return BatchNormFn.apply(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual)
+
+
+class MaxPool3s2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = dense_nhwc(x)
+        B, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = nhwc_empty(B, C, OH, OW, x.dtype, x.device)
+        am = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
+        lib().octa_maxpool3s2_fwd(_p(x), _p(y), _p(am), B, H, W, C, OH, OW, _dt(x), _st())
+        ctx.save_for_backward(am)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        dy = dense_nhwc(dy)
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        lib().octa_maxpool3s2_bwd(_p(dy), _p(am), _p(dx), B, H, W, C, dy.shape[2], dy.shape[3], _dt(dy), _st())
+        return dx
+
+
+def max_pool3s2(x):
+    return MaxPool3s2Fn.apply(x)
+
+
+class AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, ceil_mode, count_include_pad):
+        x = dense_nhwc(x)
+        B, C, H, W = x.shape
+
+        def osz(L):
+            num = L + 2 * pad - k
+            o = (-(-num // stride) if ceil_mode else num // stride) + 1
+            if ceil_mode and (o - 1) * stride >= L + pad:
+                o -= 1
+            return o
+        OH, OW = osz(H), osz(W)
+        y = nhwc_empty(B, C, OH, OW, x.dtype, x.device)
+        lib().octa_avgpool_fwd(_p(x), _p(y), B, H, W, C, OH, OW, k, stride, pad, int(count_include_pad), _dt(x), _st())
+        ctx.cfg = (B, C, H, W, OH, OW, k, stride, pad, int(count_include_pad))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, C, H, W, OH, OW, k, stride, pad, cip = ctx.cfg
+        dy = dense_nhwc(dy)
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        lib().octa_avgpool_bwd(_p(dy), _p(dx), B, H, W, C, OH, OW, k, stride, pad, cip, _dt(dy), _st())
+        return dx, None, None, None, None, None
+
+
+def avg_pool(x, k, stride, pad=0, ceil_mode=False, count_include_pad=True):
+    return AvgPoolFn.apply(x, k, stride, pad, ceil_mode, count_include_pad)
+
+
+class CatFn(Function):
+    """torch.cat((a, b), dim=1) followed by an optional bottom/right crop (compose.py:141-147)."""
+
+    @staticmethod
+    def forward(ctx, a, b, Hc, Wc):
+        a, b = to_nhwc(a), to_nhwc(b, dtype=a.dtype)
+        B, Ca, Ha, Wa = a.shape
+        Cb = b.shape[1]
+        if Ca % 8 or Cb % 8:
+            raise OctaError("cat: channel counts must be multiples of 8")
+        out = nhwc_empty(B, Ca + Cb, Hc, Wc, a.dtype, a.device)
+        L = lib()
+        L.octa_copy_channels(_p(a), Ha, Wa, nhwc_ld(a), 0, _p(out), Hc, Wc, Ca + Cb, 0, B, Ca, _dt(a), 0, _st())
+        L.octa_copy_channels(_p(b), b.shape[2], b.shape[3], nhwc_ld(b), 0, _p(out[:, Ca:]), Hc, Wc, Ca + Cb, 0, B, Cb, _dt(a), 0, _st())
+        ctx.cfg = (Ca, Cb, tuple(a.shape), tuple(b.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        Ca, Cb, sa, sb = ctx.cfg
+        d = to_nhwc(d)
+        B, _, Hc, Wc = d.shape
+        ld = nhwc_ld(d)
+
+        def part(off, C, shape):
+            if shape[2] == Hc and shape[3] == Wc:
+                return d[:, off:off + C]                       # zero-copy channel slice
+            g = nhwc_empty(B, C, shape[2], shape[3], d.dtype, d.device)   # un-crop: zero fill
+            lib().octa_copy_channels(_p(d[:, off:off + C]), Hc, Wc, ld, 0, _p(g), shape[2], shape[3], C, 0, B, C, _dt(d), 0, _st())
+            return g
+        return part(0, Ca, sa), part(Ca, Cb, sb), None, None
+
+
+def cat_crop(a, b, Hc=None, Wc=None):
+    Hc = a.shape[2] if Hc is None else Hc
+    Wc = a.shape[3] if Wc is None else Wc
+    return CatFn.apply(a, b, Hc, Wc)
+
+
+class PadBRFn(Function):
+    """F.pad(x, (0, pw, 0, ph)) with zeros (compose.py:125-130)."""
+
+    @staticmethod
+    def forward(ctx, x, ph, pw):
+        x = to_nhwc(x)
+        B, C, H, W = x.shape
+        out = nhwc_empty(B, C, H + ph, W + pw, x.dtype, x.device)
+        lib().octa_copy_channels(_p(x), H, W, nhwc_ld(x), 0, _p(out), H + ph, W + pw, C, 0, B, C, _dt(x), 0, _st())
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        B, C, H, W = ctx.shape
+        d = to_nhwc(d)
+        g = nhwc_empty(B, C, H, W, d.dtype, d.device)
+        lib().octa_copy_channels(_p(d), d.shape[2], d.shape[3], nhwc_ld(d), 0, _p(g), H, W, C, 0, B, C, _dt(d), 0, _st())
+        return g, None, None
+
+
+def pad_bottom_right(x, ph, pw):
+    return PadBRFn.apply(x, ph, pw)
+
+
+class SplatTailFn(Function):
+    """Everything of SplAtConv2d.forward after bn0+relu (extra/resnest.py:106-138), radix 2:
+    radix-sum GAP -> fc1 -> bn1 -> relu -> fc2 -> radix softmax -> weighted sum [-> relu].
+    One Function so that the backward can run its two streaming passes around the micro-net."""
+
+    @staticmethod
+    def forward(ctx, xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu):
+        xr = dense_nhwc(xr)
+        B, C2, H, W = xr.shape
+        C, HW = C2 // 2, H * W
+        L = lib()
+        gap = torch.empty((B, C), dtype=torch.float32, device=xr.device)
+        L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), _st())
+        gap4 = gap.view(B, 1, 1, C).permute(0, 3, 1, 2)                     # (B,C,1,1) NHWC fp32
+        h1 = raw_conv_fwd(gap4, fc1_w, fc1_b, 1, 0, cardinality)
+        h2, mean1, invstd1, h1n = raw_bn_fwd(h1, g1, b1, rm1, rv1, momentum, eps, training, True)
+        logits4 = raw_conv_fwd(h2, fc2_w, fc2_b, 1, 0, cardinality)         # (B,2C,1,1)
+        logits = logits4.permute(0, 2, 3, 1).reshape(B, C2)
+        out = nhwc_empty(B, C, H, W, xr.dtype, xr.device)
+        L.octa_splat_apply(_p(xr), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
+        ctx.cfg = (cardinality, training, relu, B, C, H, W)
+        ctx.save_for_backward(xr, out if relu else None, logits, gap4, h1n, h2, mean1, invstd1, g1, fc1_w, fc2_w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        xr, out, logits, gap4, h1, h2, mean1, invstd1, g1, fc1_w, fc2_w = ctx.saved_tensors
+        card, training, relu, B, C, H, W = ctx.cfg
+        HW = H * W
+        L = lib()
+        dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
+        dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=xr.device)
+        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, _st())
+        dl4 = dlogits.view(B, 1, 1, 2 * C).permute(0, 3, 1, 2)
+        d_fc2_w = raw_conv_wgrad(h2, dl4, fc2_w, 1, 0, card)
+        d_fc2_b = raw_colsum(dl4)
+        dh2 = raw_conv_dgrad(dl4, fc2_w, tuple(h2.shape), 1, 0, card)
+        dg1 = torch.zeros_like(g1)
+        db1 = torch.zeros_like(g1)
+        if not training:
+            raise OctaError("SplAt backward in eval mode is not part of the hot path")
+        dh1, _ = raw_bn_bwd(dh2, h1, h2, mean1, invstd1, g1, True, False, dg1, db1)
+        d_fc1_w = raw_conv_wgrad(gap4, dh1, fc1_w, 1, 0, card)
+        d_fc1_b = raw_colsum(dh1)
+        dgap4 = raw_conv_dgrad(dh1, fc1_w, tuple(gap4.shape), 1, 0, card)
+        dgap = dgap4.permute(0, 2, 3, 1).reshape(B, C)
+        if not dgap.is_contiguous():
+            dgap = dgap.contiguous()
+        dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, xr.device)
+        L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, _st())
+        return dx, d_fc1_w, d_fc1_b, dg1, db1, None, None, d_fc2_w, d_fc2_b, None, None, None, None, None
+
+
+def splat_tail(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum=0.1, eps=1e-5, training=True, relu=False):
+    return SplatTailFn.apply(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu)
+
+
+class AagFn(Function):
+    """AdversarialAttentionGate.forward (segmentor/blocks.py:38-46) / 1x1 head (compose.py:181)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mode):
+        x = dense_nhwc(x)
+        B, C, H, W = x.shape
+        K = w.shape[0]
+        w2 = w.detach().reshape(K, C)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        y = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+        masked = nhwc_empty(B, C, H, W, x.dtype, x.device) if mode == 0 else None
+        lib().octa_aag_fwd(_p(x), _p(w2), _p(bias), _p(masked), _p(y), B, H * W, C, K, _dt(x), mode, _st())
+        ctx.mode = mode
+        ctx.wshape = tuple(w.shape)
+        ctx.save_for_backward(x, w2, y if mode == 0 else None)
+        if mode == 0:
+            return masked, y
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        x, w2, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        K = w2.shape[0]
+        if ctx.mode == 0:
+            dmasked, dy = grads
+            if dmasked is None:
+                dmasked = torch.zeros_like(x)
+            dmasked = dense_nhwc(to_nhwc(dmasked, dtype=x.dtype))
+        else:
+            dmasked, dy = None, grads[0]
+        if dy is not None:
+            dy = dy.float().contiguous()
+        dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
+        dw = torch.zeros((K, C), dtype=torch.float32, device=x.device)
+        db = torch.zeros((K,), dtype=torch.float32, device=x.device)
+        lib().octa_aag_bwd(_p(x), _p(w2), _p(y), _p(dmasked), _p(dy), _p(dx), _p(dw), _p(db), B, H * W, C, K, _dt(x), ctx.mode, _st())
+        return dx, dw.view(ctx.wshape), db, None
+
+
+def attention_gate(x, w, bias):
+    return AagFn.apply(x, w, bias, 0)
+
+
+def head_1x1(x, w, bias):
+    return AagFn.apply(x, w, bias, 1)
+
+
+# ----------------------------------------------------------------------------- losses
+class WpceDiceFn(Function):
+    """out[0] = WeightedPartialCE(manual=True), out[1] = DiceLoss, on probabilities or (fused
+    softmax) on logits; segmentor/losses.py:26-61, 70-74."""
+
+    @staticmethod
+    def forward(ctx, inp, ys, from_logits, full, reduction_sum):
+        _require_gpu(inp)
+        if inp.dtype != torch.float32:
+            inp = inp.float()
+        if ys.dtype != torch.float32:
+            ys = ys.float()
+        B, K, H, W = inp.shape
+        L = lib()
+        ws = torch.empty((L.octa_loss_workspace_floats(B, K),), dtype=torch.float32, device=inp.device)
+        out = torch.empty((2,), dtype=torch.float32, device=inp.device)
+        L.octa_wpce_dice_fwd(_p(inp), _strides4(inp), _p(ys), _strides4(ys), B, K, H, W, int(from_logits), int(full), int(reduction_sum),
+                             _p(out), _p(ws), _st())
+        ctx.cfg = (int(from_logits), int(full), int(reduction_sum))
+        ctx.save_for_backward(inp, ys, ws)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        inp, ys, ws = ctx.saved_tensors
+        B, K, H, W = inp.shape
+        g = g.float().contiguous()
+        din = torch.empty((B, K, H, W), dtype=torch.float32, device=inp.device)
+        fl, full, rs = ctx.cfg
+        lib().octa_wpce_dice_bwd(_p(inp), _strides4(inp), _p(ys), _strides4(ys), B, K, H, W, fl, full, rs, g.data_ptr(),
+                                 g.data_ptr() + 4, _p(ws), _p(din), _strides4(din), _st())
+        return din, None, None, None, None
+
+
+def wpce_dice(inp, ys, from_logits=False, full=False, reduction_sum=False):
+    return WpceDiceFn.apply(inp, ys, from_logits, full, reduction_sum)
+
+
+class InterlayerKLFn(Function):
+    """InterlayerDivergence KLD/mean (segmentor/losses.py:111-147) with the nearest up-sampling fused."""
+
+    @staticmethod
+    def forward(ctx, weights, stop_gradient, basis, *maps):
+        _require_gpu(basis)
+        basis = basis.float().contiguous()
+        B, K, H, W = basis.shape
+        use = [(m.float().contiguous(), float(w)) for m, w in zip(maps, weights) if w != 0]
+        shifts = []
+        for m, _ in use:
+            f = H // m.shape[2]
+            if f < 1 or f & (f - 1) or m.shape[2] * f != H or m.shape[3] * f != W:
+                raise OctaError(f"interlayer KL: map {tuple(m.shape)} is not a power-of-two reduction of {tuple(basis.shape)}")
+            shifts.append(f.bit_length() - 1)
+        n = len(use)
+        ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m, _ in use])
+        sh = (ctypes.c_int * n)(*shifts)
+        wt = (ctypes.c_float * n)(*[w for _, w in use])
+        wsum = float(sum(weights))
+        out = torch.empty((2,), dtype=torch.float32, device=basis.device)
+        ws = torch.empty((1024,), dtype=torch.float32, device=basis.device)
+        lib().octa_interlayer_kl_fwd(_p(basis), ptrs, sh, wt, n, wsum, B, K, H, W, _p(out), _p(ws), _st())
+        ctx.cfg = (shifts, [w for _, w in use], wsum, stop_gradient, [i for i, w in enumerate(weights[:len(maps)]) if w != 0], len(maps))
+        ctx.save_for_backward(basis, *[m for m, _ in use])
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        basis, *use = ctx.saved_tensors
+        shifts, wts, wsum, stop_gradient, idx, nmaps = ctx.cfg
+        B, K, H, W = basis.shape
+        g0 = g.float().contiguous()
+        n = len(use)
+        dmaps = [torch.empty_like(m) for m in use]
+        ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in use])
+        dptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in dmaps])
+        sh = (ctypes.c_int * n)(*shifts)
+        wt = (ctypes.c_float * n)(*wts)
+        dbasis = None if stop_gradient else torch.empty_like(basis)
+        lib().octa_interlayer_kl_bwd(_p(basis), ptrs, sh, wt, n, wsum, B, K, H, W, _p(g0), _p(dbasis), dptrs, _st())
+        grads: List[Optional[Tensor]] = [None] * nmaps
+        for i, d in zip(idx, dmaps):
+            grads[i] = d
+        return (None, None, dbasis, *grads)
+
+
+def interlayer_kl(attentions: Sequence[Tensor], weights, stop_gradient=False) -> Tensor:
+    """returns a (2,) tensor: [loss, nan_flag]."""
+    return InterlayerKLFn.apply(list(weights), stop_gradient, attentions[0], *attentions[1:])
+
+
+class LsganFn(Function):
+    @staticmethod
+    def forward(ctx, mode, fake, real):
+        _require_gpu(fake)
+        fake = fake.float().contiguous()
+        real = real.float().contiguous() if real is not None else None
+        out = torch.empty((1,), dtype=torch.float32, device=fake.device)
+        lib().octa_lsgan_fwd(_p(real), _p(fake), real.numel() if real is not None else 0, fake.numel(), mode, _p(out), _st())
+        ctx.mode = mode
+        ctx.save_for_backward(fake, real)
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        fake, real = ctx.saved_tensors
+        g = g.float().contiguous()
+        df = torch.empty_like(fake)
+        dr = torch.empty_like(real) if real is not None else None
+        lib().octa_lsgan_bwd(_p(real), _p(fake), real.numel() if real is not None else 0, fake.numel(), ctx.mode, _p(g), _p(dr), _p(df), _st())
+        return None, df, dr
+
+
+def lsgan_generator(fake):
+    return LsganFn.apply(0, fake, None)
+
+
+def lsgan_discriminator(real, fake):
+    return LsganFn.apply(1, fake, real)
+
+
+# ----------------------------------------------------------------------------- discriminator pieces
+class NoiseClipFn(Function):
+    """InstanceNoise (+clip) on an NCHW fp32 map, emitting the NHWC activation (blocks.py:149-154)."""
+
+    @staticmethod
+    def forward(ctx, y, noise, dtype):
+        _require_gpu(y)
+        y = y.float()
+        B, C, H, W = y.shape
+        out = nhwc_empty(B, C, H, W, dtype, y.device, zero=True)
+        mask = torch.empty((B, C, H, W), dtype=torch.uint8, device=y.device)
+        lib().octa_noise_clip_fwd(_p(y), _strides4(y), _p(noise), _p(out), _p(mask), B, C, H, W, round8(C), round8(C), _dt(dtype), _st())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        (mask,) = ctx.saved_tensors
+        B, C, H, W = mask.shape
+        d = to_nhwc(d)
+        g = torch.empty((B, C, H, W), dtype=torch.float32, device=d.device)
+        lib().octa_noise_clip_bwd(_p(d), nhwc_ld(d), _p(mask), _p(g), B, C, H, W, _dt(d), _st())
+        return g, None, None
+
+
+class ToNhwcFn(Function):
+    """NCHW fp32 map -> NHWC activation of `dtype` (buffer padded to a multiple of 8 channels)."""
+
+    @staticmethod
+    def forward(ctx, y, dtype):
+        out = to_nhwc(y, dtype=dtype)
+        if out is y:
+            out = y.clone()
+        ctx.shape = tuple(y.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        return to_nchw_f32(to_nhwc(d)), None
+
+
+class DiscCatFn(Function):
+    """torch.cat((s, y), dim=1) for the discriminator (blocks.py:124): s is the NHWC squeeze output,
+    y a user-facing NCHW fp32 map; the result lives in a buffer padded to a multiple of 8."""
+
+    @staticmethod
+    def forward(ctx, s, y):
+        s = to_nhwc(s)
+        B, Cs, H, W = s.shape
+        Cy = y.shape[1]
+        C = Cs + Cy
+        out = nhwc_empty(B, C, H, W, s.dtype, s.device, zero=True)
+        ld = round8(C)
+        L = lib()
+        s32 = to_nchw_f32(s)
+        L.octa_nchw_to_nhwc(_p(s32), s32.stride(0), s32.stride(1), s32.stride(2), s32.stride(3), _p(out), B, Cs, H, W, ld, 0, Cs, _dt(s), _st())
+        yf = y.float()
+        L.octa_nchw_to_nhwc(_p(yf), yf.stride(0), yf.stride(1), yf.stride(2), yf.stride(3), _p(out), B, Cy, H, W, ld, Cs, Cy, _dt(s), _st())
+        ctx.cfg = (Cs, Cy)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        Cs, Cy = ctx.cfg
+        d = to_nhwc(d)
+        B, C, H, W = d.shape
+        ld = nhwc_ld(d)
+        ds = d[:, :Cs]
+        dy = torch.empty((B, Cy, H, W), dtype=torch.float32, device=d.device)
+        lib().octa_nhwc_to_nchw(_p(d), ld, Cs, _dt(d), _p(dy), B, Cy, H, W, 0, _st())
+        return ds, dy
+
+
+class SpectralNormFn(Function):
+    """weight = weight_orig / sigma with one power iteration in training (blocks.py:105-108)."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, training, eps):
+        _require_gpu(w)
+        wd = w.detach().contiguous()
+        Cout = wd.shape[0]
+        K = wd.numel() // Cout
+        sigma = torch.empty((1,), dtype=torch.float32, device=w.device)
+        wsn = torch.empty_like(wd)
+        lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _st())
+        ctx.save_for_backward(wsn, u.clone(), v.clone(), sigma)
+        return wsn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dwsn):
+        wsn, u, v, sigma = ctx.saved_tensors
+        Cout = wsn.shape[0]
+        K = wsn.numel() // Cout
+        dwsn = dwsn.float().contiguous()
+        dw = torch.zeros_like(wsn)
+        lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(u), _p(v), _p(sigma), Cout, K, _p(dw), None, _st())
+        return dw, None, None, None, None
+
+
+class FullConvFn(Function):
+    """Conv2d whose kernel covers the whole map (blocks.py:68-72) = one dot product per sample."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, sign):
+        x = dense_nhwc(x)
+        B, C, H, W = x.shape
+        if tuple(w.shape) != (1, C, H, W):
+            raise OctaError(f"full conv: weight {tuple(w.shape)} does not cover input {tuple(x.shape)}")
+        wp = torch.empty((H * W * C,), dtype=torch.float32, device=x.device)
+        s = w.stride()
+        lib().octa_pack_weight_fwd(_p(w.detach()), s[0], s[1], s[2], s[3], _p(wp), 1, C, H, W, 1, C, OCTA_F32, _st())
+        out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+        lib().octa_fullconv_fwd(_p(x), _p(wp), _p(bias), _p(out), B, H * W * C, _dt(x), float(sign), _st())
+        ctx.sign = float(sign)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, wp)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, wp = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = dout.float().contiguous()
+        dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
+        dwp = torch.zeros_like(wp)
+        db = torch.zeros((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dwp), _p(db), B, H * W * C, _dt(x), ctx.sign, _st())
+        dw = torch.empty((1, C, H, W), dtype=torch.float32, device=x.device)
+        lib().octa_nhwc_to_nchw(_p(dwp), C, 0, OCTA_F32, _p(dw), 1, C, H, W, 0, _st())
+        return dx, dw, db, None
+
+
+def fill_(t: Tensor, value: float):
+    t.fill_(value)
+    return t

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/octa_hip.h declares; argument
+checking returns error codes (no compute needs a GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "octave_amd", "libocta_hip.so")):
+        g.build()
+    from octave_amd._lib import lib
+    return lib()
+
+
+def test_header_declares_the_whole_surface():
+    from octave_amd._lib import parse_header
+    sig = parse_header()
+    for name in ("octa_conv2d_fwd", "octa_conv2d_dgrad", "octa_conv2d_wgrad", "octa_bn_stats", "octa_bn_apply", "octa_bn_bwd",
+                 "octa_maxpool3s2_fwd", "octa_avgpool_fwd", "octa_splat_gap", "octa_splat_apply", "octa_splat_bwd", "octa_aag_fwd",
+                 "octa_aag_bwd", "octa_wpce_dice_fwd", "octa_wpce_dice_bwd", "octa_interlayer_kl_fwd", "octa_interlayer_kl_bwd",
+                 "octa_lsgan_fwd", "octa_noise_clip_fwd", "octa_spectral_norm_fwd", "octa_fullconv_fwd", "octa_adam_step",
+                 "octa_version", "octa_last_error"):
+        assert name in sig, name
+    assert len(sig) >= 44
+
+
+def test_library_exports_every_declared_symbol(L):
+    dll = ctypes.CDLL(os.path.join(ROOT, "octave_amd", "libocta_hip.so"))
+    for name in L.signatures:
+        assert hasattr(dll, name), f"{name} declared in octa_hip.h but not exported"
+    assert L.octa_version() >= 100
+
+
+def test_bad_arguments_return_error_codes_not_crashes(L):
+    from octave_amd._lib import ConvDesc, OctaError
+    d = ConvDesc()
+    with pytest.raises(OctaError, match="dtype|dims|null"):
+        L.octa_conv2d_fwd(ctypes.byref(d), None, None, None, None, None)
+    with pytest.raises(OctaError):
+        L.octa_bn_stats(None, 0, 0, 0, 0, 0, 1e-5, 0.1, None, None, None, None, None, None)
+    with pytest.raises(OctaError, match="num_classes|null"):
+        L.octa_aag_fwd(None, None, None, None, None, 1, 1, 8, 9, 0, 0, None)
+    assert L.raw("octa_last_error")() is not None
+
+
+def test_cpu_tensor_is_rejected_loudly(L):
+    import torch
+    from octave_amd import functional as F_
+    from octave_amd._lib import OctaError
+    with pytest.raises(OctaError, match="no CPU fallback"):
+        F_.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from octave_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libocta_hip.so")
+    with pytest.raises(_lib.OctaError, match="no fallback"):
+        _lib._Lib()
+
+
+def test_module_state_dict_matches_reference_layout():
+    """Keys, shapes and order of OctaScribbleNet.state_dict() equal the reference's (derived in oracle/shapes.py)."""
+    import torch
+    from architectures.models.octa import OctaScribbleNet
+    from oracle.shapes import octa_state_shapes
+    net = OctaScribbleNet(torch.Size((2, 3, 48, 48)), torch.Size((2, 2, 48, 48)), True, False)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    want = octa_state_shapes(48)
+    assert mine == dict(want)
+    assert sum(p.numel() for p in net.segmentor.parameters()) == 73056784
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1))

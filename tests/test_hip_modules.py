@@ -1,0 +1,288 @@
+"""GPU parity tests, module level: the drop-in ``architectures`` modules (HIP path) against the golden
+vectors produced by the reference (tests/golden) and against the oracle, through the same public
+nn.Module API a user of the reference would call."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.fill import fill_state_dict, hash_input
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the MI355X (run with -m gpu on the GPU box)")
+    return torch.device("cuda:0")
+
+
+def check(name, got, want, rtol, atol):
+    got = got.detach().float().cpu()
+    want = torch.as_tensor(np.asarray(want)).float() if not isinstance(want, torch.Tensor) else want.detach().float().cpu()
+    assert tuple(got.shape) == tuple(want.shape), f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, got.shape) if got.dim() else ()
+        raise AssertionError(f"{name}: {int(bad.sum())}/{got.numel()} out of tolerance; worst at {idx}: got {got[idx].item():.6g} "
+                             f"want {want[idx].item():.6g} (|err| {err[idx].item():.3g}, max|want| {want.abs().max().item():.3g})")
+
+
+def run_block(G, tag, mod, x, dev, rtol=2e-4, atol=2e-5, gtol=5.0):
+    fill_state_dict(mod.state_dict())
+    mod = mod.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    out = mod(xd)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    loss = 0
+    for i, o in enumerate(outs):
+        check(f"{tag} out{i}", o, G[f"{tag}/out{i}"], rtol, atol)
+        loss = loss + (o.float() * hash_input(tuple(o.shape), 7000 + i, -1, 1).to(dev)).sum()
+    loss.backward()
+    check(f"{tag} grad_x", xd.grad, G[f"{tag}/grad_x"], rtol * gtol, atol * gtol)
+    params = dict(mod.named_parameters())
+    bufs = dict(mod.named_buffers())
+    n = 0
+    for k, g in G.items():
+        if k.startswith(f"{tag}/grad/"):
+            name = k[len(f"{tag}/grad/"):]
+            assert params[name].grad is not None, f"{tag}: no grad for {name}"
+            check(k, params[name].grad, g, rtol * gtol, atol * gtol * 4)
+            n += 1
+        if k.startswith(f"{tag}/buf/") and not k.endswith("num_batches_tracked"):
+            check(k, bufs[k[len(f"{tag}/buf/"):]], g, 1e-4, 1e-5)
+        if k.endswith("num_batches_tracked") and k.startswith(f"{tag}/buf/"):
+            assert int(bufs[k[len(f"{tag}/buf/"):]]) == int(g), k
+    assert n > 0
+
+
+def test_blocks_vs_reference_golden(dev, golden):
+    from torch import nn
+    from architectures.extra.resnest import Bottleneck, ResNestDecoder, SplAtConv2d, Upsampling, _AvgDown, _ConvBN
+    from architectures.segmentor.blocks import AdversarialAttentionGate
+    from octave_amd.layers import BatchNorm2d, Conv2d
+    G = golden("blocks.npz")
+    run_block(G, "splat_enc", SplAtConv2d(16, 16, 3, padding=1, groups=1, bias=False, radix=2, norm_layer=BatchNorm2d),
+              hash_input((3, 16, 6, 5), 11, -1, 1), dev)
+    run_block(G, "splat_dec", SplAtConv2d(32, 32, 3, padding=1, stride=1, groups=2, radix=2, norm_layer=BatchNorm2d),
+              hash_input((3, 32, 5, 7), 12, -1, 1), dev)
+    down = _ConvBN(_AvgDown(2), Conv2d(32, 64, 1, bias=False), BatchNorm2d(64))
+    run_block(G, "bottleneck_s2", Bottleneck(32, 16, stride=2, downsample=down, radix=2, cardinality=1, bottleneck_width=64, avd=True,
+                                             avd_first=False, norm_layer=BatchNorm2d), hash_input((3, 32, 8, 8), 13, -1, 1), dev)
+    run_block(G, "bottleneck_id", Bottleneck(64, 16, radix=2, cardinality=1, bottleneck_width=64, avd=True, avd_first=False,
+                                             norm_layer=BatchNorm2d), hash_input((3, 64, 5, 5), 14, -1, 1), dev)
+    run_block(G, "decoder", ResNestDecoder(64, 32), hash_input((3, 64, 6, 6), 15, -1, 1), dev)
+    run_block(G, "upsampling", Upsampling(16, 8), hash_input((2, 16, 5, 3), 16, -1, 1), dev)
+    run_block(G, "aag", AdversarialAttentionGate(32, 2), hash_input((2, 32, 7, 5), 17, -1, 1), dev)
+    run_block(G, "aag3", AdversarialAttentionGate(16, 3), hash_input((2, 16, 4, 4), 18, -1, 1), dev)
+
+
+# ----------------------------------------------------------------------------- losses vs reference golden
+B, C, H, W = 3, 2, 16, 16
+
+
+def probs(seed, shape=(B, C, H, W)):
+    return F.softmax(3.0 * hash_input(shape, seed, -1, 1), dim=1)
+
+
+def scribble(seed, shape=(B, C, H, W), empty_class=None):
+    u = hash_input((shape[0], 1, shape[2], shape[3]), seed)
+    ys = torch.zeros(shape)
+    ys[:, 1:2] = (u < 0.08).float()
+    ys[:, 0:1] = ((u > 0.3) & (u < 0.4)).float()
+    if empty_class is not None:
+        ys[:, empty_class] = 0
+    return ys
+
+
+def test_losses_vs_reference_golden(dev, golden):
+    from architectures.discriminator.losses import LSDiscriminatorialLoss, LSGeneratorLoss
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence, WeightedPartialCE
+    G = golden("losses.npz")
+    wpce = WeightedPartialCE(num_classes=2, manual=True)
+    for tag, kw in [("wpce_mean", {}), ("wpce_sum", {"reduction": "sum"}), ("wpce_full", {"full": True}),
+                    ("wpce_ignore_bg", {"ignore_bg": True})]:
+        p = probs(21).to(dev).requires_grad_(True)
+        ys = scribble(22).to(dev)
+        l = wpce(p, ys, **kw)
+        l.backward()
+        check(f"{tag} loss", l, G[f"{tag}/loss"], 2e-5, 1e-6)
+        check(f"{tag} grad", p.grad, G[f"{tag}/grad"], 2e-4, 1e-7)
+        check(f"{tag} ys_after", ys, G[f"{tag}/ys_after"], 0, 0)
+    p = probs(21).to(dev).requires_grad_(True)
+    l = wpce(p, scribble(22, empty_class=1).to(dev))
+    l.backward()
+    check("wpce_empty loss", l, G["wpce_empty/loss"], 2e-5, 1e-6)
+    check("wpce_empty grad", p.grad, G["wpce_empty/grad"], 2e-4, 1e-7)
+    with pytest.raises(AssertionError):
+        wpce(torch.rand(1, 2, 4, 4, device=dev), torch.rand(1, 3, 4, 4, device=dev))
+
+    for tag, ps, t in [("dice", 23, scribble(24)),
+                       ("dice_dense", 25, F.one_hot((hash_input((B, H, W), 26) > 0.7).long(), 2).permute(0, 3, 1, 2).float())]:
+        p = probs(ps).to(dev).requires_grad_(True)
+        l = DiceLoss()(p, t.to(dev))
+        l.backward()
+        check(f"{tag} loss", l, G[f"{tag}/loss"], 1e-5, 1e-7)
+        check(f"{tag} grad", p.grad, G[f"{tag}/grad"], 2e-4, 1e-9)
+
+    def pyramid(seed0, H0=32, n=6):
+        return [probs(seed0 + i, (B, C, H0 >> max(i - 1, 0), H0 >> max(i - 1, 0))).to(dev).requires_grad_(True) for i in range(n)]
+    for tag, kw, w in [("kl_default", {}, None), ("kl_stopgrad", {"stop_gradient": True}, None), ("kl_weights", {}, [1, 0.5, 0, 2, 1]),
+                       ("kl_short_weights", {}, [1, 2, 3, 4, 5, 6, 7])]:
+        att = pyramid(30)
+        l = InterlayerDivergence(**kw)(att, w)
+        l.backward()
+        check(f"{tag} loss", l, G[f"{tag}/loss"], 5e-5, 1e-6)
+        for i, a in enumerate(att):
+            g = a.grad if a.grad is not None else torch.zeros_like(a)
+            check(f"{tag} grad{i}", g, G[f"{tag}/grad{i}"], 5e-4, 1e-8)
+    with pytest.raises(NotImplementedError):
+        InterlayerDivergence(mode="sum")(pyramid(30))
+    bad = pyramid(30)
+    bad[2] = torch.full_like(bad[2], float("nan"))
+    with pytest.raises(Exception, match="NaN"):
+        InterlayerDivergence()(bad)
+
+    r = hash_input((4, 1), 41, -2, 2).to(dev).requires_grad_(True)
+    f = hash_input((4, 1), 42, -2, 2).to(dev).requires_grad_(True)
+    l = LSDiscriminatorialLoss()(r, f)
+    l.backward()
+    check("lsd loss", l, G["lsd/loss"], 1e-5, 1e-7)
+    check("lsd grad_real", r.grad, G["lsd/grad_real"], 1e-5, 1e-7)
+    check("lsd grad_fake", f.grad, G["lsd/grad_fake"], 1e-5, 1e-7)
+    f2 = hash_input((4, 1), 43, -2, 2).to(dev).requires_grad_(True)
+    l = LSGeneratorLoss()(f2)
+    l.backward()
+    check("lsg loss", l, G["lsg/loss"], 1e-5, 1e-7)
+    check("lsg grad", f2.grad, G["lsg/grad"], 1e-5, 1e-7)
+
+
+# ----------------------------------------------------------------------------- discriminator vs reference golden
+def test_discriminator_vs_reference_golden(dev, golden):
+    from architectures.discriminator.blocks import DiscriminatorBlock
+    G = golden("disc.npz")
+    Bd, Hd = 2, 64
+    m = DiscriminatorBlock(torch.Size((Bd, 2, Hd, Hd)), is_training=True, depth=4, num_filters=8)
+    fill_state_dict(m.state_dict())
+    m = m.to(dev).train()
+
+    def pyr(seed):
+        return [F.softmax(2 * hash_input((Bd, 2, Hd >> i, Hd >> i), seed + i, -1, 1), dim=1).to(dev).requires_grad_(True) for i in range(5)]
+    for call in range(2):
+        torch.manual_seed(100 + call)              # the forward must consume normal(H,W) then uniform(1) from the CPU generator
+        ys = pyr(50 + 10 * call)
+        out = m(ys)
+        m.zero_grad()
+        (out * hash_input(tuple(out.shape), 60 + call, -1, 1).to(dev)).sum().backward()
+        check(f"disc call{call} out", out, G[f"call{call}/out"], 5e-4, 1e-5)
+        for i, y in enumerate(ys):
+            check(f"disc call{call} grad_y{i}", y.grad, G[f"call{call}/grad_y{i}"], 2e-3, 1e-6)
+        params, bufs = dict(m.named_parameters()), dict(m.named_buffers())
+        for k, g in G.items():
+            if k.startswith(f"call{call}/grad/"):
+                check(k, params[k.split("/grad/")[1]].grad, g, 2e-3, 1e-5)
+            if k.startswith(f"call{call}/buf/"):
+                check(k, bufs[k.split("/buf/")[1]], g, 1e-4, 1e-6)
+    m.eval()
+    torch.manual_seed(7)
+    with torch.no_grad():
+        out = m([y.detach() for y in pyr(90)])
+    check("disc eval out", out, G["eval/out"], 5e-4, 1e-5)
+
+
+# ----------------------------------------------------------------------------- whole network vs reference golden
+def _scribble(Bn, Hn):
+    u = hash_input((Bn, 1, Hn, Hn), 4321)
+    ys = torch.zeros(Bn, 2, Hn, Hn)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    return ys
+
+
+@pytest.mark.parametrize("Hn", [48, 64])
+def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
+    """north_star: segmentor logits within 1e-4 of the reference CPU path (fp32), argmax bit-exact."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss
+    G = golden(f"unet_{Hn}.npz")
+    Bn = 3
+    net = OctaScribbleNet(torch.Size((Bn, 3, Hn, Hn)), torch.Size((Bn, 2, Hn, Hn)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    x = hash_input((Bn, 1, Hn, Hn), 1234).repeat(1, 3, 1, 1).to(dev)
+    att, agg, x4 = net.segmentor(x)
+    check("agg_map (logits)", agg, G["agg"], 0, 1e-4)
+    check("x_4", x4, G["x4"], 1e-3, 1e-4)
+    for i, a in enumerate(att):
+        check(f"att{i}", a, G[f"att{i}"], 0, 1e-4)
+    want_arg = np.argmax(G["agg"], axis=1)
+    got_arg = torch.argmax(agg, dim=1).cpu().numpy()
+    margin = np.abs(G["agg"][:, 0] - G["agg"][:, 1])
+    assert np.array_equal(got_arg[margin > 2e-4], want_arg[margin > 2e-4]), "argmax mask differs where the reference margin is > 2e-4"
+    assert (got_arg != want_arg).sum() == 0 or (got_arg != want_arg).mean() < 1e-3
+    if Hn == 48:
+        onehot = net.segmentor.predict(x, "one-hot")[1]
+        assert (onehot.cpu().numpy().astype(np.uint8) != G["onehot"]).mean() < 1e-3
+        # a second train-mode forward advanced the running stats: rebuild for the backward check
+        net = OctaScribbleNet(torch.Size((Bn, 3, Hn, Hn)), torch.Size((Bn, 2, Hn, Hn)), True, False)
+        fill_state_dict(net.state_dict())
+        net = net.to(dev).train()
+        att, agg, x4 = net.segmentor(x)
+    ys = _scribble(Bn, Hn).to(dev)
+    p = torch.softmax(agg, dim=1)
+    loss = net.supervised_loss(p, ys) + DiceLoss()(p, ys)
+    loss.backward()
+    check("loss", loss, G["loss"], 1e-4, 1e-6)
+    params, bufs = dict(net.segmentor.named_parameters()), dict(net.segmentor.named_buffers())
+    worst = 0.0
+    for k, g in G.items():
+        if k.startswith("grad/"):
+            check(k, params[k[5:]].grad, g, 2e-2, 1e-5 + 2e-3 * float(np.abs(g).max()))
+        if k.startswith("gradnorm/"):
+            gn = params[k[9:]].grad.double().norm().item()
+            rel = abs(gn - float(g)) / (float(g) + 1e-12)
+            worst = max(worst, rel)
+            assert rel < 2e-2, (k, gn, float(g))
+        if k.startswith("buf/"):
+            check(k, bufs[k[4:]], g, 1e-3, 1e-5)
+    for k in G["nograd_keys"].tolist():
+        assert params[k].grad is None, f"{k} must not receive a gradient"
+    print(f"[unet {Hn}] worst grad-norm relative error {worst:.2e}")
+
+
+def test_unet_bf16_sane(dev, golden):
+    """bf16 activations: finite, same argmax as the fp32 reference on all but low-margin pixels."""
+    from architectures.models.octa import OctaScribbleNet
+    G = golden("unet_64.npz")
+    Bn, Hn = 3, 64
+    net = OctaScribbleNet(torch.Size((Bn, 3, Hn, Hn)), torch.Size((Bn, 2, Hn, Hn)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    net.segmentor.compute_dtype = torch.bfloat16
+    x = hash_input((Bn, 1, Hn, Hn), 1234).repeat(1, 3, 1, 1).to(dev)
+    att, agg, x4 = net.segmentor(x)
+    assert torch.isfinite(agg).all()
+    err = (agg.cpu().numpy() - G["agg"])
+    print(f"[bf16] logits max abs err {np.abs(err).max():.3e}, rms {np.sqrt((err ** 2).mean()):.3e}, ref rms {np.sqrt((G['agg'] ** 2).mean()):.3e}")
+    margin = np.abs(G["agg"][:, 0] - G["agg"][:, 1])
+    got_arg = torch.argmax(agg, dim=1).cpu().numpy()
+    want_arg = np.argmax(G["agg"], axis=1)
+    big = margin > 0.25 * np.abs(G["agg"]).max()
+    assert (got_arg[big] == want_arg[big]).mean() > 0.98
+    ys = _scribble(Bn, Hn).to(dev)
+    out = net.supervised_loss(torch.softmax(agg, 1), ys)
+    out.backward()
+    for k, p in net.segmentor.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+
+
+def test_product_path_has_no_cpu_fallback():
+    from octave_amd import functional as F_
+    from octave_amd._lib import OctaError
+    with pytest.raises(OctaError):
+        F_.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))

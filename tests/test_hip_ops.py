@@ -1,0 +1,292 @@
+"""GPU parity tests, kernel level: every C-ABI op of libocta_hip.so against plain torch CPU ops
+(the primitives the oracle is written in) on seeded inputs, fp32 (tight) and bf16 (loose)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the MI355X (run with -m gpu on the GPU box)")
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return lo + (hi - lo) * torch.rand(shape, generator=g)
+
+
+def check(name, got, want, rtol, atol):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, got.shape)
+        raise AssertionError(f"{name}: {int(bad.sum())}/{got.numel()} out of tolerance; worst at {idx}: got {got[idx].item():.6g} "
+                             f"want {want[idx].item():.6g} (|err| {err[idx].item():.3g}, max|want| {want.abs().max().item():.3g})")
+
+
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+
+
+# --------------------------------------------------------------------------- layout probes
+def test_mfma_and_tr16_layouts(dev):
+    from octave_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.randint(-4, 5, (16, 32)).float()
+    b = torch.randint(-4, 5, (32, 16)).float()
+    d = torch.zeros(16, 16, device=dev)
+    L.octa_probe_mfma(0, a.to(dev).bfloat16().data_ptr(), b.to(dev).bfloat16().data_ptr(), d.data_ptr(), st)
+    check("mfma bf16 16x16x32 layout", d, a @ b, 0, 0)
+    a = torch.randint(-4, 5, (16, 4)).float()
+    b = torch.randint(-4, 5, (4, 16)).float()
+    ad, bd = a.to(dev), b.to(dev)
+    L.octa_probe_mfma(1, ad.data_ptr(), bd.data_ptr(), d.data_ptr(), st)
+    check("mfma f32 16x16x4 layout", d, a @ b, 0, 0)
+    p = torch.randint(-4, 5, (32, 16)).float()
+    q = torch.randint(-4, 5, (32, 16)).float()
+    pd, qd = p.to(dev).bfloat16(), q.to(dev).bfloat16()
+    L.octa_probe_mfma(2, pd.data_ptr(), qd.data_ptr(), d.data_ptr(), st)
+    check("ds_read_tr16_b64 transposed operand", d, p.t() @ q, 0, 0)
+
+
+# --------------------------------------------------------------------------- conv engine
+CONV_CASES = [
+    # Cin, Cout, k, s, p, g, B, H, W
+    (16, 32, 1, 1, 0, 1, 3, 7, 5),
+    (32, 64, 3, 1, 1, 1, 2, 9, 6),
+    (32, 64, 3, 1, 1, 2, 2, 6, 9),
+    (64, 128, 3, 1, 1, 4, 2, 5, 5),
+    (32, 64, 3, 1, 1, 4, 2, 8, 8),       # decoder_0 SplAt conv: 8 in / 16 out per group
+    (3, 32, 3, 2, 1, 1, 2, 16, 16),      # stem (Cin padded 3 -> 8)
+    (2, 8, 4, 2, 1, 1, 2, 16, 16),       # discriminator stack_0
+    (15, 16, 4, 2, 1, 1, 2, 8, 8),       # spectral conv (Cin padded 15 -> 16)
+    (64, 13, 1, 1, 0, 1, 2, 6, 6),       # squeeze conv (Cout 13)
+    (256, 200, 1, 1, 0, 1, 1, 13, 11),   # N-tile edge
+    (128, 64, 3, 1, 1, 1, 2, 20, 20),    # long K, several M tiles
+    (24, 40, 3, 2, 1, 1, 2, 11, 9),      # odd sizes, stride 2
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, dtype, case):
+    from octave_amd import functional as F_
+    Cin, Cout, k, s, p, g, B, H, W = case
+    x = rnd((B, Cin, H, W), 1)
+    w = rnd((Cout, Cin // g, k, k), 2) * (1.0 / (k * k * Cin / g) ** 0.5)
+    b = rnd((Cout,), 3)
+    if dtype == torch.bfloat16:   # compare against the same rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p, groups=g)
+    gy = rnd(tuple(yr.shape), 4)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    (yr * gy).sum().backward()
+
+    xd = x.to(dev).to(dtype).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = F_.conv2d(xd, wd, bd, s, p, g)
+    assert y.shape == yr.shape
+    t = TOL[dtype]
+    check(f"conv fwd {case}", y, yr, **t)
+    (y.float() * gy.to(dev)).sum().backward()
+    check(f"conv dgrad {case}", xd.grad, xr.grad, **t)
+    sc = float(B * yr.shape[2] * yr.shape[3]) ** 0.5
+    check(f"conv wgrad {case}", wd.grad, wr.grad, rtol=t["rtol"], atol=t["atol"] * sc)
+    check(f"conv bias grad {case}", bd.grad, br.grad, rtol=t["rtol"], atol=t["atol"] * sc)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_channels_last_weight_and_act(dev, dtype):
+    from octave_amd import functional as F_
+    from octave_amd._lib import ACT_TANH
+    x = rnd((2, 16, 6, 6), 5)
+    w = rnd((24, 16, 3, 3), 6) * 0.1
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.tanh(F.conv2d(xr, wr, None, padding=1))
+    gy = rnd(tuple(yr.shape), 7)
+    (yr * gy).sum().backward()
+    xd = x.to(dev).to(dtype).requires_grad_(True)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F_.conv2d(xd, wd, None, 1, 1, 1, ACT_TANH)
+    (y.float() * gy.to(dev)).sum().backward()
+    t = TOL[dtype]
+    check("conv+tanh fwd", y, yr, **t)
+    check("conv+tanh dgrad", xd.grad, xr.grad, **t)
+    check("conv+tanh wgrad (channels-last dw)", wd.grad, wr.grad, rtol=t["rtol"], atol=t["atol"] * 10)
+    assert wd.grad.stride() == wd.stride()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(16, 8, 2, 5, 3), (64, 32, 2, 6, 6), (24, 40, 1, 4, 7)])
+def test_conv_transpose2x2(dev, dtype, shape):
+    from octave_amd import functional as F_
+    Cin, Cout, B, H, W = shape
+    x = rnd((B, Cin, H, W), 8)
+    w = rnd((Cin, Cout, 2, 2), 9) * 0.2
+    b = rnd((Cout,), 10)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    gy = rnd(tuple(yr.shape), 11)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    (yr * gy).sum().backward()
+    xd = x.to(dev).to(dtype).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = F_.conv_transpose2x2(xd, wd, bd)
+    (y.float() * gy.to(dev)).sum().backward()
+    t = TOL[dtype]
+    check("convT fwd", y, yr, **t)
+    check("convT dgrad", xd.grad, xr.grad, **t)
+    check("convT wgrad", wd.grad, wr.grad, rtol=t["rtol"], atol=t["atol"] * 10)
+    check("convT bias grad", bd.grad, br.grad, rtol=t["rtol"], atol=t["atol"] * 10)
+
+
+# --------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(32, 3, 7, 5, True, True), (64, 2, 6, 6, False, False), (2048, 2, 2, 2, True, False),
+                                 (40, 4, 1, 1, True, False), (512, 2, 9, 9, False, True)])
+def test_batch_norm(dev, dtype, cfg):
+    from octave_amd import functional as F_
+    C, B, H, W, relu, use_res = cfg
+    x = rnd((B, C, H, W), 12, -2, 3)
+    res = rnd((B, C, H, W), 13)
+    gam, bet = rnd((C,), 14, 0.5, 1.5), rnd((C,), 15)
+    rm, rv = rnd((C,), 16), rnd((C,), 17, 0.5, 1.5)
+    if dtype == torch.bfloat16:
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if use_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd(tuple(yr.shape), 18)
+    (yr * gy).sum().backward()
+    xd = x.to(dev).to(dtype).requires_grad_(True)
+    rd = res.to(dev).to(dtype).requires_grad_(True)
+    gd, bd = gam.to(dev).requires_grad_(True), bet.to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    y = F_.batch_norm(xd, gd, bd, rmd, rvd, 0.1, 1e-5, True, relu, rd if use_res else None)
+    (y.float() * gy.to(dev)).sum().backward()
+    t = TOL[dtype]
+    check("bn fwd", y, yr, **t)
+    check("bn running_mean", rmd, rmr, rtol=1e-4, atol=1e-5)
+    check("bn running_var", rvd, rvr, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-5)
+    n = B * H * W
+    check("bn dx", xd.grad, xr.grad, rtol=t["rtol"] * 5, atol=t["atol"] * 5)
+    check("bn dgamma", gd.grad, gr.grad, rtol=t["rtol"] * 5, atol=t["atol"] * n ** 0.5)
+    check("bn dbeta", bd.grad, br.grad, rtol=t["rtol"] * 5, atol=t["atol"] * n ** 0.5)
+    if use_res:
+        check("bn dres", rd.grad, rr.grad, **t)
+
+
+def test_batch_norm_single_value_raises(dev):
+    from octave_amd import functional as F_
+    x = torch.zeros(1, 8, 1, 1, device=dev)
+    with pytest.raises(ValueError):
+        F_.batch_norm(x, torch.ones(8, device=dev), torch.zeros(8, device=dev), None, None, 0.1, 1e-5, True)
+
+
+# --------------------------------------------------------------------------- pooling / copies
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pools(dev, dtype):
+    from octave_amd import functional as F_
+    t = TOL[dtype]
+    for (B, C, H, W) in [(2, 16, 8, 8), (2, 8, 9, 7), (1, 64, 12, 12)]:
+        x = rnd((B, C, H, W), 20, -1, 1)
+        x[:, :, ::3, ::2] = 0.0   # ties, like post-ReLU maps
+        if dtype == torch.bfloat16:
+            x = x.bfloat16().float()
+        for name, fr, fg in [
+            ("maxpool3s2", lambda a: F.max_pool2d(a, 3, 2, 1), lambda a: F_.max_pool3s2(a)),
+            ("avgpool3s2p1", lambda a: F.avg_pool2d(a, 3, 2, 1), lambda a: F_.avg_pool(a, 3, 2, 1)),
+            ("avgpool2s2ceil", lambda a: F.avg_pool2d(a, 2, 2, ceil_mode=True, count_include_pad=False),
+             lambda a: F_.avg_pool(a, 2, 2, 0, True, False)),
+        ]:
+            xr = x.clone().requires_grad_(True)
+            yr = fr(xr)
+            gy = rnd(tuple(yr.shape), 21)
+            (yr * gy).sum().backward()
+            xd = x.to(dev).to(dtype).requires_grad_(True)
+            y = fg(xd)
+            (y.float() * gy.to(dev)).sum().backward()
+            check(f"{name} fwd {B,C,H,W}", y, yr, **t)
+            check(f"{name} bwd {B,C,H,W}", xd.grad, xr.grad, **t)
+
+
+def test_cat_pad_crop(dev):
+    from octave_amd import functional as F_
+    a = rnd((2, 16, 4, 4), 22)
+    b = rnd((2, 8, 4, 4), 23)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.cat((ar, br), 1)[:, :, :-1, :-1]
+    gy = rnd(tuple(yr.shape), 24)
+    (yr * gy).sum().backward()
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = F_.cat_crop(ad, bd, 3, 3)
+    (y * gy.to(dev)).sum().backward()
+    check("cat+crop", y, yr, 0, 0)
+    check("cat+crop grad a", ad.grad, ar.grad, 0, 0)
+    check("cat+crop grad b", bd.grad, br.grad, 0, 0)
+    x = rnd((2, 8, 3, 3), 25)
+    xr = x.clone().requires_grad_(True)
+    yr = F.pad(xr, (0, 1, 0, 1))
+    gy = rnd(tuple(yr.shape), 26)
+    (yr * gy).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    y = F_.pad_bottom_right(xd, 1, 1)
+    (y * gy.to(dev)).sum().backward()
+    check("pad", y, yr, 0, 0)
+    check("pad grad", xd.grad, xr.grad, 0, 0)
+
+
+# --------------------------------------------------------------------------- loss kernels (vs oracle)
+def test_losses_vs_oracle_random(dev):
+    from oracle import ref_ops as R
+    from octave_amd import functional as F_
+    B, K, H, W = 3, 2, 40, 24
+    logits = rnd((B, K, H, W), 30, -3, 3)
+    u = rnd((B, 1, H, W), 31, 0, 1)
+    ys = torch.zeros(B, K, H, W)
+    ys[:, 1:2] = (u < 0.1).float()
+    ys[:, 0:1] = ((u > 0.4) & (u < 0.5)).float()
+    lr = logits.clone().requires_grad_(True)
+    p = F.softmax(lr, 1)
+    want = R.weighted_partial_ce(p, ys, K) + 0.7 * R.dice_loss(p, ys)
+    want.backward()
+    ld = logits.to(dev).requires_grad_(True)
+    out = F_.wpce_dice(ld, ys.to(dev), from_logits=True)
+    got = out[0] + 0.7 * out[1]
+    got.backward()
+    check("fused softmax+wpce+dice", got, want, 2e-5, 1e-6)
+    check("fused loss grad", ld.grad, lr.grad, 2e-4, 1e-8)
+    # non-contiguous (NHWC-strided) probabilities
+    pd = F.softmax(logits, 1).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pr = F.softmax(logits, 1).requires_grad_(True)
+    w2 = R.weighted_partial_ce(pr, ys, K)
+    w2.backward()
+    g2 = F_.wpce_dice(pd, ys.to(dev))[0]
+    g2.backward()
+    check("wpce strided", g2, w2, 2e-5, 1e-6)
+    check("wpce strided grad", pd.grad, pr.grad, 2e-4, 1e-8)
