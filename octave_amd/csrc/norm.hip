@@ -33,13 +33,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                         int64_t rows, int C, int TX, int rpb, float* __restrict__ partial) {
     constexpr int EPC = DT<T>::EPC;
-    extern __shared__ float red[];   // [RY][TX*EPC][2]
+    extern __shared__ float red[];   // [RY][TX*EPC][2 or 3]
     const int RY = 256 / TX;
     const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
     const int col = blockIdx.x * TX + cx;
     const int cpr = C / EPC;
     const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
     float sa[EPC], sb[EPC], mu[EPC], is[EPC];
+    int cnt = 0;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { sa[e] = 0.f; sb[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; }
     if (col < cpr) {
@@ -51,8 +52,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
             float xv[EPC];
             unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
             if (MODE == 0) {
+                // shifted sums (shift = this thread's first sample): no E[x^2]-E[x]^2 cancellation
+                if (cnt == 0) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { sa[e] += xv[e]; sb[e] += xv[e] * xv[e]; }
+                    for (int e = 0; e < EPC; ++e) mu[e] = xv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float d = xv[e] - mu[e]; sa[e] += d; sb[e] += d * d; }
+                ++cnt;
             } else {
                 float dv[EPC], yv[EPC];
                 unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
@@ -64,6 +71,37 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                 }
             }
         }
+    }
+    if (MODE == 0) {
+        // thread partial -> (mean_t, M2_t); the count rides along in a third slot
+        float* myred = red + ((size_t)ry * TX + cx) * EPC * 3;
+        const float fn = (float)cnt;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float m1 = cnt ? sa[e] / fn : 0.f;
+            myred[3 * e] = mu[e] + m1;
+            myred[3 * e + 1] = cnt ? sb[e] - sa[e] * m1 : 0.f;
+            myred[3 * e + 2] = fn;
+        }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+            const int c = blockIdx.x * TX * EPC + ch;
+            if (c >= C) continue;
+            double n = 0.0, mean_b = 0.0, m2 = 0.0;      // Chan et al. pairwise merge
+            for (int yy = 0; yy < RY; ++yy) {
+                const float* pr = red + ((size_t)yy * TX * EPC + ch) * 3;
+                const double nb = (double)pr[2];
+                if (nb > 0.0) {
+                    const double delta = (double)pr[0] - mean_b, tot = n + nb;
+                    mean_b += delta * nb / tot;
+                    m2 += (double)pr[1] + delta * delta * n * nb / tot;
+                    n = tot;
+                }
+            }
+            partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)mean_b;
+            partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)m2;
+        }
+        return;
     }
     float* myred = red + ((size_t)ry * TX + cx) * EPC * 2;
 #pragma unroll
@@ -80,15 +118,21 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float eps, float momentum,
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int rpb, int C, int64_t rows, float eps, float momentum,
                                          float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nby; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
-    const double n = (double)rows;
-    const double m = s / n;
-    double var = ss / n - m * m;
+    double n = 0.0, m = 0.0, m2 = 0.0;
+    for (int b = 0; b < nby; ++b) {
+        const int64_t lo = (int64_t)b * rpb;
+        const double nb = (double)((rows - lo) < rpb ? (rows - lo) : rpb);
+        const double mb = (double)partial[((size_t)b * 2) * C + c], m2b = (double)partial[((size_t)b * 2 + 1) * C + c];
+        const double delta = mb - m, tot = n + nb;
+        m += delta * nb / tot;
+        m2 += m2b + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    double var = m2 / n;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -107,13 +151,13 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     const int rpb = rows_per_block(rows, cm.RY);
     const int nby = (int)cdiv64(rows, rpb);
     dim3 grid(cm.gridx, nby);
-    const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
+    const size_t sh = (size_t)256 * epc * 3 * sizeof(float);
     if (dtype == OCTA_F32)
         bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
     else
         bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(stats)");
-    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, nby, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
     OCTA_CHECK_LAUNCH("bn_stats_finalize");
     return OCTA_OK;
 }

@@ -266,6 +266,17 @@ def gen_unet():
         att, agg, x4 = net.segmentor(x)
         d["agg"] = _np(agg)
         d["x4"] = _np(x4)
+        # the same reference modules in float64: how far the reference's OWN fp32 result is from the
+        # exact answer (the network amplifies rounding noise through 93 train-mode BatchNorms; an
+        # independent fp32 implementation cannot be closer to the fp32 reference than that)
+        net64 = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+        fill_state_dict(net64.state_dict())
+        net64 = net64.double().train()
+        with torch.no_grad():
+            att64, agg64, _ = net64.segmentor(x.double())
+        d["agg_f64"] = _np(agg64)
+        for i, a in enumerate(att64):
+            d[f"att{i}_f64"] = _np(a)
         for i, a in enumerate(att):
             d[f"att{i}"] = _np(a)
         # segmentor-only loss (BASELINE config 2): WPCE + Dice on softmax(agg)

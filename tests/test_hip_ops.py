@@ -47,7 +47,8 @@ def test_mfma_and_tr16_layouts(dev):
     a = torch.randint(-4, 5, (16, 32)).float()
     b = torch.randint(-4, 5, (32, 16)).float()
     d = torch.zeros(16, 16, device=dev)
-    L.octa_probe_mfma(0, a.to(dev).bfloat16().data_ptr(), b.to(dev).bfloat16().data_ptr(), d.data_ptr(), st)
+    ad, bd = a.to(dev).bfloat16(), b.to(dev).bfloat16()      # keep references: data_ptr() of a temporary dangles
+    L.octa_probe_mfma(0, ad.data_ptr(), bd.data_ptr(), d.data_ptr(), st)
     check("mfma bf16 16x16x32 layout", d, a @ b, 0, 0)
     a = torch.randint(-4, 5, (16, 4)).float()
     b = torch.randint(-4, 5, (4, 16)).float()
