@@ -277,6 +277,20 @@ def gen_unet():
         d["agg_f64"] = _np(agg64)
         for i, a in enumerate(att64):
             d[f"att{i}_f64"] = _np(a)
+        net64.zero_grad()
+        att64, agg64, _ = net64.segmentor(x.double())     # with grad this time (running stats are not compared for net64)
+        from architectures.segmentor.losses import DiceLoss as _Dice
+        u64 = hash_input((B, 1, H, H), 4321)
+        ys64 = torch.zeros(B, 2, H, H, dtype=torch.float64)
+        ys64[:, 1:2] = (u64 < 0.05).double()
+        ys64[:, 0:1] = ((u64 > 0.5) & (u64 < 0.55)).double()
+        p64 = F.softmax(agg64, dim=1)
+        loss64 = net64.supervised_loss(p64, ys64) + _Dice()(p64, ys64)
+        loss64.backward()
+        d["loss_f64"] = _np(loss64)
+        for k, pr in net64.segmentor.named_parameters():
+            if pr.grad is not None:
+                d[f"gradnorm_f64/{k}"] = _np(pr.grad.norm())
         for i, a in enumerate(att):
             d[f"att{i}"] = _np(a)
         # segmentor-only loss (BASELINE config 2): WPCE + Dice on softmax(agg)

@@ -53,6 +53,12 @@ def run_block(G, tag, mod, x, dev, rel=1e-4, gtol=10.0):
         if k.startswith(f"{tag}/grad/"):
             name = k[len(f"{tag}/grad/"):]
             assert params[name].grad is not None, f"{tag}: no grad for {name}"
+            if name.endswith(("fc1.bias", "conv2.conv.bias", "conv.3.conv.bias")) or name == "conv.bias":
+                # a bias directly in front of a BatchNorm has an analytically ZERO gradient: the reference's
+                # value is rounding noise (|g| ~ 1e-6), so only its smallness is checked
+                assert float(params[name].grad.abs().max()) < 1e-3 * max(1.0, float(np.abs(G[f"{tag}/grad_x"]).max())), name
+                n += 1
+                continue
             check(k, params[name].grad, g, 0, rel * gtol * float(np.abs(g).max()) + 1e-6)
             n += 1
         if k.startswith(f"{tag}/buf/") and not k.endswith("num_batches_tracked"):
@@ -260,6 +266,58 @@ def test_unet_stagewise_vs_oracle_fp32(dev, Hn):
     assert [tuple(a.shape[2:]) for a in att] == [(Hn >> i, Hn >> i) for i in range(5)]
 
 
+STAGES = [
+    # name, input shape, oracle function
+    ("encoder_1", (4, 64, 12, 12), lambda R, x, P, n: R.encoder_stage(x, P, n, 0)),
+    ("encoder_2", (4, 256, 12, 12), lambda R, x, P, n: R.encoder_stage(x, P, n, 1)),
+    ("encoder_4", (4, 1024, 4, 4), lambda R, x, P, n: R.encoder_stage(x, P, n, 3)),
+    ("decoder_4", (4, 2048, 3, 3), lambda R, x, P, n: R.resnest_decoder(x, P, n)),
+    ("decoder_2", (4, 512, 12, 12), lambda R, x, P, n: R.resnest_decoder(x, P, n)),
+    ("decoder_0", (2, 64, 32, 32), lambda R, x, P, n: R.resnest_decoder(x, P, n)),
+    ("upsampling_4", (4, 2048, 2, 2), lambda R, x, P, n: R.upsampling(x, P, n)),
+    ("upsampling_0", (2, 64, 16, 16), lambda R, x, P, n: R.upsampling(x, P, n)),
+    ("aag_4", (4, 1024, 3, 3), lambda R, x, P, n: R.attention_gate(x, P, n)),
+    ("aag_0", (2, 32, 32, 32), lambda R, x, P, n: R.attention_gate(x, P, n)),
+]
+
+
+@pytest.mark.parametrize("stage", STAGES, ids=[s[0] for s in STAGES])
+def test_real_width_stage_fwd_bwd_vs_oracle(dev, stage):
+    """Forward AND backward of each U-Net stage at its real channel widths (tile edges of the MFMA
+    kernels: N up to 2048, K up to 18432) against the oracle on the same seeded input/cotangent."""
+    from oracle import ref_ops as R
+    name, shape, fn = stage
+    net, P = _build(2, 48, dev)
+    mod = getattr(net.segmentor, name)
+    pref = "segmentor." + name
+    Ps = {k: v.clone() for k, v in P.items() if k.startswith(pref + ".")}
+    for k, v in Ps.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    x = hash_input(shape, 77, -1, 1)
+    xr = x.clone().requires_grad_(True)
+    outs_r = fn(R, xr, Ps, pref)
+    outs_r = outs_r if isinstance(outs_r, tuple) else (outs_r,)
+    cots = [hash_input(tuple(o.shape), 88 + i, -1, 1) for i, o in enumerate(outs_r)]
+    sum((o * c).sum() for o, c in zip(outs_r, cots)).backward()
+    xd = x.to(dev).requires_grad_(True)
+    outs = mod(xd)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    sum((o.float() * c.to(dev)).sum() for o, c in zip(outs, cots)).backward()
+    for i, (o, w) in enumerate(zip(outs, outs_r)):
+        check(f"{name} out{i}", o, w, 0, 1e-4 * float(w.abs().max()))
+    check(f"{name} grad_x", xd.grad, xr.grad, 0, 2e-3 * float(xr.grad.abs().max()))
+    for k, pm in mod.named_parameters():
+        want = Ps[pref + "." + k].grad
+        if k.endswith(("fc1.bias", "conv2.conv.bias", "conv.3.conv.bias")):
+            continue        # analytically zero gradient (bias in front of a BatchNorm)
+        assert pm.grad is not None and want is not None, k
+        check(f"{name} grad {k}", pm.grad, want, 0, 2e-3 * float(want.abs().max()) + 1e-7)
+    for k, b in mod.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            check(f"{name} buffer {k}", b, Ps[pref + "." + k], 1e-4, 1e-5)
+
+
 @pytest.mark.parametrize("Hn", [48, 64])
 def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     """End to end against the reference's CPU fp32 result.  93 train-mode BatchNorms (some over 3
@@ -298,21 +356,26 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     p = torch.softmax(agg, dim=1)
     loss = net.supervised_loss(p, ys) + DiceLoss()(p, ys)
     loss.backward()
-    check("loss", loss, G["loss"], 2e-3, 1e-5)
+    l64, l32 = float(G["loss_f64"]), float(G["loss"])
+    assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l32, l64)
     params, bufs = dict(net.segmentor.named_parameters()), dict(net.segmentor.named_buffers())
-    worst = 0.0
+    worst_hip = worst_ref = 0.0
     for k, g in G.items():
-        if k.startswith("gradnorm/"):
-            assert params[k[9:]].grad is not None, k
-            gn = params[k[9:]].grad.double().norm().item()
-            rel = abs(gn - float(g)) / (float(g) + 1e-12)
-            worst = max(worst, rel)
-            assert rel < 0.1, (k, gn, float(g))
+        if k.startswith("gradnorm_f64/"):
+            name = k[len("gradnorm_f64/"):]
+            assert params[name].grad is not None, name
+            g64 = float(g)
+            if g64 < 1e-9:          # analytically zero (a bias in front of a BatchNorm): rounding noise only
+                continue
+            dev_hip = abs(params[name].grad.double().norm().item() - g64) / g64
+            dev_ref = abs(float(G["gradnorm/" + name]) - g64) / g64
+            worst_hip, worst_ref = max(worst_hip, dev_hip), max(worst_ref, dev_ref)
+            assert dev_hip <= 4 * dev_ref + 2e-3, (name, dev_hip, dev_ref)
         if k.startswith("buf/"):
             check(k, bufs[k[4:]], g, 2e-3, 1e-4)
     for k in G["nograd_keys"].tolist():
         assert params[k].grad is None, f"{k} must not receive a gradient"
-    print(f"[unet {Hn}] worst grad-norm relative deviation from the fp32 reference {worst:.2e}")
+    print(f"[unet {Hn}] grad norms vs float64 reference: worst deviation HIP {worst_hip:.2e}, reference fp32 {worst_ref:.2e}")
 
 
 def test_unet_bf16_sane(dev, golden):
