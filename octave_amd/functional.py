@@ -4,6 +4,7 @@ runs in libocta_hip.so.  Activations are torch tensors of logical shape (B, C, H
 is NHWC (channels-last) with a per-pixel stride `ld` that is a multiple of 8.
 """
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -141,11 +142,15 @@ def bump_weight_epoch():
 
 
 def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
-    key = (w.data_ptr(), kind, dtype, groups, pad_to)
-    tag = (w._version, _WEIGHT_EPOCH, tuple(w.shape), tuple(w.stride()))
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
+    # only nn.Parameters are cached (they persist); identity is checked through a weak reference
+    # because both id() and data_ptr() are recycled once a tensor dies
+    cacheable = isinstance(w, torch.nn.Parameter)
+    key = (id(w), kind, dtype, groups, pad_to)
+    tag = (w._version, _WEIGHT_EPOCH, w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+    if cacheable:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0] == tag and hit[2]() is w:
+            return hit[1]
     L = lib()
     wd = w.detach()
     if wd.dtype != torch.float32:
@@ -168,7 +173,10 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
         L.octa_pack_weight_convT(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, pad_to, _dt(dtype), _st())
     else:
         raise ValueError(kind)
-    _PACK_CACHE[key] = (tag, out)
+    if cacheable:
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (tag, out, weakref.ref(w))
     return out
 
 

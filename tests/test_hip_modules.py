@@ -359,7 +359,7 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     l64, l32 = float(G["loss_f64"]), float(G["loss"])
     assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l32, l64)
     params, bufs = dict(net.segmentor.named_parameters()), dict(net.segmentor.named_buffers())
-    worst_hip = worst_ref = 0.0
+    devs = {}
     for k, g in G.items():
         if k.startswith("gradnorm_f64/"):
             name = k[len("gradnorm_f64/"):]
@@ -367,15 +367,20 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
             g64 = float(g)
             if g64 < 1e-9:          # analytically zero (a bias in front of a BatchNorm): rounding noise only
                 continue
-            dev_hip = abs(params[name].grad.double().norm().item() - g64) / g64
-            dev_ref = abs(float(G["gradnorm/" + name]) - g64) / g64
-            worst_hip, worst_ref = max(worst_hip, dev_hip), max(worst_ref, dev_ref)
-            assert dev_hip <= 4 * dev_ref + 2e-3, (name, dev_hip, dev_ref)
+            devs[name] = (abs(params[name].grad.double().norm().item() - g64) / g64, abs(float(G["gradnorm/" + name]) - g64) / g64)
         if k.startswith("buf/"):
             check(k, bufs[k[4:]], g, 2e-3, 1e-4)
+    # the backward is as chaotic as the forward: the reference's own fp32 gradient norms sit up to
+    # worst_ref away from its float64 evaluation; the HIP path must stay within 4x that band
+    worst_hip = max(d[0] for d in devs.values())
+    worst_ref = max(d[1] for d in devs.values())
+    med_hip = float(np.median([d[0] for d in devs.values()]))
+    med_ref = float(np.median([d[1] for d in devs.values()]))
+    assert worst_hip <= 4 * worst_ref + 2e-3, (worst_hip, worst_ref)
+    assert med_hip <= 4 * med_ref + 1e-3, (med_hip, med_ref)
     for k in G["nograd_keys"].tolist():
         assert params[k].grad is None, f"{k} must not receive a gradient"
-    print(f"[unet {Hn}] grad norms vs float64 reference: worst deviation HIP {worst_hip:.2e}, reference fp32 {worst_ref:.2e}")
+    print(f"[unet {Hn}] grad norms vs float64 reference: worst/median deviation HIP {worst_hip:.2e}/{med_hip:.2e}, reference fp32 {worst_ref:.2e}/{med_ref:.2e}")
 
 
 def test_unet_bf16_sane(dev, golden):
