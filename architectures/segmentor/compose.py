@@ -120,7 +120,7 @@ class ResnestUNet(nn.Module):
         """ref :189-199.  The post-processing of the (B, classes, H, W) logits is host-level glue."""
         attentions, agg_map, _ = self.forward(x)
         if method == 'softmax':
-            predicate = torch.softmax(agg_map, dim=1)
+            predicate = F_.class_softmax(agg_map)
         elif method == 'sigmoid':
             predicate = torch.sigmoid(agg_map)
         elif method == 'one-hot':

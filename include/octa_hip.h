@@ -196,6 +196,13 @@ int octa_wpce_dice_bwd(const float* in, const int64_t* in_strides, const float* 
                        int full, int reduction_sum, const float* g_wpce, const float* g_dice,
                        const float* ws, float* din, const int64_t* din_strides, octa_stream_t stream);
 
+/* nn.Softmax(dim=1) over the class axis of the (B,K,H,W) logits (segmentor/compose.py:192):
+ * strided fp32 in, dense NCHW fp32 out; backward from the saved probabilities. */
+int octa_class_softmax_fwd(const float* in, const int64_t* in_strides, float* out, int B, int K, int H,
+                           int W, octa_stream_t stream);
+int octa_class_softmax_bwd(const float* p, const float* dp, const int64_t* dp_strides, float* din,
+                           int B, int K, int H, int W, octa_stream_t stream);
+
 /* InterlayerDivergence, KLD/mean (segmentor/losses.py:111-147), nearest up-sampling fused.
  * basis: [B,K,H,W]; maps[i]: [B,K,H>>shift[i],W>>shift[i]] (dense NCHW fp32), weight[i] != 0.
  * out[0] = loss, out[1] = NaN flag. */

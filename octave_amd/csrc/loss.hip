@@ -316,3 +316,63 @@ extern "C" int octa_lsgan_bwd(const float* real, const float* fake, int n_real, 
     OCTA_CHECK_LAUNCH("lsgan_bwd");
     return OCTA_OK;
 }
+
+// ------------------------------------------------------------------------------------------ per-pixel class softmax
+// nn.Softmax(dim=1) on the (B, classes, H, W) logits (segmentor/compose.py:192): strided in, dense NCHW out.
+template <int K>
+__global__ __launch_bounds__(256) void class_softmax_fwd_kernel(const float* __restrict__ in, Strides4 si, float* __restrict__ out, int B, int H, int W) {
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int b = (int)(i / ((int64_t)W * H));
+        float v[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { v[k] = in[b * si.b + k * si.c + h * si.h + w * si.w]; mx = fmaxf(mx, v[k]); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[(((int64_t)b * K + k) * H + h) * W + w] = v[k] * inv;
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void class_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, Strides4 sd, float* __restrict__ din,
+                                                                int B, int H, int W) {
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int b = (int)(i / ((int64_t)W * H));
+        float pv[K], g[K];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pv[k] = p[(((int64_t)b * K + k) * H + h) * W + w];
+            g[k] = dp[b * sd.b + k * sd.c + h * sd.h + w * sd.w];
+            dot += pv[k] * g[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) din[(((int64_t)b * K + k) * H + h) * W + w] = pv[k] * (g[k] - dot);
+    }
+}
+extern "C" int octa_class_softmax_fwd(const float* in, const int64_t* is, float* out, int B, int K, int H, int W, octa_stream_t stream) {
+    OCTA_REQUIRE(in && is && out && B > 0, "octa_class_softmax_fwd: bad arguments");
+    Strides4 si{is[0], is[1], is[2], is[3]};
+    const int64_t total = (int64_t)B * H * W;
+    int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    LOSS_K_SWITCH(K, class_softmax_fwd_kernel<KK><<<blocks, 256, 0, st>>>(in, si, out, B, H, W); OCTA_CHECK_LAUNCH("class_softmax_fwd");)
+    return OCTA_OK;
+}
+extern "C" int octa_class_softmax_bwd(const float* p, const float* dp, const int64_t* ds, float* din, int B, int K, int H, int W, octa_stream_t stream) {
+    OCTA_REQUIRE(p && dp && ds && din && B > 0, "octa_class_softmax_bwd: bad arguments");
+    Strides4 sd{ds[0], ds[1], ds[2], ds[3]};
+    const int64_t total = (int64_t)B * H * W;
+    int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    LOSS_K_SWITCH(K, class_softmax_bwd_kernel<KK><<<blocks, 256, 0, st>>>(p, dp, sd, din, B, H, W); OCTA_CHECK_LAUNCH("class_softmax_bwd");)
+    return OCTA_OK;
+}

@@ -335,6 +335,33 @@ def raw_bn_bwd(dy: Tensor, x: Tensor, y: Optional[Tensor], mean: Tensor, invstd:
     return dx, dres
 
 
+# ----------------------------------------------------------------------------- parameter-gradient sink
+_GRAD_SINK = False
+
+
+def set_grad_sink(on: bool):
+    """When on, backward kernels accumulate parameter gradients DIRECTLY into an existing fp32
+    ``param.grad`` (e.g. a view of a flat gradient arena, zeroed once per step) and return None to
+    autograd, instead of materialising a fresh tensor per parameter.  Every weight/bias/affine
+    gradient kernel of the library has += semantics, so this is exact."""
+    global _GRAD_SINK
+    _GRAD_SINK = bool(on)
+
+
+def _sink(p: Optional[Tensor]) -> Optional[Tensor]:
+    if not _GRAD_SINK or p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_cuda:
+        return None
+    return g
+
+
+def _ret(p: Tensor, buf: Tensor) -> Optional[Tensor]:
+    """What backward hands to autograd for parameter p whose gradient was written into buf."""
+    return None if (_GRAD_SINK and p.grad is buf) else buf
+
+
 # ============================================================================= autograd Functions
 class Conv2dFn(Function):
     """nn.Conv2d (+ fused activation).  Weight OIHW-logical fp32 parameter, any strides."""
@@ -345,6 +372,7 @@ class Conv2dFn(Function):
         y = raw_conv_fwd(x, w, bias, stride, pad, groups, act)
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -356,8 +384,12 @@ class Conv2dFn(Function):
         if act != ACT_NONE:
             dy = raw_act_bwd(y, dy, act)
         dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups) if ctx.needs_input_grad[0] else None
-        dw = raw_conv_wgrad(x, dy, w, stride, pad, groups) if ctx.needs_input_grad[1] else None
-        db = raw_colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = _ret(w, raw_conv_wgrad(x, dy, w, stride, pad, groups, _sink(w)))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            b = ctx.bias_ref
+            db = _ret(b, raw_colsum(dy, _sink(b)))
         return dx, dw, db, None, None, None, None
 
 
@@ -382,6 +414,7 @@ class ConvTranspose2x2Fn(Function):
         lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -390,10 +423,12 @@ class ConvTranspose2x2Fn(Function):
         x, w = ctx.saved_tensors
         # the adjoint is a plain conv k2 s2 p0 from the (2H,2W,CoutT) image to (H,W,CinT) whose OIHW weight is w itself
         dx = raw_conv_fwd(dy, w, None, 2, 0, 1) if ctx.needs_input_grad[0] else None
-        dw = None
+        dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1)
-        db = raw_colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            dw = _ret(w, raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1, _sink(w)))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            b = ctx.bias_ref
+            db = _ret(b, raw_colsum(dy, _sink(b)))
         return dx, dw, db
 
 
@@ -409,6 +444,7 @@ class BatchNormFn(Function):
         _require_gpu(x)
         y, mean, invstd, xn = raw_bn_fwd(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual)
         ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
+        ctx.beta_ref = beta
         ctx.save_for_backward(xn, y if relu else None, mean, invstd, gamma)
         return y
 
@@ -418,10 +454,13 @@ class BatchNormFn(Function):
         x, y, mean, invstd, gamma = ctx.saved_tensors
         if not ctx.training:
             raise OctaError("BatchNorm backward in eval mode is not part of the hot path")
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
+        beta = ctx.beta_ref
+        dgamma = _sink(gamma)
+        dbeta = _sink(beta)
+        if dgamma is None or dbeta is None:
+            dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
         dx, dres = raw_bn_bwd(dy, x, y, mean, invstd, gamma, ctx.relu, ctx.has_res and ctx.needs_input_grad[9], dgamma, dbeta)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+        return dx, _ret(gamma, dgamma), _ret(beta, dbeta), None, None, None, None, None, None, dres
 
 
 def batch_norm(x, gamma, beta, rm, rv, momentum=0.1, eps=1e-5, training=True, relu=False, residual=None):
@@ -575,6 +614,7 @@ class SplatTailFn(Function):
         out = nhwc_empty(B, C, H, W, xr.dtype, xr.device)
         L.octa_splat_apply(_p(xr), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
         ctx.cfg = (cardinality, training, relu, B, C, H, W)
+        ctx.refs = (fc1_b, b1, fc2_b)
         ctx.save_for_backward(xr, out if relu else None, logits, gap4, h1n, h2, mean1, invstd1, g1, fc1_w, fc2_w)
         return out
 
@@ -589,23 +629,25 @@ class SplatTailFn(Function):
         dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=xr.device)
         L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, _st())
         dl4 = dlogits.view(B, 1, 1, 2 * C).permute(0, 3, 1, 2)
-        d_fc2_w = raw_conv_wgrad(h2, dl4, fc2_w, 1, 0, card)
-        d_fc2_b = raw_colsum(dl4)
+        fc1_b, b1, fc2_b = ctx.refs
+        d_fc2_w = _ret(fc2_w, raw_conv_wgrad(h2, dl4, fc2_w, 1, 0, card, _sink(fc2_w)))
+        d_fc2_b = _ret(fc2_b, raw_colsum(dl4, _sink(fc2_b)))
         dh2 = raw_conv_dgrad(dl4, fc2_w, tuple(h2.shape), 1, 0, card)
-        dg1 = torch.zeros_like(g1)
-        db1 = torch.zeros_like(g1)
+        dg1, db1 = _sink(g1), _sink(b1)
+        if dg1 is None or db1 is None:
+            dg1, db1 = torch.zeros_like(g1), torch.zeros_like(g1)
         if not training:
             raise OctaError("SplAt backward in eval mode is not part of the hot path")
         dh1, _ = raw_bn_bwd(dh2, h1, h2, mean1, invstd1, g1, True, False, dg1, db1)
-        d_fc1_w = raw_conv_wgrad(gap4, dh1, fc1_w, 1, 0, card)
-        d_fc1_b = raw_colsum(dh1)
+        d_fc1_w = _ret(fc1_w, raw_conv_wgrad(gap4, dh1, fc1_w, 1, 0, card, _sink(fc1_w)))
+        d_fc1_b = _ret(fc1_b, raw_colsum(dh1, _sink(fc1_b)))
         dgap4 = raw_conv_dgrad(dh1, fc1_w, tuple(gap4.shape), 1, 0, card)
         dgap = dgap4.permute(0, 2, 3, 1).reshape(B, C)
         if not dgap.is_contiguous():
             dgap = dgap.contiguous()
         dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, xr.device)
         L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, _st())
-        return dx, d_fc1_w, d_fc1_b, dg1, db1, None, None, d_fc2_w, d_fc2_b, None, None, None, None, None
+        return dx, d_fc1_w, d_fc1_b, _ret(g1, dg1), _ret(b1, db1), None, None, d_fc2_w, d_fc2_b, None, None, None, None, None
 
 
 def splat_tail(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum=0.1, eps=1e-5, training=True, relu=False):
@@ -628,6 +670,7 @@ class AagFn(Function):
         lib().octa_aag_fwd(_p(x), _p(w2), _p(bias), _p(masked), _p(y), B, H * W, C, K, _dt(x), mode, _st())
         ctx.mode = mode
         ctx.wshape = tuple(w.shape)
+        ctx.refs = (w, bias)
         ctx.save_for_backward(x, w2, y if mode == 0 else None)
         if mode == 0:
             return masked, y
@@ -649,10 +692,13 @@ class AagFn(Function):
         if dy is not None:
             dy = dy.float().contiguous()
         dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
-        dw = torch.zeros((K, C), dtype=torch.float32, device=x.device)
-        db = torch.zeros((K,), dtype=torch.float32, device=x.device)
+        wp, bp = ctx.refs
+        dw, db = _sink(wp), _sink(bp)
+        if dw is None or db is None or dw.stride(0) != C or dw.stride(1) != 1:
+            dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=x.device)
+            db = torch.zeros((K,), dtype=torch.float32, device=x.device)
         lib().octa_aag_bwd(_p(x), _p(w2), _p(y), _p(dmasked), _p(dy), _p(dx), _p(dw), _p(db), B, H * W, C, K, _dt(x), ctx.mode, _st())
-        return dx, dw.view(ctx.wshape), db, None
+        return dx, _ret(wp, dw), _ret(bp, db), None
 
 
 def attention_gate(x, w, bias):
@@ -702,6 +748,35 @@ def wpce_dice(inp, ys, from_logits=False, full=False, reduction_sum=False):
     return WpceDiceFn.apply(inp, ys, from_logits, full, reduction_sum)
 
 
+class ClassSoftmaxFn(Function):
+    """nn.Softmax(dim=1) on the (B, classes, H, W) logits (compose.py:192)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        _require_gpu(logits)
+        if logits.dtype != torch.float32:
+            logits = logits.float()
+        B, K, H, W = logits.shape
+        p = torch.empty((B, K, H, W), dtype=torch.float32, device=logits.device)
+        lib().octa_class_softmax_fwd(_p(logits), _strides4(logits), _p(p), B, K, H, W, _st())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        B, K, H, W = p.shape
+        dp = dp.float()
+        din = torch.empty_like(p)
+        lib().octa_class_softmax_bwd(_p(p), _p(dp), _strides4(dp), _p(din), B, K, H, W, _st())
+        return din
+
+
+def class_softmax(logits):
+    return ClassSoftmaxFn.apply(logits)
+
+
 class InterlayerKLFn(Function):
     """InterlayerDivergence KLD/mean (segmentor/losses.py:111-147) with the nearest up-sampling fused."""
 
@@ -727,7 +802,6 @@ class InterlayerKLFn(Function):
         lib().octa_interlayer_kl_fwd(_p(basis), ptrs, sh, wt, n, wsum, B, K, H, W, _p(out), _p(ws), _st())
         ctx.cfg = (shifts, [w for _, w in use], wsum, stop_gradient, [i for i, w in enumerate(weights[:len(maps)]) if w != 0], len(maps))
         ctx.save_for_backward(basis, *[m for m, _ in use])
-        ctx.mark_non_differentiable()
         return out
 
     @staticmethod

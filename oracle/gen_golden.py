@@ -323,15 +323,13 @@ def gen_unet():
 
 
 def gen_trainstep():
-    """One full adversarial step on the reference modules, B=2, 48x48, plain SGD-free:
-    records the two losses and gradient norms so the oracle's and the HIP path's step can be pinned."""
+    """One full adversarial step on the reference modules, B=6, 48x48: the two losses and the
+    gradient norms, in fp32 and (same modules, .double()) in float64, so that the HIP path and the oracle
+    can be pinned relative to the reference's own rounding band."""
     from architectures.models.octa import OctaScribbleNet
     from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
-    B, H = 2, 48
+    B, H = 6, 48
     d = {}
-    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
-    fill_state_dict(net.state_dict())
-    net.train()
     x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
     u = hash_input((B, 1, H, H), 4321)
     ys = torch.zeros(B, 2, H, H)
@@ -339,32 +337,37 @@ def gen_trainstep():
     ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
     dense = (hash_input((B, H, H), 999) > 0.8).long()
     real = F.one_hot(dense, 2).permute(0, 3, 1, 2).float()
-    real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous() for i in range(5)]
-
-    torch.manual_seed(2024)
-    att, agg, _ = net.segmentor(x)
-    p = F.softmax(agg, dim=1)
-    l_seg = net.supervised_loss(p, ys) + DiceLoss()(p, ys) \
-        + 0.1 * InterlayerDivergence()([p, *att]) + 0.1 * net.generator_loss(net.discriminator(att))
-    net.zero_grad()
-    l_seg.backward()
-    d["l_seg"] = _np(l_seg)
-    for k, pr in net.segmentor.named_parameters():
-        if pr.grad is not None:
-            d[f"seg_gradnorm/{k}"] = _np(pr.grad.double().norm())
-    net.zero_grad()
-    l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
-    l_d.backward()
-    d["l_d"] = _np(l_d)
-    for k, pr in net.discriminator.named_parameters():
-        d[f"disc_gradnorm/{k}"] = _np(pr.grad.double().norm())
-        if pr.numel() <= 4096:
-            d[f"disc_grad/{k}"] = _np(pr.grad)
     # RNG draws consumed, in order: 3 discriminator calls x (normal(H,W), uniform(1))
     torch.manual_seed(2024)
     for c in range(3):
         d[f"noise{c}"] = _np(torch.normal(mean=0.0, std=0.2, size=(H, H)))
         d[f"uniform{c}"] = _np(torch.FloatTensor(1).uniform_(0, 1))
+    for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+        fill_state_dict(net.state_dict())
+        net = net.to(dt).train()
+        xx, yy = x.to(dt), ys.to(dt)
+        real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous().to(dt) for i in range(5)]
+        torch.manual_seed(2024)
+        att, agg, _ = net.segmentor(xx)
+        p = F.softmax(agg, dim=1)
+        parts = [net.supervised_loss(p, yy), DiceLoss()(p, yy), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
+        l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
+        net.zero_grad()
+        l_seg.backward()
+        d["l_seg" + tag] = _np(l_seg)
+        d["parts" + tag] = np.array([float(v) for v in parts])
+        for k, pr in net.segmentor.named_parameters():
+            if pr.grad is not None:
+                d[f"seg_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+        net.zero_grad()
+        l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
+        l_d.backward()
+        d["l_d" + tag] = _np(l_d)
+        for k, pr in net.discriminator.named_parameters():
+            d[f"disc_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+            if pr.numel() <= 4096 and tag == "":
+                d[f"disc_grad/{k}"] = _np(pr.grad)
     _save("trainstep_48.npz", d)
 
 
