@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the OCTAve segmentor+discriminator training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the config its metric is quoted on): OctaScribbleNet, full
+adversarial loop (segmentor fwd/bwd + WeightedPartialCE + Dice + InterlayerDivergence + LS-GAN
+generator term, Adam; then the LS-GAN discriminator step, Adam), batch 16 per GPU, 400x400, bf16
+activations, synthetic OCTA-like data, default-initialised weights.  Weak scaling: every rank runs
+the same per-GPU batch; gradients are all-reduced over RCCL.
+
+One JSON line is printed by rank 0.  Extra objects: "roofline" (MFMA-bound conv engine kernel:
+algorithmic FLOPs / HIP-event time of its launches) and "cpu_baseline" (the CPU oracle's step on
+the host cores, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask, cgroup quota, capped at 16 (the GPU
+    box gives one-GPU jobs a 16-CPU share; oversubscribing it makes the baseline meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("OCTA_CPU_THREADS", "16"))))
+
+
+def synth_batch(B, H, rank, device):
+    """grayscale OCTA-like plane replicated to 3 channels; scribbles ~5 % per class;
+    dense real vessel mask, one-hot."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand((B, 1, H, H), generator=g).repeat(1, 3, 1, 1)
+    g2 = torch.Generator().manual_seed(4321 + rank)
+    u = torch.rand((B, 1, H, H), generator=g2)
+    ys = torch.zeros(B, 2, H, H)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    g3 = torch.Generator().manual_seed(999 + rank)
+    dense = (torch.rand((B, H, H), generator=g3) > 0.8).long()
+    real = torch.nn.functional.one_hot(dense, 2).permute(0, 3, 1, 2).float().contiguous()
+    return x.to(device), ys.to(device), real.to(device)
+
+
+def conv_flops(d):
+    if d.upshuffle:
+        return 2.0 * d.B * d.H * d.W * d.Cin * d.Cout
+    return 2.0 * d.B * d.OH * d.OW * d.Cout * (d.Cin // d.groups) * d.KH * d.KW
+
+
+def kernel_name(kind, d):
+    """The template instance the host dispatcher picks (octave_amd/csrc/conv.hip launch_igemm / launch_wgrad)."""
+    t = "bf16" if d.dtype == 1 else "f32"
+    if kind == "wgrad":
+        ng = d.Cout // d.groups
+        return f"conv_wgrad_kernel<{t},{'128' if ng > 64 else ('64' if ng > 32 else '32')}>"
+    ng = (d.Cin if kind == "dgrad" else d.Cout) // d.groups
+    tile = "128x128" if ng > 64 else ("256x64" if ng > 32 else ("256x32" if ng > 16 else "256x16"))
+    return f"conv_igemm_kernel<{t},{tile}>"
+
+
+def roofline_leg(step, batch, dtype_name):
+    """Record one step's conv-engine launches, then replay each launch REP times between HIP events on
+    the stream it is launched on (torch's current stream) and aggregate per kernel instance."""
+    import ctypes
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    L = lib()
+    F_.start_recording()
+    step(*batch)
+    rec = F_.stop_recording()
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    REP = 3
+    agg = {}
+    dw_scratch = {}
+    for kind, d, ptrs, keep in rec:
+        def launch():
+            if kind == "fwd":
+                L.octa_conv2d_fwd(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[3], st)
+            elif kind == "dgrad":
+                L.octa_conv2d_dgrad(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], st)
+            else:
+                shape, stride = ptrs[2], ptrs[3]
+                key = (shape, stride)
+                if key not in dw_scratch:
+                    n = sum((s - 1) * t for s, t in zip(shape, stride)) + 1
+                    dw_scratch[key] = torch.zeros(n, dtype=torch.float32, device="cuda")
+                L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], dw_scratch[key].data_ptr(), (ctypes.c_int64 * 4)(*stride), st)
+        launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REP):
+            launch()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / REP
+        a = agg.setdefault(kernel_name(kind, d), [0.0, 0.0, 0])
+        a[0] += conv_flops(d)
+        a[1] += ms * 1e-3
+        a[2] += 1
+    tot_f = sum(a[0] for a in agg.values())
+    tot_t = sum(a[1] for a in agg.values())
+    name, (f, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
+    peak = PEAK_BF16_TFLOPS if dtype_name == "bf16" else PEAK_F32_TFLOPS
+    per_kernel = {k: {"launches_per_step": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    return {
+        "bound": "mfma", "kernel": name, "achieved": round(f / t / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(f / t / 1e12 / peak, 4), "traffic": None,
+        "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n,
+        "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
+                             "time_ms_per_step": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_f / 1e9, 1)},
+        "per_kernel": per_kernel,
+    }
+
+
+def cpu_baseline_leg(net_state, seconds_budget=25.0):
+    """the CPU oracle (a port of the reference's path, oracle/ref_ops.py) running the full
+    adversarial step of BASELINE config 1: batch 2, 304x304, fp32, all 4 losses, Adam, on the host cores."""
+    from oracle import ref_ops as R
+    ncpu = host_cores()
+    torch.set_num_threads(ncpu)
+    B, H = 2, 304
+    x, ys, real = [t.cpu() for t in synth_batch(B, H, 0, "cpu")]
+    P = {}
+    for k, v in net_state.items():
+        v = v.detach().cpu().clone().contiguous()
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")) and "linear_head_" not in k:
+            v.requires_grad_(True)
+        P[k] = v
+    # the discriminator head depends on the resolution (blocks.py:68-72): re-shape it for 304
+    hw = H // 32
+    P["discriminator.out.0.weight"] = (torch.randn(1, P["discriminator.out.0.weight"].shape[1], hw, hw) * 0.01).requires_grad_(True)
+    seg = [v for k, v in P.items() if k.startswith("segmentor.") and v.requires_grad]
+    dis = [v for k, v in P.items() if k.startswith("discriminator.") and v.requires_grad]
+    opt_s, opt_d = torch.optim.Adam(seg, lr=1e-4), torch.optim.Adam(dis, lr=1e-4)
+
+    def one():
+        opt_s.zero_grad(); opt_d.zero_grad()
+        l, att, _ = R.segmentor_loss(P, x, ys)
+        l.backward(); opt_s.step()
+        opt_d.zero_grad()
+        ld = R.discriminator_loss(P, R.mask_pyramid(real), att)
+        ld.backward(); opt_d.step()
+    one()                                    # warm
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and (time.time() - t_start) < seconds_budget:
+        t0 = time.time(); one(); times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/sec", "cores": ncpu, "kind": "port",
+            "sample": f"{len(times)} full adversarial steps, batch 2, 304x304, fp32 (BASELINE config 1), median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--seg-only", action="store_true", help="BASELINE configs[1]: segmentor-only (WPCE+Dice)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    t_begin = time.perf_counter()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs the MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd.train import TrainStep, mask_pyramid
+    B, H = args.batch, args.size
+    torch.manual_seed(0)      # identical default-init weights on every rank
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
+    net_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only)
+    x, ys, real = synth_batch(B, H, rank, dev)
+    batch = (x, ys, mask_pyramid(real))
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_begin:7.1f}s] {msg}", file=sys.stderr, flush=True)
+    log(f"model built, {B}x3x{H}x{H} {args.dtype}, world {world}")
+    for i in range(args.warmup):
+        step(*batch)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    from octave_amd import _lib as _l
+    if _l.PROFILE is not None and rank == 0:
+        print(_l.profile_report(), file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss_seg"].item())
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    if _l.PROFILE is not None and rank == 0:
+        print(_l.profile_report(), file=sys.stderr, flush=True)
+
+    if rank == 0:
+        res = {
+            "metric": "images/sec (seg+disc train step) 400x400 bf16" if not args.seg_only else "images/sec (segmentor-only train step)",
+            "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("OctaScribbleNet full adversarial step (segmentor + LS-GAN discriminator + InterlayerDivergence), "
+                                    if not args.seg_only else "OctaScribbleNet segmentor-only step (WeightedPartialCE + Dice), ")
+                       + f"batch {B}/GPU, {H}x{H}", "global_batch": world * B, "image": H, "parallelism": f"dp{world}",
+                       "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)"},
+            "final_loss_seg": round(loss, 5),
+        }
+        if not args.no_roofline:
+            res["roofline"] = roofline_leg(step, batch, args.dtype)
+            log("roofline leg done")
+        if net_state is not None:
+            res["cpu_baseline"] = cpu_baseline_leg(net_state)
+            log("cpu baseline leg done")
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

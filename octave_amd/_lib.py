@@ -60,6 +60,17 @@ def parse_header(path: str = HEADER):
     return out
 
 
+PROFILE = {} if os.environ.get("OCTA_PROFILE") == "1" else None
+
+
+def profile_report(reset=True):
+    rows = sorted(PROFILE.items(), key=lambda kv: -kv[1][0]) if PROFILE else []
+    txt = "\n".join(f"{n:32s} {v[0] * 1e3:10.2f} ms {v[1]:6d} calls {v[0] / max(v[1], 1) * 1e6:10.1f} us/call" for n, v in rows)
+    if reset and PROFILE is not None:
+        PROFILE.clear()
+    return txt
+
+
 _lock = threading.Lock()
 _LIB = None
 
@@ -87,7 +98,25 @@ class _Lib:
         return getattr(self._dll, name)
 
     def call(self, name, *args):
+        if PROFILE is not None:
+            return self._call_profiled(name, *args)
         rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            msg = self._dll.octa_last_error()
+            raise OctaError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def _call_profiled(self, name, *args):
+        """OCTA_PROFILE=1: synchronise around every entry point and accumulate wall time per function
+        (debug aid; serialises the stream)."""
+        import time
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = getattr(self._dll, name)(*args)
+        torch.cuda.synchronize()
+        e = PROFILE.setdefault(name, [0.0, 0])
+        e[0] += time.perf_counter() - t0
+        e[1] += 1
         if rc != 0:
             msg = self._dll.octa_last_error()
             raise OctaError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -180,6 +180,30 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- launch recorder (bench.py roofline leg)
+_RECORD = None
+
+
+def start_recording():
+    """Record every conv-engine launch (kind, descriptor, buffers) of the following calls so that bench.py
+    can replay each one between HIP events and attribute time/FLOPs per kernel."""
+    global _RECORD
+    _RECORD = []
+
+
+def stop_recording():
+    global _RECORD
+    r, _RECORD = _RECORD, None
+    return r
+
+
+def _record(kind, d, ptrs, keep):
+    if _RECORD is not None:
+        dd = ConvDesc()
+        ctypes.memmove(ctypes.byref(dd), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+        _RECORD.append((kind, dd, ptrs, keep))
+
+
 # ----------------------------------------------------------------------------- raw conv ops
 def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dtype, act=ACT_NONE, upshuffle=0) -> ConvDesc:
     d = ConvDesc()
@@ -222,6 +246,7 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
     wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
     lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+    _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
     return y
 
 
@@ -239,6 +264,7 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
     lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
+    _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
     return dx
 
 
@@ -252,6 +278,7 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
         dw = torch.zeros_like(w, dtype=torch.float32)
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
     lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _st())
+    _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw
 
 
@@ -349,7 +376,7 @@ def set_grad_sink(on: bool):
 
 
 def _sink(p: Optional[Tensor]) -> Optional[Tensor]:
-    if not _GRAD_SINK or p is None:
+    if not _GRAD_SINK or p is None or not p.is_leaf:
         return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_cuda:
@@ -359,7 +386,7 @@ def _sink(p: Optional[Tensor]) -> Optional[Tensor]:
 
 def _ret(p: Tensor, buf: Tensor) -> Optional[Tensor]:
     """What backward hands to autograd for parameter p whose gradient was written into buf."""
-    return None if (_GRAD_SINK and p.grad is buf) else buf
+    return None if (_GRAD_SINK and p.is_leaf and p.grad is buf) else buf
 
 
 # ============================================================================= autograd Functions
@@ -412,6 +439,7 @@ class ConvTranspose2x2Fn(Function):
         d = _desc(B, H, W, H, W, Cin, 4 * CoutT, 1, 1, 1, 0, 1, ldx, nhwc_ld(y), x.dtype, ACT_NONE, upshuffle=1)
         wp = _packed(w, "convT", x.dtype, 1, d.cin_g_pad)
         lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+        _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
