@@ -1,0 +1,128 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of octave_amd.train (flat gradient arena,
+all-reduce, 1/world scaling) with the oracle standing in for the per-rank compute.  Semantics under
+test: per-replica BatchNorm/statistics, gradients AVERAGED over ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_state():
+    from oracle.fill import fill_tensor
+    from oracle.shapes import discriminator_shapes
+    shapes = discriminator_shapes(32, in_ch=2, nf=8, depth=4, prefix="")
+    P = {}
+    for k, shp in shapes.items():
+        t = fill_tensor(k, torch.empty(shp))
+        P[k] = torch.nn.Parameter(t) if not k.endswith(("weight_u", "weight_v")) else t
+    return P
+
+
+def _shard(rank, B=2, H=32):
+    from oracle.fill import hash_input
+
+    def pyr(seed):
+        return [F.softmax(2 * hash_input((B, 2, H >> i, H >> i), seed + i + 100 * rank, -1, 1), dim=1) for i in range(5)]
+    return pyr(10), pyr(20)
+
+
+def _local_grads(P, rank, reset=True):
+    from oracle import ref_ops as R
+    real, fake = _shard(rank)
+    for p in P.values():
+        if isinstance(p, torch.nn.Parameter) and reset:
+            p.grad = None
+    Q = {k: (v if isinstance(v, torch.nn.Parameter) else v.clone()) for k, v in P.items()}   # u/v: same start on every rank
+    noise = torch.zeros(32, 32)
+    l = R.ls_discriminator_loss(R.discriminator_forward(real, Q, prefix="", noise=noise, flip=False),
+                                R.discriminator_forward(fake, Q, prefix="", noise=noise, flip=False))
+    l.backward()
+    return {k: p.grad.clone() for k, p in P.items() if isinstance(p, torch.nn.Parameter)}
+
+
+def _worker(rank, world, port, q):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    ok = False
+    try:
+        from octave_amd.train import FlatArena
+        P = _make_state()
+        params = [p for p in P.values() if isinstance(p, torch.nn.Parameter)]
+        arena = FlatArena(params)
+        assert all(p.grad.data_ptr() >= arena.g.data_ptr() for p in params)
+        arena.zero_grad()
+        g_local = _local_grads(P, rank, reset=False)
+        # the oracle's autograd wrote into the arena views in place (p.grad pre-assigned)
+        for (k, p) in [(k, p) for k, p in P.items() if isinstance(p, torch.nn.Parameter)]:
+            assert p.grad.data_ptr() >= arena.g.data_ptr() and torch.equal(p.grad, g_local[k])
+        arena.all_reduce(world)
+        avg = {k: p.grad.clone() / world for k, p in P.items() if isinstance(p, torch.nn.Parameter)}
+        if rank == 0:
+            P2 = _make_state()
+            want = None
+            for r in range(world):
+                g = _local_grads(P2, r)
+                want = g if want is None else {k: want[k] + g[k] for k in g}
+            err = max(((avg[k] - want[k] / world).abs().max().item()) for k in want)
+            q.put(("ok", err, arena.numel, len(params)))
+        ok = True
+    except Exception as e:   # surface the failure to the parent
+        import traceback
+        q.put(("fail", traceback.format_exc(), 0, 0))
+        raise
+    finally:
+        if ok:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_flat_arena_all_reduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        status, err, numel, nparams = q.get(timeout=200)
+    finally:
+        for p in procs:
+            p.join(timeout=100)
+            if p.is_alive():
+                p.kill()
+    assert status == "ok", err
+    assert err < 1e-6, err
+    assert numel >= 1 and nparams == 20
+
+
+def test_bench_shards_data_by_rank():
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["bench"] = bench
+    spec.loader.exec_module(bench)
+    x0, ys0, r0 = bench.synth_batch(2, 32, 0, "cpu")
+    x1, ys1, r1 = bench.synth_batch(2, 32, 1, "cpu")
+    assert x0.shape == (2, 3, 32, 32) and ys0.shape == (2, 2, 32, 32) and r0.shape == (2, 2, 32, 32)
+    assert not torch.equal(x0, x1) and not torch.equal(ys0, ys1)
+    assert torch.equal(x0[:, 0], x0[:, 1]) and float(ys0.sum(1).max()) <= 1.0 and torch.all(r0.sum(1) == 1)
+    assert 1 <= bench.host_cores() <= 16
+    d = type("D", (), dict(upshuffle=0, B=2, OH=4, OW=4, Cout=8, Cin=16, groups=2, KH=3, KW=3, H=4, W=4))()
+    assert bench.conv_flops(d) == 2.0 * 2 * 16 * 8 * 8 * 9
