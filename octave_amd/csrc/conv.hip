@@ -7,6 +7,7 @@
 // Chunk c of row r is stored at slot c ^ ((-(r>>2))&3): ds_read_b128 of a fragment is then
 // bank-conflict free without padding ("LDS image").
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -28,6 +29,20 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so linear
+// id L runs on XCD L%8.  Re-map so that every XCD owns a CONTIGUOUS range of (m-tile, n-tile) pairs with
+// the n-tiles of one pixel tile adjacent: the pixel rows (and the 3x3 halo rows of the neighbouring
+// tiles) are then re-read from that XCD's L2 instead of HBM.  Bijective for any grid size; speed only.
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& mt, int& nt) {
+    const int total = gx * gy;
+    const int L = blockIdx.x + blockIdx.y * gx;
+    const int xcd = L & 7, j = L >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+    nt = Lp % gy;
+    mt = Lp / gy;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -57,7 +72,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int g = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt, nt;
+    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
     const T* __restrict__ xg = (const T*)a.x + a.xoff + g * a.CgStride;
     const size_t Kelem = (size_t)a.Kc * EPC;
     const T* __restrict__ wg = (const T*)a.w + (size_t)g * a.Ng * Kelem;
@@ -200,21 +217,251 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the same tile: global_load_lds_dwordx4 writes the (pre-swizzled) chunks straight
+// into a STAGES-deep LDS ring, STAGES-1 K-tiles stay in flight across the single raw s_barrier per
+// K-step (counted vmcnt), padding / K-tail / out-of-tile chunks are sourced from a 16-byte zero page.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int octa_zero_page[4] = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_base, +1 KiB).
+// Inline asm on purpose: hipcc then neither counts the load nor drains it with vmcnt(0) in front of the
+// ds_reads (it would for the builtin); completion is tracked by the explicit counted s_waitcnt below.
+// M0 is written in the same statement that uses it and restored (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base /* wave-uniform */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
+
+// LDS image of one stage: K-chunk-major planes, A = [4 planes][BM rows], B = [4 planes][BNR rows] of 16-byte
+// chunks.  One LDS-DMA wave-instruction fills 64 consecutive rows of ONE plane, so the K decode of that
+// instruction (tap, channel chunk) is wave-uniform scalar work and a lane only adds its pixel offset.
+// Fragment reads (lane (r,q) -> plane q, row r) are conflict-free without any swizzle: the 16 rows of a
+// 16-lane group are 256 contiguous bytes and planes are 256-byte aligned.
+// MODE 0: forward gather; 1: data-gradient gather, stride 1; 2: data-gradient gather, any stride.
+template <typename T, int WM, int WN, int TM, int TN, int STAGES, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int BNR = BN < 64 ? 64 : BN;          // rows reserved for the weight tile
+    constexpr int A_CH = BM / 64, B_CH = BNR / 64;  // wave-instructions per wave per K-tile
+    constexpr int LPT = A_CH + B_CH;
+    constexpr int STAGE_CHUNKS = (BM + BNR) * 4;
+    static_assert(WM * WN == 4 && STAGES >= 2 && STAGES <= 4, "shape");
+    static_assert(BM == 128 || BM == 256, "pixel tile");
+    __shared__ uint4 smem[STAGES * STAGE_CHUNKS];   // ONE array: [stage][A planes | B planes]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = blockIdx.z;
+    int mt, nt;
+    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + g * a.CgStride;
+    const size_t Kelem = (size_t)a.Kc * EPC;
+    const T* __restrict__ wg = (const T*)a.w + (size_t)g * a.Ng * Kelem;
+    const int CgC = a.Cg / EPC;
+    const T* zero = (const T*)octa_zero_page;
+
+    // this wave's (row block, plane) assignment: A_CH instructions on row block arb, planes apl0 + i*apstep
+    const int arb = (BM == 128) ? (wave & 1) : wave;
+    const int apl0 = (BM == 128) ? (wave >> 1) : 0;
+    constexpr int apstep = (BM == 128) ? 2 : 1;
+    const int brb = (BNR == 128) ? (wave & 1) : 0;
+    const int bpl0 = (BNR == 128) ? (wave >> 1) : wave;
+    constexpr int bpstep = 2;
+
+    // the ONE pixel row this lane gathers: element offset of tap (0,0) and the bit mask of in-image taps
+    int roff;
+    unsigned rmask = 0;
+    {
+        const int m = m0 + arb * 64 + lane;
+        const bool rvalid = m < a.M;
+        const int mm = rvalid ? m : 0;
+        const int ow = mm % a.OW;
+        const int tq = mm / a.OW;
+        const int oh = tq % a.OH;
+        const int b = tq / a.OH;
+        int rh, rw;
+        if (MODE == 0) { rh = oh * a.stride - a.pad; rw = ow * a.stride - a.pad; }
+        else { rh = oh + a.pad; rw = ow + a.pad; }
+        if (rvalid) {
+            const int ntaps = a.KH * a.KW;
+            for (int tp = 0; tp < ntaps; ++tp) {
+                const int kh_ = tp / a.KW, kw_ = tp - kh_ * a.KW;
+                bool ok;
+                if (MODE == 0) ok = ((unsigned)(rh + kh_) < (unsigned)a.H) && ((unsigned)(rw + kw_) < (unsigned)a.W);
+                else if (MODE == 1) ok = ((unsigned)(rh - kh_) < (unsigned)a.H) && ((unsigned)(rw - kw_) < (unsigned)a.W);
+                else {
+                    const int th = rh - kh_, tw = rw - kw_;
+                    const int ih = th / a.stride, iw = tw / a.stride;
+                    ok = (th >= 0) && (tw >= 0) && (ih * a.stride == th) && (iw * a.stride == tw) && (ih < a.H) && (iw < a.W);
+                }
+                rmask |= (ok ? 1u : 0u) << tp;
+            }
+        }
+        if (MODE == 2) roff = (b * a.H) * a.W * a.stride + rh * a.W + rw;   // pixel units, divided per tap
+        else roff = ((b * a.H + rh) * a.W + rw) * a.ldx;                       // element units
+    }
+    // the ONE weight row this lane fetches
+    const int nrow = brb * 64 + lane;
+    const bool wvalid = (nrow < BN) && (n0 + nrow < a.Ng);
+    const T* wrow = wg + (size_t)(wvalid ? n0 + nrow : 0) * Kelem;
+
+    // scalar K state of the A instructions (chunk index inside the tap, tap index, tap displacement)
+    int s_kcg[A_CH], s_cc[A_CH], s_tap[A_CH], s_kh[A_CH], s_kw[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        s_kcg[i] = apl0 + i * apstep;
+        s_cc[i] = s_kcg[i] % CgC;
+        s_tap[i] = s_kcg[i] / CgC;
+        s_kh[i] = s_tap[i] / a.KW;
+        s_kw[i] = s_tap[i] % a.KW;
+    }
+    int b_kcg[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) b_kcg[j] = bpl0 + j * bpstep;
+
+    auto issue = [&](int stage) {
+        const unsigned sbase = lds_addr(smem + stage * STAGE_CHUNKS);
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int plane = apl0 + i * apstep;
+            const bool ok = (s_kcg[i] < a.Kc) && ((rmask >> s_tap[i]) & 1u);
+            const int tpix = s_kh[i] * a.W + s_kw[i];
+            int eoff;
+            if (MODE == 0) eoff = roff + tpix * a.ldx + s_cc[i] * EPC;
+            else if (MODE == 1) eoff = roff - tpix * a.ldx + s_cc[i] * EPC;
+            else eoff = ((roff - tpix) / a.stride) * a.ldx + s_cc[i] * EPC;
+            const T* src = ok ? (xg + eoff) : zero;
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)((plane * BM + arb * 64) * 16)));
+            s_kcg[i] += 4; s_cc[i] += 4;
+            while (s_cc[i] >= CgC) { s_cc[i] -= CgC; ++s_tap[i]; if (++s_kw[i] == a.KW) { s_kw[i] = 0; ++s_kh[i]; } }
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            const int plane = bpl0 + j * bpstep;
+            const T* src = (wvalid && b_kcg[j] < a.Kc) ? (wrow + (size_t)b_kcg[j] * EPC) : zero;
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)((BM * 4 + plane * BNR + brb * 64) * 16)));
+            b_kcg[j] += 4;
+        }
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = (a.Kc + 3) >> 2;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles issued so far = min(nk, kt+STAGES-1); leave all but tile kt in flight
+        const int rem = min(nk, kt + STAGES - 1) - (kt + 1);
+        if (rem >= 2) wait_vmcnt<2 * LPT>();
+        else if (rem == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+        const uint4* sA = smem + (kt % STAGES) * STAGE_CHUNKS + q * BM;
+        const uint4* sB = smem + (kt % STAGES) * STAGE_CHUNKS + BM * 4 + q * BNR;
+        uint4 xf[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = sA[(wm * TM + i) * 16 + r];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = sB[(wn * TN + i) * 16 + r];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 16 + r;
+        if (m >= a.M) continue;
+        size_t pix = (size_t)m;
+        int ow = 0, oh = 0, bb = 0;
+        if (a.upshuffle) { ow = m % a.OW; const int tq = m / a.OW; oh = tq % a.OH; bb = tq / a.OH; }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = n0 + (wn * TN + i) * 16 + q * 4;
+            if (nb >= a.Ng) continue;
+            int chan = g * a.Ng + nb;
+            int bidx = chan;
+            if (a.upshuffle) {
+                const int dd = nb / a.CoutT;
+                chan = nb - dd * a.CoutT;
+                bidx = chan;
+                pix = ((size_t)(bb * 2 * a.OH + 2 * oh + (dd >> 1)) * (2 * a.OW) + 2 * ow + (dd & 1));
+            }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f = acc[i][j][e];
+                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
+                v[e] = act_apply(f, a.act);
+            }
+            T* dst = yb + pix * a.ldy + chan;
+            if (a.vec_store && nb + 3 < a.Ng) {
+                if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+            }
+        }
+    }
+}
+
+static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
+static int conv_variant() {
+    if (g_conv_variant < 0) { const char* e = getenv("OCTA_CONV_VARIANT"); g_conv_variant = e ? atoi(e) : 1; }
+    return g_conv_variant;
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    if (a.mode == 0) conv_igemm_dma_kernel<T, WM, WN, TM, TN, 3, 0><<<grid, 256, 0, st>>>(a);
+    else if (a.stride == 1) conv_igemm_dma_kernel<T, WM, WN, TM, TN, 3, 1><<<grid, 256, 0, st>>>(a);
+    else conv_igemm_dma_kernel<T, WM, WN, TM, TN, 3, 2><<<grid, 256, 0, st>>>(a);
+}
+
 template <typename T>
 static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
     dim3 block(256);
+    // LDS-DMA kernel: tap masks are 32 bits and element offsets 32-bit
+    const bool dma = conv_variant() == 1 && a.KH * a.KW <= 32 &&
+                     (int64_t)a.B * a.H * a.W * (int64_t)a.ldx * (a.mode == 1 ? a.stride : 1) < (1ll << 31);
     if (a.Ng > 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
-        conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
+        if (dma) launch_dma<T, 2, 2, 4, 4>(a, grid, st);
+        else conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
     } else if (a.Ng > 32) {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a);
+        if (dma) launch_dma<T, 4, 1, 4, 4>(a, grid, st);
+        else conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a);
     } else if (a.Ng > 16) {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a);
+        if (dma) launch_dma<T, 4, 1, 4, 2>(a, grid, st);
+        else conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a);
     } else {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a);
+        if (dma) launch_dma<T, 4, 1, 4, 1>(a, grid, st);
+        else conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a);
     }
     OCTA_CHECK_LAUNCH("conv_igemm");
     return OCTA_OK;
@@ -423,6 +670,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const bool pn_ok = (n0 + pc * EPC) < a.Ng;
 
     uint4 rp[P_CH], rq[Q_CH];
+    // pixel coordinates of this thread's Q rows, advanced incrementally by MT per tile (no divisions in the loop)
+    int qb[Q_CH], qoh[Q_CH], qow[Q_CH];
+#pragma unroll
+    for (int i = 0; i < Q_CH; ++i) {
+        const int m = mbeg + qrow0 + i * (256 / QCPR);
+        qow[i] = m % a.OW;
+        const int tq = m / a.OW;
+        qoh[i] = tq % a.OH;
+        qb[i] = tq / a.OH;
+    }
+    const int qdh = qkh - a.pad, qdw = qkw - a.pad;
     auto load_tile = [&](int mt0) {
 #pragma unroll
         for (int i = 0; i < P_CH; ++i) {
@@ -437,16 +695,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int row = qrow0 + i * (256 / QCPR);
             const int m = mt0 + row;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < mend && kq_ok) {
-                const int ow = m % a.OW;
-                const int tq = m / a.OW;
-                const int oh = tq % a.OH;
-                const int b = tq / a.OH;
-                const int ih = oh * a.stride - a.pad + qkh, iw = ow * a.stride - a.pad + qkw;
-                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    v = *(const uint4*)(xg + ((size_t)(b * a.H + ih) * a.W + iw) * a.ldx + qcc);
-            }
+            const int ih = qoh[i] * a.stride + qdh, iw = qow[i] * a.stride + qdw;
+            if (m < mend && kq_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                v = *(const uint4*)(xg + ((size_t)(qb[i] * a.H + ih) * a.W + iw) * a.ldx + qcc);
             rq[i] = v;
+            qow[i] += MT;
+            while (qow[i] >= a.OW) { qow[i] -= a.OW; if (++qoh[i] == a.OH) { qoh[i] = 0; ++qb[i]; } }
         }
     };
     auto store_tile = [&](int buf) {
