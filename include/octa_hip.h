@@ -82,6 +82,11 @@ int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed
 /* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
 int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
                       octa_stream_t stream);
+/* Strided data gradient as GEMM + col2im: Z[(b,oh,ow)][(ci*KH+kh)*KW+kw] = dy x W^T comes from
+ * octa_conv2d_fwd (1x1, operand = the data-grad packed weight); this folds the overlapping taps:
+ * dx[b,ih,iw,ci] = sum_{kh,kw : ih+pad-kh = stride*oh, ...} Z[...].  (discriminator/blocks.py:46,97) */
+int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int Cin,
+                int KH, int KW, int stride, int pad, int dtype, octa_stream_t stream);
 /* dw[o,i,kh,kw] += sum_pixels dy * x   (fp32 gradient of the OIHW-logical parameter, addressed
  * through its element strides so OIHW-dense and channels-last storage both work; accumulated
  * with atomics, so the caller zeroes it once per step). */

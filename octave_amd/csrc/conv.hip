@@ -239,6 +239,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base /* wa
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// Same without saving M0: hipcc itself treats M0 as scratch around its own LDS-DMA lowering (it re-materialises
+// M0 before every use), so the two extra SALU moves per instruction are dropped in the hot loops.
+__device__ __forceinline__ void glds16_fast(const void* gsrc, unsigned lds_base /* wave-uniform */) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
 
 // LDS image of one stage: K-chunk-major planes, A = [4 planes][BM rows], B = [4 planes][BNR rows] of 16-byte
@@ -427,6 +432,194 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 specialisation with halo reuse.  A block owns an 8x16-pixel output tile of
+// one image and a BN-wide slice of output channels.  Per 64-byte channel chunk the (8+2)x(16+2)
+// input patch is brought into LDS ONCE (zero-filled outside the image) and the nine taps read it at
+// shifted rows, so activation traffic drops ~6x and no per-tap bounds logic is left in the K loop;
+// only the [BN x 64 B] weight tile of each (chunk, tap) step streams through a 4-deep LDS-DMA ring.
+// MODE 0: forward (tap (kh,kw) reads pixel (y-1+kh, x-1+kw)); MODE 1: data gradient with the
+// [ci][kh][kw][co] operand (tap reads (y+1-kh, x+1-kw)).
+// ------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int CK = 4 * EPC;                         // channels per chunk (64 bytes)
+    constexpr int BN = WN * TN * 16;
+    constexpr int BNR = BN < 64 ? 64 : BN;
+    constexpr int TH = 8, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 180 patch pixels
+    constexpr int PPL = 192;                            // patch rows per plane (padded: planes 256-B aligned mod banks)
+    constexpr int WSTG = 4;                             // weight ring depth
+    constexpr int LW = BNR / 64;                        // weight DMA instructions per wave per step
+    constexpr int LP = 3;                               // patch DMA instructions per wave per chunk
+    static_assert(WM * WN == 4 && WM * TM == TH, "wave layout must cover the 8 tile rows");
+    __shared__ uint4 smem[2 * 4 * PPL + WSTG * 4 * BNR];
+    uint4* const sP = smem;                             // [2][4 planes][PPL]
+    uint4* const sW = smem + 2 * 4 * PPL;               // [WSTG][4 planes][BNR]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = blockIdx.z;
+    int mt, nt;
+    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tx = mt % tiles_x;
+    const int ty = (mt / tiles_x) % tiles_y;
+    const int b = mt / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + g * a.CgStride;
+    const size_t Kelem = (size_t)9 * a.Cg;
+    const T* __restrict__ wg = (const T*)a.w + (size_t)g * a.Ng * Kelem;
+    const T* zero = (const T*)octa_zero_page;
+    const int nchunks = a.Cg / CK;
+    const int S = 9 * nchunks;
+
+    // patch rows this lane fetches: plane = wave, row blocks 0..2
+    int poff[LP];
+    bool pok[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const int prow = i * 64 + lane;
+        const int py = prow / PW, px = prow - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        pok[i] = (prow < PROWS) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
+        poff[i] = pok[i] ? (((b * a.H + iy) * a.W + ix) * a.ldx + wave * EPC) : 0;
+    }
+    // weight row this lane fetches: row block wrb, planes wpl0 (+2)
+    const int wrb = (BNR == 128) ? (wave & 1) : 0;
+    const int wpl0 = (BNR == 128) ? (wave >> 1) : wave;
+    const int nrow = wrb * 64 + lane;
+    const bool wvalid = (nrow < BN) && (n0 + nrow < a.Ng);
+    const T* wrow = wg + (size_t)(wvalid ? n0 + nrow : 0) * Kelem;
+
+    const unsigned sP_base = lds_addr(sP + wave * PPL);
+    const unsigned sW_base = lds_addr(sW);
+    auto issue_patch = [&](int c) {
+        const unsigned base = sP_base + (unsigned)((c & 1) * 4 * PPL * 16);
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            const T* src = pok[i] ? (xg + poff[i] + c * CK) : zero;
+            glds16_fast(src, __builtin_amdgcn_readfirstlane(base + (unsigned)(i * 64 * 16)));
+        }
+    };
+    // weights of step (c, tap) into ring slot `slot`
+    auto issue_w = [&](int c, int tap, int slot) {
+        const unsigned base = sW_base + (unsigned)(slot * 4 * BNR * 16);
+        const int koff = tap * a.Cg + c * CK;
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int plane = wpl0 + 2 * j;
+            const T* src = wvalid ? (wrow + koff + plane * EPC) : zero;
+            glds16_fast(src, __builtin_amdgcn_readfirstlane(base + (unsigned)((plane * BNR + wrb * 64) * 16)));
+        }
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int r = lane & 15, q = lane >> 4;
+    const uint4* const pA0 = sP + q * PPL + r;
+    const uint4* const pB0 = sW + q * BNR + r;
+    // prologue: patch 0, weights of steps 0..2 (program order = completion order of the vm counter)
+    issue_patch(0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
+    // step s = 9*c + tap uses ring slot s & 3 = (c + tap) & 3; the nine taps are unrolled so that tap offsets,
+    // the patch prefetch point (tap 4) and the counted waits are compile-time
+    for (int c = 0; c < nchunks; ++c) {
+        const bool last = (c + 1 == nchunks);
+        const uint4* const pA = pA0 + (c & 1) * 4 * PPL;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // younger than W(s): W(s+1), W(s+2) and, for taps 5..7, the patch of the next chunk issued at tap 4
+            if (last && tap >= 7) wait_vmcnt<0>();
+            else if (!last && tap >= 5 && tap <= 7) wait_vmcnt<2 * LW + LP>();
+            else wait_vmcnt<2 * LW>();
+            // every ds_read of the previous step has returned before any wave may refill that slot (WAR)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // refill the slot released by step s-1 with the weights of step s+3
+            if (tap + 3 < 9) issue_w(c, tap + 3, (c + tap + 3) & 3);
+            else if (!last) issue_w(c + 1, tap + 3 - 9, (c + tap + 3) & 3);
+            if (tap == 4 && !last) issue_patch(c + 1);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int dy = (MODE == 0) ? kh : 2 - kh, dx = (MODE == 0) ? kw : 2 - kw;
+            const uint4* pB = pB0 + ((c + tap) & 3) * 4 * BNR;
+            uint4 xf[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[i] = pA[(wm * TM + i + dy) * PW + dx];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = pB[(wn * TN + i) * 16];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+    }
+
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+    const int ox = x0 + r;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int oy = y0 + wm * TM + j;
+        if (oy >= a.H || ox >= a.W) continue;
+        const size_t pix = ((size_t)b * a.H + oy) * a.W + ox;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = n0 + (wn * TN + i) * 16 + q * 4;
+            if (nb >= a.Ng) continue;
+            const int chan = g * a.Ng + nb;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f = acc[i][j][e];
+                if (a.bias && nb + e < a.Ng) f += a.bias[chan + e];
+                v[e] = act_apply(f, a.act);
+            }
+            T* dst = yb + pix * a.ldy + chan;
+            if (a.vec_store && nb + 3 < a.Ng) {
+                if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+            }
+        }
+    }
+}
+
+template <typename T, int MODE>
+static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
+    // eligibility: 3x3, stride 1, pad 1 (same image in and out), 64-byte channel chunks, 32-bit offsets
+    constexpr int CK = 4 * DT<T>::EPC;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.upshuffle) return false;
+    if (a.H != a.OH || a.W != a.OW || a.Cg % CK != 0) return false;
+    if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 31)) return false;
+    const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
+    // partial 8x16 tiles waste MFMA work: below ~80 % tile utilisation the generic gather kernel is faster
+    if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
+    const int tiles = a.B * th * tw;
+    if (a.Ng > 64) {
+        dim3 grid(tiles, cdiv(a.Ng, 128), groups);
+        conv3x3_halo_kernel<T, 2, 2, 4, 4, MODE><<<grid, 256, 0, st>>>(a);
+    } else if (a.Ng > 32) {
+        dim3 grid(tiles, 1, groups);
+        conv3x3_halo_kernel<T, 4, 1, 2, 4, MODE><<<grid, 256, 0, st>>>(a);
+    } else if (a.Ng > 16) {
+        dim3 grid(tiles, 1, groups);
+        conv3x3_halo_kernel<T, 4, 1, 2, 2, MODE><<<grid, 256, 0, st>>>(a);
+    } else {
+        dim3 grid(tiles, 1, groups);
+        conv3x3_halo_kernel<T, 4, 1, 2, 1, MODE><<<grid, 256, 0, st>>>(a);
+    }
+    return true;
+}
+
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
 static int conv_variant() {
     if (g_conv_variant < 0) { const char* e = getenv("OCTA_CONV_VARIANT"); g_conv_variant = e ? atoi(e) : 1; }
@@ -443,8 +636,12 @@ static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
 template <typename T>
 static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
     dim3 block(256);
+    if (conv_variant() >= 1) {
+        const bool done = a.mode == 0 ? launch_halo<T, 0>(a, groups, st) : launch_halo<T, 1>(a, groups, st);
+        if (done) { OCTA_CHECK_LAUNCH("conv3x3_halo"); return OCTA_OK; }
+    }
     // LDS-DMA kernel: tap masks are 32 bits and element offsets 32-bit
-    const bool dma = conv_variant() == 1 && a.KH * a.KW <= 32 &&
+    const bool dma = conv_variant() == 2 && a.KH * a.KW <= 32 &&
                      (int64_t)a.B * a.H * a.W * (int64_t)a.ldx * (a.mode == 1 ? a.stride : 1) < (1ll << 31);
     if (a.Ng > 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
@@ -804,8 +1001,10 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     const int bnn = a.Ng > 64 ? 128 : (a.Ng > 32 ? 64 : 32);
     const int tilesN = cdiv(a.Ng, bnn);
     const int base = tilesK * tilesN * groups;
-    int split = cdiv(1024, base);
-    const int maxsplit = max(1, a.M / (MT * 8));
+    // every block ends with BNn x 128 fp32 atomics (~13 us per block at the chip-wide atomic rate): give it at
+    // least 16 m-tiles of MFMA work, and no more blocks than ~2 per CU
+    int split = cdiv(512, base);
+    const int maxsplit = max(1, a.M / (MT * 16));
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
     int mps = cdiv(a.M, split);
@@ -841,6 +1040,50 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
     a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
     return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
                                 : launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// col2im for strided data gradients: dx[b,ih,iw,ci] = sum over taps with (ih+p-kh) = s*oh of
+// Z[(b,oh,ow)][(ci*KH + kh)*KW + kw], where Z = dy x W^T is produced by the 1x1 GEMM path.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ z, int ldz, T* __restrict__ dx, int lddx, int B, int H, int W, int OH,
+                                                     int OW, int Cin, int KH, int KW, int stride, int pad) {
+    const int64_t total = (int64_t)B * H * W * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        int64_t p = i / Cin;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int th = ih + pad - kh;
+            if (th < 0 || th % stride) continue;
+            const int oh = th / stride;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int tw = iw + pad - kw;
+                if (tw < 0 || tw % stride) continue;
+                const int ow = tw / stride;
+                if (ow >= OW) continue;
+                acc += DT<T>::ld(z + ((int64_t)(b * OH + oh) * OW + ow) * ldz + (ci * KH + kh) * KW + kw);
+            }
+        }
+        DT<T>::st(dx + ((int64_t)(b * H + ih) * W + iw) * lddx + ci, acc);
+    }
+}
+extern "C" int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int Cin, int KH, int KW, int stride,
+                           int pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(z && dx && B > 0 && Cin > 0 && stride > 0, "octa_col2im: bad arguments");
+    const int64_t total = (int64_t)B * H * W * Cin;
+    const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) col2im_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
+    else if (dtype == OCTA_BF16) col2im_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_col2im: bad dtype");
+    OCTA_CHECK_LAUNCH("col2im");
+    return OCTA_OK;
 }
 
 // ------------------------------------------------------------------------------------------

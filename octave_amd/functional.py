@@ -263,6 +263,16 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
     dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device)
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
+    if stride > 1 and groups == 1 and (Cin * KH * KW) % 8 == 0:
+        # strided data gradient = dense GEMM Z = dy x W^T (no wasted taps, N = Cin*KH*KW) + col2im fold;
+        # the data-grad operand [ci][kh][kw][co] is exactly the [N][K] matrix the 1x1 forward wants
+        N = Cin * KH * KW
+        z = nhwc_empty(B, N, OH, OW, dy.dtype, dy.device)
+        dz = _desc(B, OH, OW, OH, OW, d.cout_g_pad, N, 1, 1, 1, 0, 1, ldy, N, dy.dtype)
+        lib().octa_conv2d_fwd(ctypes.byref(dz), _p(dy), _p(wt), None, _p(z), _st())
+        _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
+        lib().octa_col2im(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, Cin, KH, KW, stride, pad, _dt(dy), _st())
+        return dx
     lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
     _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
     return dx
@@ -275,7 +285,9 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
     dy = to_nhwc(dy, dtype=x.dtype, cpad=need)
     ldy = nhwc_ld(dy)
     if dw is None:
-        dw = torch.zeros_like(w, dtype=torch.float32)
+        # channels-last storage: the kernel's atomics then land in contiguous runs along Cin (17x the
+        # rate of a strided OIHW target; MI355X_MICROARCH.md "Global float atomics")
+        dw = torch.empty(tuple(w.shape), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
     lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))

@@ -77,6 +77,10 @@ CONV_CASES = [
     (256, 200, 1, 1, 0, 1, 1, 13, 11),   # N-tile edge
     (128, 64, 3, 1, 1, 1, 2, 20, 20),    # long K, several M tiles
     (24, 40, 3, 2, 1, 1, 2, 11, 9),      # odd sizes, stride 2
+    (64, 16, 3, 1, 1, 1, 2, 9, 19),      # 3x3 halo kernel: N<=16, partial tiles
+    (64, 48, 3, 1, 1, 1, 2, 17, 33),     # 3x3 halo kernel: N<=64, partial tiles in both axes
+    (96, 256, 3, 1, 1, 1, 1, 8, 16),     # 3x3 halo kernel: two N tiles, 3 channel chunks
+    (128, 256, 3, 1, 1, 2, 2, 13, 13),   # 3x3 halo kernel, grouped (encoder SplAt shape)
 ]
 
 

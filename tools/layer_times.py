@@ -1,0 +1,45 @@
+"""Per-launch time table of one training step's conv-engine launches (recorded, then replayed 3x between events)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from architectures.models.octa import OctaScribbleNet
+from octave_amd.train import TrainStep, mask_pyramid
+from octave_amd import functional as F_
+from octave_amd._lib import lib
+
+B, H = 16, 400
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
+step = TrainStep(net, compute_dtype=torch.bfloat16)
+x, ys, real = bench.synth_batch(B, H, 0, dev)
+batch = (x, ys, mask_pyramid(real))
+step(*batch); step(*batch)
+F_.start_recording(); step(*batch); rec = F_.stop_recording()
+torch.cuda.synchronize()
+L = lib(); st = torch.cuda.current_stream().cuda_stream
+rows = []
+scratch = {}
+for kind, d, ptrs, keep in rec:
+    def launch():
+        if kind == "fwd": L.octa_conv2d_fwd(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[3], st)
+        elif kind == "dgrad": L.octa_conv2d_dgrad(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], st)
+        else:
+            shape, stride = ptrs[2], ptrs[3]
+            if (shape, stride) not in scratch:
+                scratch[(shape, stride)] = torch.zeros(sum((s - 1) * t for s, t in zip(shape, stride)) + 1, device=dev)
+            L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], scratch[(shape, stride)].data_ptr(), (ctypes.c_int64 * 4)(*stride), st)
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); launch(); launch(); e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) / 3 * 1e3
+    fl = bench.conv_flops(d)
+    rows.append((us, kind, f"{'bf16' if d.dtype else 'f32'} B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}", fl))
+tot = sum(r[0] for r in rows)
+print(f"total conv time {tot/1e3:.2f} ms over {len(rows)} launches")
+agg = {}
+for us, kind, desc, fl in rows:
+    a = agg.setdefault((kind, desc), [0.0, 0, 0.0]); a[0] += us; a[1] += 1; a[2] += fl
+for (kind, desc), (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{us:9.1f} us {n:3d}x  {kind:6s} {desc:44s} {fl / us / 1e6:7.1f} TF/s")
