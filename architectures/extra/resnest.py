@@ -13,7 +13,7 @@ from torch import nn
 from torch.nn.modules.utils import _pair
 
 from octave_amd import functional as F_
-from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU
+from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_counter
 
 BN_MOMENTUM = 0.1
 
@@ -51,7 +51,7 @@ class SplAtConv2d(nn.Module):
         bn1 = self.bn1
         training = bn1.training
         if training and bn1.num_batches_tracked is not None:
-            bn1.num_batches_tracked.add_(1)
+            bump_counter(bn1.num_batches_tracked)
         return F_.splat_tail(x, self.fc1.weight, self.fc1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                              self.fc2.weight, self.fc2.bias, self.cardinality, bn1.momentum, bn1.eps, training, relu_after)
 

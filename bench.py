@@ -103,7 +103,7 @@ def roofline_leg(step, batch, dtype_name):
                 if key not in dw_scratch:
                     n = sum((s - 1) * t for s, t in zip(shape, stride)) + 1
                     dw_scratch[key] = torch.zeros(n, dtype=torch.float32, device="cuda")
-                L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], dw_scratch[key].data_ptr(), (ctypes.c_int64 * 4)(*stride), st)
+                L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], dw_scratch[key].data_ptr(), (ctypes.c_int64 * 4)(*stride), None, st)
         launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -91,7 +91,9 @@ int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W,
  * through its element strides so OIHW-dense and channels-last storage both work; accumulated
  * with atomics, so the caller zeroes it once per step). */
 int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, float* dw,
-                      const int64_t* dw_strides /* o,i,h,w element strides of dw */, octa_stream_t stream);
+                      const int64_t* dw_strides /* o,i,h,w element strides of dw */,
+                      float* dbias /* optional: dbias[Cout] += sum_pixels dy (fused bias gradient) */,
+                      octa_stream_t stream);
 /* out[c] += sum over rows of src[row*ld + off + c]  (bias gradients; fp32 accumulate). */
 int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out,
                 octa_stream_t stream);

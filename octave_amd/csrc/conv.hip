@@ -817,6 +817,7 @@ struct WgradArgs {
     int M, Kpad;                // Kpad = KH*KW*Cg
     int64_t s_o, s_i, s_h, s_w; // strides of the fp32 gradient tensor, OIHW-logical
     int splitM, mPerSplit;
+    float* dbias;               // optional: dbias[cout] += column sums of dy (fused bias gradient)
 };
 
 template <typename T> struct WgLds;
@@ -867,6 +868,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const bool pn_ok = (n0 + pc * EPC) < a.Ng;
 
     uint4 rp[P_CH], rq[Q_CH];
+    // fused bias gradient: the blocks of k-tile 0 also sum the dy chunks they stage anyway
+    const bool do_bias = (a.dbias != nullptr) && (blockIdx.x == 0);
+    float bsum[P_CH][EPC];
+#pragma unroll
+    for (int i = 0; i < P_CH; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) bsum[i][e] = 0.f;
     // pixel coordinates of this thread's Q rows, advanced incrementally by MT per tile (no divisions in the loop)
     int qb[Q_CH], qoh[Q_CH], qow[Q_CH];
 #pragma unroll
@@ -886,6 +894,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < MT && m < mend && pn_ok) v = *(const uint4*)(dyg + (size_t)m * a.ldy + n0 + pc * EPC);
             rp[i] = v;
+            if (do_bias) {
+                float f[EPC];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) bsum[i][e] += f[e];
+            }
         }
 #pragma unroll
         for (int i = 0; i < Q_CH; ++i) {
@@ -974,6 +988,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         __syncthreads();
     }
     if (nt <= 0) return;
+    if (do_bias) {   // reduce the per-thread column sums over the 256/PCPR row lanes through LDS (staging buffers are free now)
+        float* red = (float*)sP[0];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < P_CH; ++i) v += bsum[i][e];
+            red[prow0 * BNn + pc * EPC + e] = v;
+        }
+        __syncthreads();
+        if (t < BNn && n0 + t < a.Ng) {
+            float v = 0.f;
+            for (int rr = 0; rr < 256 / PCPR; ++rr) v += red[rr * BNn + t];
+            atomicAdd(a.dbias + g * a.Ng + n0 + t, v);
+        }
+    }
     // D[row = n (q*4+e)][col = k (r)]
 #pragma unroll
     for (int j = 0; j < TK; ++j) {
@@ -1020,7 +1050,7 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
 }
 
 extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, float* dw, const int64_t* dw_strides,
-                                 octa_stream_t stream) {
+                                 float* dbias, octa_stream_t stream) {
     int rc = check_desc(d, "octa_conv2d_wgrad");
     if (rc) return rc;
     OCTA_REQUIRE(x && dy && dw && dw_strides, "octa_conv2d_wgrad: null pointer");
@@ -1038,6 +1068,7 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
     a.ldx = d->ldx; a.xoff = d->xoff; a.ldy = d->ldy; a.yoff = d->yoff;
     a.M = d->B * d->OH * d->OW; a.Kpad = d->KH * d->KW * a.Cg;
     a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
+    a.dbias = dbias;
     return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
                                 : launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream);
 }

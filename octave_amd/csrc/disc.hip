@@ -91,17 +91,24 @@ __global__ __launch_bounds__(1024) void spectral_fwd_kernel(const float* __restr
     for (int j = t; j < K; j += nt) vs[j] = v[j];
     __syncthreads();
     if (iter) {
-        // v = normalize(W^T u)
+        // v = normalize(W^T u): column j is owned by the threads {j, j+K', ...}: each sums a strided subset of rows
+        // (consecutive threads read consecutive columns), partial sums meet in LDS
+        const int KP = (K + 63) / 64 * 64;            // columns padded to whole waves
+        const int G = nt / KP > 0 ? nt / KP : 1;      // row groups
+        const int j = t % KP, gidx = t / KP;
+        float s = 0.f;
+        if (j < K && gidx < G)
+            for (int i = gidx; i < Cout; i += G) s += w[(int64_t)i * K + j] * us[i];
+        __syncthreads();
+        if (gidx == 0 && j < K) vs[j] = 0.f;
+        __syncthreads();
+        if (j < K && gidx < G) atomicAdd(&vs[j], s);
+        __syncthreads();
         float nrm = 0.f;
-        for (int j = t; j < K; j += nt) {
-            float s = 0.f;
-            for (int i = 0; i < Cout; ++i) s += w[(int64_t)i * K + j] * us[i];
-            vs[j] = s;
-            nrm += s * s;
-        }
+        for (int jj = t; jj < K; jj += nt) nrm += vs[jj] * vs[jj];
         nrm = sqrtf(block_total(nrm, red));
         const float dv = fmaxf(nrm, eps);
-        for (int j = t; j < K; j += nt) vs[j] /= dv;
+        for (int jj = t; jj < K; jj += nt) vs[jj] /= dv;
         __syncthreads();
     }
     // wv = W v  (one wave per row, lanes over K)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(1024) void spectral_fwd_kernel(const float* __restr
 }
 extern "C" int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter, float eps, float* sigma,
                                       float* w_sn, octa_stream_t stream) {
-    OCTA_REQUIRE(w && u && v && sigma && w_sn && Cout > 0 && K > 0, "octa_spectral_norm_fwd: bad arguments");
+    OCTA_REQUIRE(w && u && v && sigma && w_sn && Cout > 0 && K > 0 && K <= 1024, "octa_spectral_norm_fwd: bad arguments (K <= 1024)");
     const size_t sh = (size_t)(2 * Cout + K + 16) * sizeof(float);
     OCTA_REQUIRE(sh <= 60000, "octa_spectral_norm_fwd: matrix too large for the single-block kernel");
     spectral_fwd_kernel<<<1, 1024, sh, (hipStream_t)stream>>>(w, u, v, Cout, K, do_power_iter, eps, sigma, w_sn);

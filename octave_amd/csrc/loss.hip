@@ -64,23 +64,27 @@ __global__ __launch_bounds__(256) void wpce_dice_partial_kernel(const float* __r
 
 // final[0..K) = w_c ; final[K..2K) = n_c ; final[2K + 2b] = inter_b ; final[2K + 2b + 1] = card_b
 template <int K>
-__global__ void wpce_dice_final_kernel(const float* __restrict__ partial, int B, int nblk, int64_t npix, int reduction_sum, float* __restrict__ fin,
-                                       float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void wpce_dice_final_kernel(const float* __restrict__ partial, int B, int nblk, int64_t npix, int reduction_sum,
+                                                             float* __restrict__ fin, float* __restrict__ out) {
+    // one wavefront: lanes stride over the block partials of a sample, wave_sum_d folds them
+    const int lane = threadIdx.x;
     double n[K], S[K];
     for (int k = 0; k < K; ++k) { n[k] = 0.0; S[k] = 0.0; }
     double dice = 0.0;
     for (int b = 0; b < B; ++b) {
-        double inter = 0.0, card = 0.0;
-        for (int j = 0; j < nblk; ++j) {
+        double inter = 0.0, card = 0.0, nb[K], Sb[K];
+        for (int k = 0; k < K; ++k) { nb[k] = 0.0; Sb[k] = 0.0; }
+        for (int j = lane; j < nblk; j += 64) {
             const float* p = partial + ((size_t)b * nblk + j) * (2 * K + 2);
-            for (int k = 0; k < K; ++k) { n[k] += (double)p[k]; S[k] += (double)p[K + k]; }
+            for (int k = 0; k < K; ++k) { nb[k] += (double)p[k]; Sb[k] += (double)p[K + k]; }
             inter += (double)p[2 * K]; card += (double)p[2 * K + 1];
         }
-        fin[2 * K + 2 * b] = (float)inter;
-        fin[2 * K + 2 * b + 1] = (float)card;
+        inter = wave_sum_d(inter); card = wave_sum_d(card);
+        for (int k = 0; k < K; ++k) { n[k] += wave_sum_d(nb[k]); S[k] += wave_sum_d(Sb[k]); }
+        if (lane == 0) { fin[2 * K + 2 * b] = (float)inter; fin[2 * K + 2 * b + 1] = (float)card; }
         dice += 1.0 - 2.0 * inter / (card + 1e-12);
     }
+    if (lane != 0) return;
     double ntot = 0.0;
     for (int k = 0; k < K; ++k) ntot += n[k];
     double l = 0.0;

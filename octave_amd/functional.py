@@ -278,7 +278,9 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
     return dx
 
 
-def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, groups: int, dw: Optional[Tensor] = None) -> Tensor:
+def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, groups: int, dw: Optional[Tensor] = None,
+                   dbias: Optional[Tensor] = None) -> Tensor:
+    """dw += wgrad; when `dbias` (fp32 [Cout]) is given the bias gradient is accumulated by the same kernel."""
     B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
     x, ldx = _conv_input(x, round8(Cin_g), groups)
     need = round8(Cout // groups) if groups == 1 else Cout
@@ -289,7 +291,7 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
         # rate of a strided OIHW target; MI355X_MICROARCH.md "Global float atomics")
         dw = torch.empty(tuple(w.shape), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
-    lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _st())
+    lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw
 
@@ -424,11 +426,18 @@ class Conv2dFn(Function):
             dy = raw_act_bwd(y, dy, act)
         dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups) if ctx.needs_input_grad[0] else None
         dw = db = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        b = ctx.bias_ref
+        if want_b:
+            db = _sink(b)
+            if db is None:
+                db = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
         if ctx.needs_input_grad[1]:
-            dw = _ret(w, raw_conv_wgrad(x, dy, w, stride, pad, groups, _sink(w)))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            b = ctx.bias_ref
-            db = _ret(b, raw_colsum(dy, _sink(b)))
+            dw = _ret(w, raw_conv_wgrad(x, dy, w, stride, pad, groups, _sink(w), db if want_b else None))   # bias gradient fused
+        elif want_b:
+            raw_colsum(dy, db)
+        if want_b:
+            db = _ret(b, db)
         return dx, dw, db, None, None, None, None
 
 

@@ -8,6 +8,33 @@ from . import functional as F_
 from ._lib import ACT_NONE
 
 
+# num_batches_tracked bookkeeping: per-call `add_(1)` is one tiny ATen launch per BatchNorm (93 per step).
+# A training loop may defer them: forwards then only enlist their counter and flush_bn_counters() bumps all
+# of them with ONE multi-tensor add.  state_dict()/eval semantics are unchanged after the flush.
+_DEFER_COUNTERS = False
+_PENDING_COUNTERS = []
+
+
+def defer_bn_counters(on: bool):
+    global _DEFER_COUNTERS
+    _DEFER_COUNTERS = bool(on)
+    if not on:
+        flush_bn_counters()
+
+
+def flush_bn_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
+def bump_counter(t):
+    if _DEFER_COUNTERS:
+        _PENDING_COUNTERS.append(t)
+    else:
+        t.add_(1)
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d with forward on the MFMA implicit-GEMM engine."""
 
@@ -43,9 +70,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         training = self.training or (self.running_mean is None)
         mom = 0.0 if self.momentum is None else self.momentum
         if training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
             if self.momentum is None:
+                self.num_batches_tracked.add_(1)
                 mom = 1.0 / float(self.num_batches_tracked)
+            else:
+                bump_counter(self.num_batches_tracked)
         return F_.batch_norm(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                              self.running_var if self.track_running_stats else None, mom, self.eps, training, relu, residual)
 

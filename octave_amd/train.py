@@ -19,6 +19,7 @@ from torch import Tensor, nn
 
 from . import functional as F_
 from ._lib import lib
+from .layers import defer_bn_counters, flush_bn_counters
 
 
 class FlatArena:
@@ -86,6 +87,7 @@ class TrainStep:
         self.seg_arena = FlatArena(seg_params)
         self.disc_arena = FlatArena(list(self.disc.parameters())) if self.adversarial else None
         F_.set_grad_sink(True)
+        defer_bn_counters(True)
 
     def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -119,4 +121,10 @@ class TrainStep:
             self.disc_arena.all_reduce(self.world)
             self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=inv_world)
             out["loss_disc"] = l_d.detach()
+        flush_bn_counters()
         return out
+
+    def close(self):
+        """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""
+        F_.set_grad_sink(False)
+        defer_bn_counters(False)

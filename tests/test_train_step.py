@@ -108,6 +108,9 @@ def test_train_step_object_fp32_matches_manual_adam():
         out = step(x, ys, mask_pyramid(real))
     finally:
         F_.set_grad_sink(False)
+        from octave_amd.layers import defer_bn_counters
+        defer_bn_counters(False)
+    assert int(a.segmentor.encoder_0_1_2[1].num_batches_tracked) == 1
     # twin: plain autograd accumulation + torch Adam
     seg_params = [p for n, p in b.segmentor.named_parameters() if not n.startswith("linear_head_")]
     opt_s = torch.optim.Adam(seg_params, lr=1e-3)
@@ -160,5 +163,7 @@ def test_train_step_bf16_runs_and_learns():
             assert all(np.isfinite(v.item()) for v in out.values())
     finally:
         F_.set_grad_sink(False)
+        from octave_amd.layers import defer_bn_counters
+        defer_bn_counters(False)
     print("[bf16 train] supervised loss per step:", ["%.4f" % v for v in losses])
     assert losses[-1] < losses[0]

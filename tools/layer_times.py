@@ -29,7 +29,7 @@ for kind, d, ptrs, keep in rec:
             shape, stride = ptrs[2], ptrs[3]
             if (shape, stride) not in scratch:
                 scratch[(shape, stride)] = torch.zeros(sum((s - 1) * t for s, t in zip(shape, stride)) + 1, device=dev)
-            L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], scratch[(shape, stride)].data_ptr(), (ctypes.c_int64 * 4)(*stride), st)
+            L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], scratch[(shape, stride)].data_ptr(), (ctypes.c_int64 * 4)(*stride), None, st)
     launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); launch(); launch(); launch(); e1.record(); e1.synchronize()
