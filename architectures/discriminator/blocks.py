@@ -54,11 +54,16 @@ class InstanceNoise(nn.Module):
     def draw(self) -> Tensor:
         return torch.normal(mean=self.mean, std=self.std, size=self.size)      # CPU generator, like ref :150
 
-    def forward(self, x: Tensor):
-        noise = self.draw()                      # drawn even when not added (ref :150-151)
+    def forward(self, x: Tensor, noise_dev: Tensor = None, fed: bool = False):
+        """`fed=True`: the (H, W) plane was drawn by the caller (same CPU-generator order) and already lives on
+        the device (hipGraph replay); otherwise it is drawn here exactly like the reference."""
         if not self.clipping:
             raise NotImplementedError("InstanceNoise without clipping is off the hot path")
-        nz = noise.to(x.device, non_blocking=True) if self.is_training else None
+        if fed:
+            nz = noise_dev if self.is_training else None
+        else:
+            noise = self.draw()                  # drawn even when not added (ref :150-151)
+            nz = noise.to(x.device, non_blocking=True) if self.is_training else None
         dtype = self.compute_dtype or torch.float32
         return F_.NoiseClipFn.apply(x, nz, dtype)
 
@@ -91,6 +96,7 @@ class DiscriminatorBlock(nn.Module):
         self.is_training = is_training
         self.depth = depth
         self.compute_dtype = None
+        self.rng_feed = None       # optional: object with next_noise()/next_sign() returning DEVICE tensors (octave_amd.train)
         in_channels = input_shape[1]
         modules = []
         if instance_noise:
@@ -131,9 +137,10 @@ class DiscriminatorBlock(nn.Module):
 
     def forward(self, y: Sequence[Tensor]):
         dtype = self.compute_dtype or torch.float32
+        feed = self.rng_feed
         if self._has_noise:
             self.stack_0[0].compute_dtype = dtype
-            s = self.stack_0[0](y[0])
+            s = self.stack_0[0](y[0], feed.next_noise(), True) if feed is not None else self.stack_0[0](y[0])
             s = self.stack_0[1](s)
         else:
             s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype))
@@ -145,6 +152,8 @@ class DiscriminatorBlock(nn.Module):
             except Exception as e:
                 raise Exception(f'Exception raised in depth = {i}') from e
         fc = self.out[0]
+        if self._has_label_noise and feed is not None:
+            return F_.FullConvFn.apply(s, fc.weight, fc.bias, 1.0, feed.next_sign())
         sign = self.out[2].draw_sign() if self._has_label_noise else 1.0
         return F_.FullConvFn.apply(s, fc.weight, fc.bias, sign)
 

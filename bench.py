@@ -83,9 +83,11 @@ def roofline_leg(step, batch, dtype_name):
     from octave_amd import functional as F_
     from octave_amd._lib import lib
     L = lib()
+    graphs, step._graphs = step._graphs, None      # record an EAGER step (a graph replay launches nothing from Python)
     F_.start_recording()
     step(*batch)
     rec = F_.stop_recording()
+    step._graphs = graphs
     torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
     REP = 3
@@ -179,6 +181,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--seg-only", action="store_true", help="BASELINE configs[1]: segmentor-only (WPCE+Dice)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -211,6 +214,9 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_begin:7.1f}s] {msg}", file=sys.stderr, flush=True)
     log(f"model built, {B}x3x{H}x{H} {args.dtype}, world {world}")
+    if not args.no_graph:
+        step.capture(*batch)
+        log("step captured into hipGraphs (2 eager warm-up steps)")
     for i in range(args.warmup):
         step(*batch)
         torch.cuda.synchronize()
@@ -224,6 +230,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(*batch)
+    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (launch-bound if ~ the total)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -233,7 +240,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss_seg"].item())
-    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host enqueue {t_enq / args.steps * 1e3:.1f} ms/step)")
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)
 
@@ -246,7 +253,8 @@ def main():
             "config": {"workload": ("OctaScribbleNet full adversarial step (segmentor + LS-GAN discriminator + InterlayerDivergence), "
                                     if not args.seg_only else "OctaScribbleNet segmentor-only step (WeightedPartialCE + Dice), ")
                        + f"batch {B}/GPU, {H}x{H}", "global_batch": world * B, "image": H, "parallelism": f"dp{world}",
-                       "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)"},
+                       "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)",
+                       "launch": "eager" if args.no_graph else "hipGraph replay (3 graphs around the 2 gradient all-reduces)"},
             "final_loss_seg": round(loss, 5),
         }
         if not args.no_roofline:

@@ -255,16 +255,20 @@ int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u
 /* Full-extent conv = per-sample dot product (blocks.py:68-72): out[b] = x[b,:].w + bias.
  * x NHWC [B, n] of dtype, w fp32 [n] in the same (h,w,c) order. */
 int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n,
-                      int dtype, float sign, octa_stream_t stream);
+                      int dtype, float sign, const float* sign_dev /* optional device scalar, multiplies sign */,
+                      octa_stream_t stream);
 int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw,
-                      float* dbias, int B, int64_t n, int dtype, float sign, octa_stream_t stream);
+                      float* dbias, int B, int64_t n, int dtype, float sign, const float* sign_dev,
+                      octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: fused Adam over a flat fp32 parameter arena (train step a17).
  * ---------------------------------------------------------------------------------------- */
+/* dyn (optional, device): {1 - beta1^t, sqrt(1 - beta2^t)} read at run time instead of being derived
+ * from `step` on the host, so a captured hipGraph can be replayed with advancing bias corrections. */
 int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale,
-                   octa_stream_t stream);
+                   const float* dyn, octa_stream_t stream);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);

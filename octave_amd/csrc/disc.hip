@@ -175,29 +175,31 @@ extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, con
 // ------------------------------------------------------------------------------------------ full-extent conv = dot product
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int64_t n,
-                                                           float sign, int nblk) {
+                                                           float sign, const float* __restrict__ sign_dev, int nblk) {
     __shared__ float red[16];
+    if (sign_dev) sign *= sign_dev[0];
     const int b = blockIdx.y;
     float acc[1] = {0.f};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) acc[0] += DT<T>::ld(x + b * n + i) * w[i];
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) atomicAdd(out + b, sign * acc[0]);
 }
-__global__ void fullconv_init_kernel(const float* __restrict__ bias, float* __restrict__ out, int B, float sign) {
+__global__ void fullconv_init_kernel(const float* __restrict__ bias, float* __restrict__ out, int B, float sign, const float* __restrict__ sign_dev) {
+    if (sign_dev) sign *= sign_dev[0];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) out[i] = sign * (bias ? bias[0] : 0.f);
 }
 extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n, int dtype, float sign,
-                                 octa_stream_t stream) {
+                                 const float* sign_dev, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && out && B > 0 && n > 0, "octa_fullconv_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    fullconv_init_kernel<<<cdiv(B, 64), 64, 0, st>>>(bias, out, B, sign);
+    fullconv_init_kernel<<<cdiv(B, 64), 64, 0, st>>>(bias, out, B, sign, sign_dev);
     OCTA_CHECK_LAUNCH("fullconv_init");
     int nblk = (int)(cdiv64(n, 256 * 8) > 64 ? 64 : cdiv64(n, 256 * 8));
     if (nblk < 1) nblk = 1;
     dim3 grid(nblk, B);
-    if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, nblk);
-    else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, nblk);
+    if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, sign_dev, nblk);
+    else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, sign_dev, nblk);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_fwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_fwd");
     return OCTA_OK;
@@ -206,7 +208,8 @@ extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bia
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dout,
                                                            T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int B, int64_t n,
-                                                           float sign) {
+                                                           float sign, const float* __restrict__ sign_dev) {
+    if (sign_dev) sign *= sign_dev[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float wi = w[i];
         float g = 0.f;
@@ -224,12 +227,12 @@ __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__
     }
 }
 extern "C" int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw, float* dbias, int B, int64_t n,
-                                 int dtype, float sign, octa_stream_t stream) {
+                                 int dtype, float sign, const float* sign_dev, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && dout && B > 0 && n > 0, "octa_fullconv_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)(cdiv64(n, 256) > 2048 ? 2048 : cdiv64(n, 256));
-    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign);
-    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign);
+    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev);
+    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_bwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_bwd");
     return OCTA_OK;

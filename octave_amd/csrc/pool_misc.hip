@@ -339,7 +339,9 @@ extern "C" int octa_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
 
 // ------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs) {
+                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs,
+                                                   const float* __restrict__ dyn) {
+    if (dyn) { bc1 = dyn[0]; bc2s = dyn[1]; }     // bias corrections from device memory (hipGraph replay)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gg = g[i] * gs;
         const float pp = p[i];
@@ -352,11 +354,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 extern "C" int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, int step, float grad_scale, octa_stream_t stream) {
-    OCTA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "octa_adam_step: bad arguments");
+                              float weight_decay, int step, float grad_scale, const float* dyn, octa_stream_t stream) {
+    OCTA_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || dyn), "octa_adam_step: bad arguments");
+    if (step < 1) step = 1;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, dyn);
     OCTA_CHECK_LAUNCH("adam");
     return OCTA_OK;
 }

@@ -1017,7 +1017,7 @@ class FullConvFn(Function):
     """Conv2d whose kernel covers the whole map (blocks.py:68-72) = one dot product per sample."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, sign):
+    def forward(ctx, x, w, bias, sign, sign_dev=None):
         x = dense_nhwc(x)
         B, C, H, W = x.shape
         if tuple(w.shape) != (1, C, H, W):
@@ -1026,25 +1026,25 @@ class FullConvFn(Function):
         s = w.stride()
         lib().octa_pack_weight_fwd(_p(w.detach()), s[0], s[1], s[2], s[3], _p(wp), 1, C, H, W, 1, C, OCTA_F32, _st())
         out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
-        lib().octa_fullconv_fwd(_p(x), _p(wp), _p(bias), _p(out), B, H * W * C, _dt(x), float(sign), _st())
+        lib().octa_fullconv_fwd(_p(x), _p(wp), _p(bias), _p(out), B, H * W * C, _dt(x), float(sign), _p(sign_dev), _st())
         ctx.sign = float(sign)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, wp)
+        ctx.save_for_backward(x, wp, sign_dev)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        x, wp = ctx.saved_tensors
+        x, wp, sign_dev = ctx.saved_tensors
         B, C, H, W = x.shape
         dout = dout.float().contiguous()
         dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
         dwp = torch.zeros_like(wp)
         db = torch.zeros((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dwp), _p(db), B, H * W * C, _dt(x), ctx.sign, _st())
+        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dwp), _p(db), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), _st())
         dw = torch.empty((1, C, H, W), dtype=torch.float32, device=x.device)
         lib().octa_nhwc_to_nchw(_p(dwp), C, 0, OCTA_F32, _p(dw), 1, C, H, W, 0, _st())
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def fill_(t: Tensor, value: float):

@@ -57,17 +57,93 @@ class FlatArena:
         if world > 1:
             dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
 
-    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-        self.step_count += 1
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None):
+        """One fused Adam launch over the arena.  `dyn` (device, 2 floats) carries the bias corrections when the
+        launch is captured in a hipGraph; the caller then advances step_count / dyn itself (set_dyn)."""
+        if dyn is None:
+            self.step_count += 1
         lib().octa_adam_step(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.numel, lr, betas[0], betas[1],
-                             eps, weight_decay, self.step_count, grad_scale, torch.cuda.current_stream().cuda_stream)
+                             eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
         F_.bump_weight_epoch()
+
+    def advance_dyn(self, ring, betas):
+        self.step_count += 1
+        h = ring.slot()
+        h[0] = 1.0 - betas[0] ** self.step_count
+        h[1] = (1.0 - betas[1] ** self.step_count) ** 0.5
+        ring.push()
 
 
 def mask_pyramid(mask: Tensor, levels: int = 5) -> List[Tensor]:
     """Real multi-scale pyramid for the discriminator: nearest down-sampling by 2**i (contract of
     discriminator/blocks.py:114-125; views, no copy)."""
     return [mask[:, :, ::2 ** i, ::2 ** i] for i in range(levels)]
+
+
+class _PinnedRing:
+    """Rotating pinned staging buffers for small host->device updates issued while the GPU still runs
+    earlier steps: a slot is only rewritten after the async copy that read it has completed (event)."""
+
+    def __init__(self, shape, device, slots=4):
+        self.host = [torch.zeros(shape, pin_memory=True) for _ in range(slots)]
+        self.events = [None] * slots
+        self.dev = torch.zeros(shape, device=device)
+        self.i = 0
+
+    def slot(self) -> Tensor:
+        ev = self.events[self.i]
+        if ev is not None:
+            ev.synchronize()
+        return self.host[self.i]
+
+    def push(self):
+        self.dev.copy_(self.host[self.i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.i] = ev
+        self.i = (self.i + 1) % len(self.host)
+
+
+class _RngFeed:
+    """The CPU random draws of the three discriminator calls of a step (InstanceNoise plane then LabelNoise
+    uniform, per call, from the GLOBAL CPU generator exactly like the reference: blocks.py:149-170), staged in
+    pinned memory and copied to static device buffers so that a captured hipGraph can consume them."""
+
+    def __init__(self, disc, device, calls=3):
+        self.has_noise, self.has_label = disc._has_noise, disc._has_label_noise
+        self.noise_mod = disc.stack_0[0] if self.has_noise else None
+        self.label_mod = disc.out[2] if self.has_label else None
+        hw = self.noise_mod.size if self.has_noise else (1, 1)
+        self.calls = calls
+        self.noise_ring = _PinnedRing((calls,) + tuple(hw), device)
+        self.sign_ring = _PinnedRing((calls,), device)
+        self.noise_dev, self.sign_dev = self.noise_ring.dev, self.sign_ring.dev
+        self.sign_dev.fill_(1.0)
+        self.i_noise = self.i_sign = 0
+
+    def refill(self):
+        nh, sh = self.noise_ring.slot(), self.sign_ring.slot()
+        for c in range(self.calls):
+            if self.has_noise:
+                nh[c].copy_(self.noise_mod.draw())
+            sh[c] = self.label_mod.draw_sign() if self.has_label else 1.0
+        self.noise_ring.push()
+        self.sign_ring.push()
+        self.rewind()
+
+    def rewind(self):
+        self.i_noise = self.i_sign = 0
+
+    def next_noise(self):
+        t = self.noise_dev[self.i_noise % self.calls]
+        self.i_noise += 1
+        return t
+
+    def next_sign(self):
+        t = self.sign_dev[self.i_sign % self.calls:self.i_sign % self.calls + 1]
+        self.i_sign += 1
+        return t
 
 
 class TrainStep:
@@ -88,11 +164,11 @@ class TrainStep:
         self.disc_arena = FlatArena(list(self.disc.parameters())) if self.adversarial else None
         F_.set_grad_sink(True)
         defer_bn_counters(True)
+        self._graphs = None
 
-    def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
-        out: Dict[str, Tensor] = {}
-        inv_world = 1.0 / self.world
-        # ---- segmentor (generator) step
+    # ------------------------------------------------------------------ the three phases of a step
+    # (split at the two gradient all-reduces so that the collectives stay OUTSIDE any captured graph)
+    def _phase_segmentor(self, x, ys, out):
         self.seg_arena.zero_grad()
         att, agg, _ = self.seg(x)
         l = F_.wpce_dice(agg, ys, from_logits=True)
@@ -106,25 +182,117 @@ class TrainStep:
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
         loss.backward()
-        self.seg_arena.all_reduce(self.world)
-        self.seg_arena.adam(self.lr, self.betas, grad_scale=inv_world)
         out["loss_seg"] = loss.detach()
-        # ---- discriminator step
+        flush_bn_counters()
+        return [a.detach() for a in att]
+
+    def _phase_discriminator(self, att, real_pyramid, out, dyn=None):
+        self.seg_arena.adam(self.lr, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
         if self.adversarial:
-            if real_pyramid is None:
-                raise ValueError("the adversarial step needs the real mask pyramid")
             self.disc_arena.zero_grad()          # drop what the generator step left in D's gradients
             d_real = self.disc(real_pyramid)
-            d_fake = self.disc([a.detach() for a in att])
+            d_fake = self.disc(att)
             l_d = F_.lsgan_discriminator(d_real, d_fake)
             l_d.backward()
-            self.disc_arena.all_reduce(self.world)
-            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=inv_world)
             out["loss_disc"] = l_d.detach()
-        flush_bn_counters()
+
+    def _phase_finish(self, dyn=None):
+        if self.adversarial:
+            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+
+    def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
+        if self.adversarial and real_pyramid is None:
+            raise ValueError("the adversarial step needs the real mask pyramid")
+        if self._graphs is not None:
+            return self._replay(x, ys, real_pyramid)
+        out: Dict[str, Tensor] = {}
+        att = self._phase_segmentor(x, ys, out)
+        self.seg_arena.all_reduce(self.world)
+        self._phase_discriminator(att, real_pyramid, out)
+        if self.adversarial:
+            self.disc_arena.all_reduce(self.world)
+        self._phase_finish()
         return out
+
+    # ------------------------------------------------------------------ hipGraph capture / replay
+    def capture(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None, warmup: int = 2):
+        """Capture the step into three hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm) around the two
+        all-reduces.  Inputs are copied into static buffers on every call; the CPU random draws of the
+        discriminator are staged through _RngFeed; Adam's bias corrections come from device memory."""
+        dev = x.device
+        self._sx, self._sys = x.clone(), ys.clone()
+        self._sreal = [r.contiguous().clone() for r in real_pyramid] if real_pyramid is not None else None
+        if self.adversarial:
+            self._feed = _RngFeed(self.disc, dev)
+            self.disc.rng_feed = self._feed
+        self._dyn = [_PinnedRing((2,), dev) for _ in range(2)]
+        self._dyn_dev = [r.dev for r in self._dyn]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):             # warm-up off the default stream, as graph capture requires
+            for _ in range(warmup):
+                self._eager_static()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self._out: Dict[str, Tensor] = {}
+        F_.bump_weight_epoch()
+        if self.adversarial:
+            self._feed.rewind()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._att = self._phase_segmentor(self._sx, self._sys, self._out)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._phase_discriminator(self._att, self._sreal, self._out, dyn=self._dyn_dev[0])
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3, pool=g1.pool()):
+            self._phase_finish(dyn=self._dyn_dev[1])
+        self._graphs = (g1, g2, g3)
+        return self
+
+    def _eager_static(self):
+        out: Dict[str, Tensor] = {}
+        if self.adversarial:
+            self._feed.refill()
+        self.seg_arena.advance_dyn(self._dyn[0], self.betas)
+        att = self._phase_segmentor(self._sx, self._sys, out)
+        self.seg_arena.all_reduce(self.world)
+        self._phase_discriminator(att, self._sreal, out, dyn=self._dyn_dev[0])
+        if self.adversarial:
+            self.disc_arena.advance_dyn(self._dyn[1], self.betas)
+            self.disc_arena.all_reduce(self.world)
+        self._phase_finish(dyn=self._dyn_dev[1])
+        return out
+
+    def _replay(self, x, ys, real_pyramid):
+        if x is not self._sx:
+            self._sx.copy_(x, non_blocking=True)
+        if ys is not self._sys:
+            self._sys.copy_(ys, non_blocking=True)
+        if self._sreal is not None and real_pyramid is not None:
+            for dst, src in zip(self._sreal, real_pyramid):
+                if dst is not src:
+                    dst.copy_(src, non_blocking=True)
+        if self.adversarial:
+            self._feed.refill()
+        g1, g2, g3 = self._graphs
+        self.seg_arena.advance_dyn(self._dyn[0], self.betas)
+        g1.replay()
+        self.seg_arena.all_reduce(self.world)
+        if self.adversarial:
+            self.disc_arena.advance_dyn(self._dyn[1], self.betas)
+        g2.replay()
+        if self.adversarial:
+            self.disc_arena.all_reduce(self.world)
+        g3.replay()
+        F_.bump_weight_epoch()      # the weights moved behind the pack cache's back
+        return self._out
 
     def close(self):
         """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""
         F_.set_grad_sink(False)
         defer_bn_counters(False)
+        if self.disc is not None:
+            self.disc.rng_feed = None
+        self._graphs = None

@@ -167,3 +167,54 @@ def test_train_step_bf16_runs_and_learns():
         defer_bn_counters(False)
     print("[bf16 train] supervised loss per step:", ["%.4f" % v for v in losses])
     assert losses[-1] < losses[0]
+
+
+def test_train_step_hipgraph_replay_matches_eager():
+    """TrainStep.capture(): three hipGraphs around the two all-reduces; a replay must reproduce the eager step
+    (same CPU random draws, same Adam bias corrections).  Float atomics make even two EAGER runs differ and
+    Adam's first steps (update = lr * sign(g)) amplify that, so the band is calibrated on an eager twin."""
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    Bn, H = 6, 48
+    x, ys, real = _inputs(Bn, H, dev)
+    pyr = mask_pyramid(real)
+
+    def make():
+        net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+        fill_state_dict(net.state_dict())
+        return net.to(dev).train()
+
+    def eager(n):
+        net = make()
+        st = TrainStep(net, lr=1e-4, compute_dtype=torch.float32)
+        try:
+            torch.manual_seed(11)
+            for _ in range(n):
+                o = {k: v.clone() for k, v in st(x, ys, pyr).items()}
+        finally:
+            st.close()
+        return net, st, o
+    a, sa, oa = eager(2)
+    a2, _, oa2 = eager(2)
+    b = make()
+    sb = TrainStep(b, lr=1e-4, compute_dtype=torch.float32)
+    try:
+        torch.manual_seed(11)
+        sb.capture(x, ys, pyr, warmup=1)          # one real (eager) step on the static buffers, then capture
+        ob = {k: v.clone() for k, v in sb(x, ys, pyr).items()}
+    finally:
+        sb.close()
+    torch.cuda.synchronize()
+    for k in oa:
+        band = 3 * abs(oa[k].item() - oa2[k].item()) + 2e-3 * abs(oa[k].item()) + 1e-5
+        assert abs(oa[k].item() - ob[k].item()) <= band, (k, {n: (oa[n].item(), oa2[n].item(), ob[n].item()) for n in oa})
+    assert sa.seg_arena.step_count == sb.seg_arena.step_count == 2 and sb.disc_arena.step_count == 2
+    ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
+    for k in ("segmentor.encoder_0_1_2.1.running_mean", "segmentor.decoder_0.conv.1.running_var",
+              "discriminator.spectral_dict.spectral_3.0.weight_u"):
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=5e-3, atol=1e-5), k
+    assert int(bb["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == 2
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    d = max((pa[k] - pb[k]).abs().max().item() for k in pa)
+    assert d <= 4.5e-4, d       # 2 Adam steps of lr 1e-4: identical up to sign flips of near-zero gradients
