@@ -165,6 +165,20 @@ int octa_splat_bwd(const void* dout, const void* x, const float* logits, const v
                    const float* dgap, void* dx, float* dlogits, int B, int HW, int C, int dtype,
                    int relu, int phase, octa_stream_t stream);
 
+/* The attention micro-net on (B, C) vectors (resnest.py:118-125), exact fp32, 2 <= B <= 32:
+ * h1 = fc1(gap) [grouped 1x1, + bias]; h2 = relu(bn1(h1)) [batch statistics when training, running stats
+ * updated]; logits = fc2(h2).  w1: [inter][C/groups], w2: [2C][inter/groups] dense.
+ * The backward consumes dlogits and produces dgap plus ACCUMULATED (+=) parameter gradients. */
+int octa_splat_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                       int training, const float* w2, const float* b2, float* h1, float* h2, float* mean,
+                       float* invstd, float* logits, int B, int C, int inter, int groups, octa_stream_t stream);
+int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2,
+                       const float* h1, const float* h2, const float* mean, const float* invstd,
+                       const float* gamma, float* dh1_workspace /* B*inter */, float* dgap, float* dw1,
+                       float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C,
+                       int inter, int groups, octa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Attention gate / head (segmentor/blocks.py:38-46; compose.py:79,181): per-pixel K-class linear
  * (K <= 8), channel softmax, x * sum_{c>=1} y_c.  Class maps are fp32 NCHW (user-facing).

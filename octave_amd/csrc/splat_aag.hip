@@ -237,6 +237,232 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
     return OCTA_OK;
 }
 
+// =========================================================================================== SplAt attention micro-net
+// fc1 (grouped 1x1) -> bn1 over the batch -> relu -> fc2 (grouped 1x1) on (B, C) vectors (resnest.py:118-125):
+// a few MFLOP, so instead of ~25 generic launches per split-attention block each direction is a handful of
+// wave-per-output-row kernels in exact fp32 (one wavefront = one output channel, lanes stride the input
+// channels, B <= 32 accumulators per lane, wavefront shuffles for the sums).
+#define SPLAT_MAXB 32
+
+// block (= 1 wave) per fc1 output channel j
+__global__ __launch_bounds__(64) void splat_mlp_fwd1_kernel(const float* __restrict__ gap, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rm,
+                                                            float* __restrict__ rv, float momentum, float eps, int training, float* __restrict__ h1,
+                                                            float* __restrict__ h2, float* __restrict__ mean, float* __restrict__ invstd, int B, int C,
+                                                            int inter, int groups) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int Cg = C / groups, grp = j / (inter / groups);
+    const float* wr = w1 + (size_t)j * Cg;
+    float acc[SPLAT_MAXB];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
+    for (int c = lane; c < Cg; c += 64) {
+        const float wv = wr[c];
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) acc[b] += wv * gap[(size_t)b * C + grp * Cg + c];
+    }
+    const float bias = b1 ? b1[j] : 0.f;
+    float m = 0.f;
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) { acc[b] = wave_sum(acc[b]) + bias; m += acc[b]; }
+    float mu, is;
+    if (training) {
+        mu = m / (float)B;
+        float var = 0.f;
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) { const float d = acc[b] - mu; var += d * d; }
+        var /= (float)B;
+        is = 1.f / sqrtf(var + eps);
+        if (lane == 0) {
+            if (rm) rm[j] = (1.f - momentum) * rm[j] + momentum * mu;
+            if (rv) rv[j] = (1.f - momentum) * rv[j] + momentum * (B > 1 ? var * (float)B / (float)(B - 1) : var);
+        }
+    } else {
+        mu = rm[j];
+        is = 1.f / sqrtf(rv[j] + eps);
+    }
+    if (lane == 0) { mean[j] = mu; invstd[j] = is; }
+    const float g = gamma[j], be = beta[j];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B && lane == (b & 63)) {
+            h1[(size_t)b * inter + j] = acc[b];
+            const float o = (acc[b] - mu) * is * g + be;
+            h2[(size_t)b * inter + j] = o > 0.f ? o : 0.f;
+        }
+}
+// block per fc2 output channel n: logits[b][n]
+__global__ __launch_bounds__(64) void splat_mlp_fwd2_kernel(const float* __restrict__ h2, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ logits, int B, int inter, int N, int groups) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int Ig = inter / groups, grp = n / (N / groups);
+    const float* wr = w2 + (size_t)n * Ig;
+    float acc[SPLAT_MAXB];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
+    for (int j = lane; j < Ig; j += 64) {
+        const float wv = wr[j];
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) acc[b] += wv * h2[(size_t)b * inter + grp * Ig + j];
+    }
+    const float bias = b2 ? b2[n] : 0.f;
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) { const float v = wave_sum(acc[b]) + bias; if (lane == (b & 63)) logits[(size_t)b * N + n] = v; }
+}
+extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* gamma, const float* beta, float* rm, float* rv,
+                                  float momentum, float eps, int training, const float* w2, const float* b2, float* h1, float* h2, float* mean,
+                                  float* invstd, float* logits, int B, int C, int inter, int groups, octa_stream_t stream) {
+    OCTA_REQUIRE(gap && w1 && gamma && beta && w2 && h1 && h2 && mean && invstd && logits, "octa_splat_mlp_fwd: null pointer");
+    OCTA_REQUIRE(B >= 1 && B <= SPLAT_MAXB && groups >= 1 && C % groups == 0 && inter % groups == 0, "octa_splat_mlp_fwd: needs 1 <= B <= 32 (got %d)", B);
+    OCTA_REQUIRE(training ? B > 1 : (rm && rv), "octa_splat_mlp_fwd: batch statistics need B > 1, eval needs running stats");
+    hipStream_t st = (hipStream_t)stream;
+    splat_mlp_fwd1_kernel<<<inter, 64, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_fwd1");
+    splat_mlp_fwd2_kernel<<<2 * C, 64, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_fwd2");
+    return OCTA_OK;
+}
+
+// backward A: block per j.  dh2[b][j] = sum_n dl[b][n] W2[n][j]  -> relu mask -> bn1 backward -> dh1[b][j]; dgamma/dbeta +=
+__global__ __launch_bounds__(64) void splat_mlp_bwdA_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+                                                            const float* __restrict__ h2, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dh1,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1, int B,
+                                                            int inter, int N, int groups) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int Ig = inter / groups, Ng = N / groups, grp = j / Ig, jl = j - grp * Ig;
+    float acc[SPLAT_MAXB];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
+    for (int nn = lane; nn < Ng; nn += 64) {
+        const int n = grp * Ng + nn;
+        const float wv = w2[(size_t)n * Ig + jl];
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) acc[b] += wv * dl[(size_t)b * N + n];
+    }
+    const float mu = mean[j], is = invstd[j], g = gamma[j];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) {
+            float d = wave_sum(acc[b]);
+            if (!(h2[(size_t)b * inter + j] > 0.f)) d = 0.f;
+            acc[b] = d;
+            s1 += d;
+            s2 += d * (h1[(size_t)b * inter + j] - mu) * is;
+        }
+    const float m1 = s1 / (float)B, m2 = s2 / (float)B;
+    float sdh = 0.f;
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) {
+            const float xh = (h1[(size_t)b * inter + j] - mu) * is;
+            const float v = g * is * (acc[b] - m1 - xh * m2);
+            sdh += v;
+            if (lane == (b & 63)) dh1[(size_t)b * inter + j] = v;
+        }
+    if (lane == 0) {
+        dgamma[j] += s2;
+        dbeta[j] += s1;
+        if (db1) db1[j] += sdh;
+    }
+}
+// backward B: block per n.  dW2[n][j] += sum_b dl[b][n] h2[b][j];  db2[n] += sum_b dl[b][n]
+__global__ __launch_bounds__(64) void splat_mlp_bwdB_kernel(const float* __restrict__ dl, const float* __restrict__ h2, float* __restrict__ dw2,
+                                                            float* __restrict__ db2, int B, int inter, int N, int groups) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int Ig = inter / groups, grp = n / (N / groups);
+    float d[SPLAT_MAXB];
+    float sb = 0.f;
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) { d[b] = b < B ? dl[(size_t)b * N + n] : 0.f; sb += d[b]; }
+    for (int j = lane; j < Ig; j += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) a += d[b] * h2[(size_t)b * inter + grp * Ig + j];
+        dw2[(size_t)n * Ig + j] += a;
+    }
+    if (lane == 0 && db2) db2[n] += sb;
+}
+// backward C: dgap[b][c] += sum_j dh1[b][j] W1[j][c].  Block = 64 channels c (lanes) x 4 waves; the j range of the
+// channel's group is split over gridDim.y blocks and the block's 4 waves (coalesced W1 rows), partial sums meet in
+// LDS and leave with one atomic per (b, c).  dgap is zeroed by the host wrapper.
+__global__ __launch_bounds__(256) void splat_mlp_bwdC_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, float* __restrict__ dgap, int B,
+                                                             int C, int inter, int groups) {
+    __shared__ float red[4][SPLAT_MAXB][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int Cg = C / groups, Ig = inter / groups;
+    const bool live = c < C;
+    const int grp = live ? c / Cg : 0, cl = live ? c - grp * Cg : 0;
+    float acc[SPLAT_MAXB];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
+    const int per = (Ig + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per, j1 = min(Ig, j0 + per);
+    if (live)
+        for (int jj = j0 + wave; jj < j1; jj += 4) {
+            const int j = grp * Ig + jj;
+            const float wv = w1[(size_t)j * Cg + cl];
+#pragma unroll
+            for (int b = 0; b < SPLAT_MAXB; ++b)
+                if (b < B) acc[b] += wv * dh1[(size_t)b * inter + j];
+        }
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) red[wave][b][lane] = acc[b];
+    __syncthreads();
+    for (int b = wave; b < B; b += 4)
+        if (live) atomicAdd(dgap + (size_t)b * C + c, red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]);
+}
+// backward D: block per j.  dW1[j][c] += sum_b dh1[b][j] gap[b][c]
+__global__ __launch_bounds__(64) void splat_mlp_bwdD_kernel(const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
+                                                            int C, int inter, int groups) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int Cg = C / groups, grp = j / (inter / groups);
+    float d[SPLAT_MAXB];
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b) d[b] = b < B ? dh1[(size_t)b * inter + j] : 0.f;
+    for (int c = lane; c < Cg; c += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int b = 0; b < SPLAT_MAXB; ++b)
+            if (b < B) a += d[b] * gap[(size_t)b * C + grp * Cg + c];
+        dw1[(size_t)j * Cg + c] += a;
+    }
+}
+extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
+                                  const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1, float* db1,
+                                  float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, octa_stream_t stream) {
+    OCTA_REQUIRE(dlogits && gap && w1 && w2 && h1 && h2 && mean && invstd && gamma && dh1_ws && dgap && dw1 && dgamma && dbeta && dw2,
+                 "octa_splat_mlp_bwd: null pointer");
+    OCTA_REQUIRE(B > 1 && B <= SPLAT_MAXB && groups >= 1, "octa_splat_mlp_bwd: needs 2 <= B <= 32");
+    hipStream_t st = (hipStream_t)stream;
+    splat_mlp_bwdA_kernel<<<inter, 64, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, B, inter, 2 * C, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdA");
+    splat_mlp_bwdB_kernel<<<2 * C, 64, 0, st>>>(dlogits, h2, dw2, db2, B, inter, 2 * C, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdB");
+    if (hipMemsetAsync(dgap, 0, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
+    {
+        const int Ig = inter / groups;
+        int js = Ig / 32;                 // >= 32 rows of W1 per block
+        if (js < 1) js = 1;
+        if (js > 8) js = 8;
+        splat_mlp_bwdC_kernel<<<dim3(cdiv(C, 64), js), 256, 0, st>>>(dh1_ws, w1, dgap, B, C, inter, groups);
+    }
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdC");
+    splat_mlp_bwdD_kernel<<<inter, 64, 0, st>>>(dh1_ws, gap, dw1, B, C, inter, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdD");
+    return OCTA_OK;
+}
+
 // =========================================================================================== AAG / head
 // LPP lanes cooperate on one pixel; each lane owns CPL chunks (channels (lp + j*LPP)*EPC ..).
 template <typename T, int K, int CPL>

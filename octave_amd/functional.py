@@ -642,61 +642,91 @@ def pad_bottom_right(x, ph, pw):
     return PadBRFn.apply(x, ph, pw)
 
 
+def _dense2d(w: Tensor) -> Optional[Tensor]:
+    """(O, I, 1, 1) conv weight (or its grad) as a dense [O][I] fp32 view, or None if its memory is not that."""
+    O, I = w.shape[0], w.shape[1]
+    if w.dtype != torch.float32 or w.stride(1) != 1 or (O > 1 and w.stride(0) != I):
+        return None
+    return w
+
+
+def _grad_buf(p: Optional[Tensor], dense2d: bool = False):
+    """fp32 accumulation target for parameter p: its pre-assigned .grad (gradient sink) or fresh zeros."""
+    if p is None:
+        return None, None
+    g = _sink(p)
+    if g is not None and (not dense2d or _dense2d(g) is not None):
+        return g, None
+    z = torch.zeros(tuple(p.shape), dtype=torch.float32, device=p.device)
+    return z, z
+
+
 class SplatTailFn(Function):
     """Everything of SplAtConv2d.forward after bn0+relu (extra/resnest.py:106-138), radix 2:
     radix-sum GAP -> fc1 -> bn1 -> relu -> fc2 -> radix softmax -> weighted sum [-> relu].
-    One Function so that the backward can run its two streaming passes around the micro-net."""
+    One Function so that the backward can run its two streaming passes around the micro-net, which itself is
+    two (forward) / four (backward) small exact-fp32 kernels."""
 
     @staticmethod
     def forward(ctx, xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu):
         xr = dense_nhwc(xr)
         B, C2, H, W = xr.shape
         C, HW = C2 // 2, H * W
+        inter = fc1_w.shape[0]
+        if B > 32:
+            raise OctaError(f"split attention: per-GPU batch {B} > 32 is not supported by the fused attention micro-net")
+        if training and B < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, inter, 1, 1)}")
         L = lib()
-        gap = torch.empty((B, C), dtype=torch.float32, device=xr.device)
+        dev = xr.device
+        gap = torch.empty((B, C), dtype=torch.float32, device=dev)
         L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), _st())
-        gap4 = gap.view(B, 1, 1, C).permute(0, 3, 1, 2)                     # (B,C,1,1) NHWC fp32
-        h1 = raw_conv_fwd(gap4, fc1_w, fc1_b, 1, 0, cardinality)
-        h2, mean1, invstd1, h1n = raw_bn_fwd(h1, g1, b1, rm1, rv1, momentum, eps, training, True)
-        logits4 = raw_conv_fwd(h2, fc2_w, fc2_b, 1, 0, cardinality)         # (B,2C,1,1)
-        logits = logits4.permute(0, 2, 3, 1).reshape(B, C2)
-        out = nhwc_empty(B, C, H, W, xr.dtype, xr.device)
+        w1, w2 = _dense2d(fc1_w.detach()), _dense2d(fc2_w.detach())
+        if w1 is None:
+            w1 = fc1_w.detach().float().contiguous()
+        if w2 is None:
+            w2 = fc2_w.detach().float().contiguous()
+        h1 = torch.empty((B, inter), dtype=torch.float32, device=dev)
+        h2 = torch.empty_like(h1)
+        mean1 = torch.empty((inter,), dtype=torch.float32, device=dev)
+        invstd1 = torch.empty_like(mean1)
+        logits = torch.empty((B, C2), dtype=torch.float32, device=dev)
+        L.octa_splat_mlp_fwd(_p(gap), _p(w1), _p(fc1_b), _p(g1), _p(b1), _p(rm1), _p(rv1), momentum, eps, int(training), _p(w2), _p(fc2_b),
+                             _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(logits), B, C, inter, cardinality, _st())
+        out = nhwc_empty(B, C, H, W, xr.dtype, dev)
         L.octa_splat_apply(_p(xr), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
-        ctx.cfg = (cardinality, training, relu, B, C, H, W)
-        ctx.refs = (fc1_b, b1, fc2_b)
-        ctx.save_for_backward(xr, out if relu else None, logits, gap4, h1n, h2, mean1, invstd1, g1, fc1_w, fc2_w)
+        ctx.cfg = (cardinality, training, relu, B, C, H, W, inter)
+        ctx.refs = (fc1_w, fc1_b, g1, b1, fc2_w, fc2_b)
+        ctx.save_for_backward(xr, out if relu else None, logits, gap, h1, h2, mean1, invstd1, w1, w2)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        xr, out, logits, gap4, h1, h2, mean1, invstd1, g1, fc1_w, fc2_w = ctx.saved_tensors
-        card, training, relu, B, C, H, W = ctx.cfg
-        HW = H * W
-        L = lib()
-        dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
-        dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=xr.device)
-        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, _st())
-        dl4 = dlogits.view(B, 1, 1, 2 * C).permute(0, 3, 1, 2)
-        fc1_b, b1, fc2_b = ctx.refs
-        d_fc2_w = _ret(fc2_w, raw_conv_wgrad(h2, dl4, fc2_w, 1, 0, card, _sink(fc2_w)))
-        d_fc2_b = _ret(fc2_b, raw_colsum(dl4, _sink(fc2_b)))
-        dh2 = raw_conv_dgrad(dl4, fc2_w, tuple(h2.shape), 1, 0, card)
-        dg1, db1 = _sink(g1), _sink(b1)
-        if dg1 is None or db1 is None:
-            dg1, db1 = torch.zeros_like(g1), torch.zeros_like(g1)
+        xr, out, logits, gap, h1, h2, mean1, invstd1, w1, w2 = ctx.saved_tensors
+        card, training, relu, B, C, H, W, inter = ctx.cfg
+        fc1_w, fc1_b, g1, b1, fc2_w, fc2_b = ctx.refs
         if not training:
             raise OctaError("SplAt backward in eval mode is not part of the hot path")
-        dh1, _ = raw_bn_bwd(dh2, h1, h2, mean1, invstd1, g1, True, False, dg1, db1)
-        d_fc1_w = _ret(fc1_w, raw_conv_wgrad(gap4, dh1, fc1_w, 1, 0, card, _sink(fc1_w)))
-        d_fc1_b = _ret(fc1_b, raw_colsum(dh1, _sink(fc1_b)))
-        dgap4 = raw_conv_dgrad(dh1, fc1_w, tuple(gap4.shape), 1, 0, card)
-        dgap = dgap4.permute(0, 2, 3, 1).reshape(B, C)
-        if not dgap.is_contiguous():
-            dgap = dgap.contiguous()
-        dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, xr.device)
+        HW = H * W
+        L = lib()
+        dev = xr.device
+        dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
+        dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, _st())
+        dw1, r_w1 = _grad_buf(fc1_w, True)
+        db1f, r_b1f = _grad_buf(fc1_b)
+        dg1, r_g1 = _grad_buf(g1)
+        dbe1, r_be1 = _grad_buf(b1)
+        dw2, r_w2 = _grad_buf(fc2_w, True)
+        db2, r_b2 = _grad_buf(fc2_b)
+        dh1 = torch.empty((B, inter), dtype=torch.float32, device=dev)
+        dgap = torch.empty((B, C), dtype=torch.float32, device=dev)
+        L.octa_splat_mlp_bwd(_p(dlogits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap), _p(dw1),
+                             _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, _st())
+        dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, dev)
         L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, _st())
-        return dx, d_fc1_w, d_fc1_b, _ret(g1, dg1), _ret(b1, db1), None, None, d_fc2_w, d_fc2_b, None, None, None, None, None
+        return dx, r_w1, r_b1f, r_g1, r_be1, None, None, r_w2, r_b2, None, None, None, None, None
 
 
 def splat_tail(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum=0.1, eps=1e-5, training=True, relu=False):
