@@ -122,10 +122,19 @@ def roofline_leg(step, batch, dtype_name):
     tot_t = sum(a[1] for a in agg.values())
     name, (f, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
     peak = PEAK_BF16_TFLOPS if dtype_name == "bf16" else PEAK_F32_TFLOPS
+    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # their own runs, gfx950 correction applied by tools/pmc_traffic.py); null when the kernel was not profiled
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        if name in pm and batch[0].shape[0] == 16 and batch[0].shape[-1] == 400:
+            traffic = round(pm[name]["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     per_kernel = {k: {"launches_per_step": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
     return {
         "bound": "mfma", "kernel": name, "achieved": round(f / t / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(f / t / 1e12 / peak, 4), "traffic": None,
+        "frac": round(f / t / 1e12 / peak, 4), "traffic": traffic,
         "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n,
         "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
                              "time_ms_per_step": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_f / 1e9, 1)},

@@ -645,7 +645,12 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
                      (int64_t)a.B * a.H * a.W * (int64_t)a.ldx * (a.mode == 1 ? a.stride : 1) < (1ll << 31);
     if (a.Ng > 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
-        if (dma) launch_dma<T, 2, 2, 4, 4>(a, grid, st);
+        static const bool small_tiles = getenv("OCTA_NO_SMALL_TILES") == nullptr;
+        if (small_tiles && !dma && (int64_t)grid.x * grid.y * grid.z < 320) {
+            // too few 128x128 tiles to fill 256 CUs (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
+            dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
+            conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
+        } else if (dma) launch_dma<T, 2, 2, 4, 4>(a, grid, st);
         else conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
     } else if (a.Ng > 32) {
         dim3 grid(cdiv(a.M, 256), 1, groups);
