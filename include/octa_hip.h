@@ -70,6 +70,18 @@ int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
                            void* packed, int Cout, int Cin_g, int KH, int KW, int groups,
                            int cout_g_pad, int dtype, octa_stream_t stream);
 
+/* One launch for many packs (all operands of a network after the optimiser step).  kind 0: forward
+ * operand, 1: data-gradient operand, 2: ConvTranspose up-shuffle operand (Cout_g = Cout_t, Cin_g = Cin_t,
+ * strides = (s_ci, s_co, s_h, s_w)).  `prefix` = exclusive prefix sum of the operands' element counts. */
+typedef struct octa_pack_desc {
+    const float* src;
+    void* dst;
+    int64_t s_o, s_i, s_h, s_w;
+    int32_t kind, dtype, Cout_g, Cin_g, KH, KW, groups, pad_to;
+} octa_pack_desc;
+int octa_pack_many(const octa_pack_desc* desc_dev, const int64_t* prefix_dev, int n, int64_t total,
+                   octa_stream_t stream);
+
 /* ConvTranspose2d k2 s2 weight (Cin_t, Cout_t, 2, 2), any strides -> up-shuffle GEMM operand
  * [(di*2+dj)*Cout_t + co][ci < cin_pad]  (extra/resnest.py:50). */
 int octa_pack_weight_convT(const float* w, int64_t s_ci, int64_t s_co, int64_t s_h, int64_t s_w,
@@ -261,8 +273,9 @@ int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask, float* ds
  * w: fp32 [Cout][K] dense (OIHW flattened).  Updates u,v in place when do_power_iter, writes
  * sigma[0] and w_sn = w / sigma. */
 int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter,
-                           float eps, float* sigma, float* w_sn, octa_stream_t stream);
-/* dw += (dw_sn - (sum(dw_sn * w_sn)) u v^T) / sigma */
+                           float eps, float* sigma, float* w_sn, float* ws /* K + Cout floats */,
+                           octa_stream_t stream);
+/* dw += (dw_sn - (sum(dw_sn * w_sn)) u v^T) / sigma      (ws: 1 float) */
 int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v,
                            const float* sigma, int Cout, int K, float* dw, float* ws,
                            octa_stream_t stream);

@@ -23,6 +23,11 @@ class ConvDesc(ctypes.Structure):
         "cin_g_pad", "cout_g_pad", "ldx", "xoff", "ldy", "yoff", "dtype", "act", "upshuffle")]
 
 
+class PackDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("s_o", ctypes.c_int64), ("s_i", ctypes.c_int64), ("s_h", ctypes.c_int64),
+                ("s_w", ctypes.c_int64)] + [(n, ctypes.c_int32) for n in ("kind", "dtype", "Cout_g", "Cin_g", "KH", "KW", "groups", "pad_to")]
+
+
 class OctaError(RuntimeError):
     pass
 
@@ -37,6 +42,8 @@ def _ctype_of(decl: str):
     d = decl.strip()
     if "octa_conv_desc" in d and "*" in d:
         return ctypes.POINTER(ConvDesc)
+    if "octa_pack_desc" in d and "*" in d:
+        return ctypes.c_void_p
     if "*" in d:
         return ctypes.c_void_p
     toks = [t for t in d.replace("const", " ").split() if t]

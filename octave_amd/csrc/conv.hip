@@ -780,6 +780,45 @@ extern "C" int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, 
     return pack_common(w, s_o, s_i, s_h, s_w, packed, Cout, Cin_g, KH, KW, groups, cout_g_pad, dtype, 1, (hipStream_t)stream);
 }
 
+// Multi-tensor pack: one launch refreshes EVERY packed operand of a network after the optimiser step (the
+// per-weight launches above cost ~190 launches per step).  desc[d] describes one operand, prefix[d] is the
+// exclusive prefix sum of the element counts; a thread finds its descriptor by binary search.
+__device__ __forceinline__ float pack_value(const octa_pack_desc& d, int64_t idx) {
+    if (d.kind == 2) {   // conv-transpose GEMM operand [(di*2+dj)*CoutT + co][ci < pad_to]: rows = 4*CoutT, Cin_g = CinT, Cout_g = CoutT
+        const int ci = (int)(idx % d.pad_to);
+        const int64_t n = idx / d.pad_to;
+        const int co = (int)(n % d.Cout_g), dd = (int)(n / d.Cout_g);
+        return ci < d.Cin_g ? d.src[ci * d.s_o + co * d.s_i + (dd >> 1) * d.s_h + (dd & 1) * d.s_w] : 0.f;
+    }
+    const int rows = d.kind == 1 ? d.Cin_g : d.Cout_g;
+    const int inner = (int)(idx % d.pad_to);
+    int64_t tq = idx / d.pad_to;
+    const int kw = (int)(tq % d.KW); tq /= d.KW;
+    const int kh = (int)(tq % d.KH); tq /= d.KH;
+    const int row = (int)(tq % rows);
+    const int g = (int)(tq / rows);
+    if (d.kind == 0) return inner < d.Cin_g ? d.src[(int64_t)(g * d.Cout_g + row) * d.s_o + inner * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
+    return inner < d.Cout_g ? d.src[(int64_t)(g * d.Cout_g + inner) * d.s_o + row * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
+}
+__global__ __launch_bounds__(256) void pack_many_kernel(const octa_pack_desc* __restrict__ desc, const int64_t* __restrict__ prefix, int n, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= i) lo = mid; else hi = mid - 1; }
+        const octa_pack_desc d = desc[lo];
+        const int64_t idx = i - prefix[lo];
+        const float v = pack_value(d, idx);
+        if (d.dtype == OCTA_F32) ((float*)d.dst)[idx] = v;
+        else ((bf16_t*)d.dst)[idx] = f2bf(v);
+    }
+}
+extern "C" int octa_pack_many(const octa_pack_desc* desc_dev, const int64_t* prefix_dev, int n, int64_t total, octa_stream_t stream) {
+    OCTA_REQUIRE(desc_dev && prefix_dev && n > 0 && total > 0, "octa_pack_many: bad arguments");
+    const int blocks = (int)(cdiv64(total, 256 * 4) > 8192 ? 8192 : cdiv64(total, 256 * 4));
+    pack_many_kernel<<<blocks < 1 ? 1 : blocks, 256, 0, (hipStream_t)stream>>>(desc_dev, prefix_dev, n, total);
+    OCTA_CHECK_LAUNCH("pack_many");
+    return OCTA_OK;
+}
+
 // ConvTranspose2d k2 s2 weight (Cin_t, Cout_t, 2, 2) -> GEMM operand [(di*2+dj)*Cout_t + co][ci < cin_pad]
 template <typename T>
 __global__ void pack_convT_kernel(const float* __restrict__ w, int64_t s_ci, int64_t s_co, int64_t s_h, int64_t s_w,

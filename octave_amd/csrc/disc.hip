@@ -79,96 +79,119 @@ __device__ float block_total(float v, float* red) {   // all threads get the blo
     for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) s += red[i];
     return s;
 }
-__global__ __launch_bounds__(1024) void spectral_fwd_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ v, int Cout,
-                                                            int K, int iter, float eps, float* __restrict__ sigma, float* __restrict__ wsn) {
-    extern __shared__ float sm[];   // us[Cout], vs[K], wv[Cout], red[16]
-    float* us = sm;
-    float* vs = us + Cout;
-    float* wv = vs + K;
-    float* red = wv + Cout;
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int i = t; i < Cout; i += nt) us[i] = u[i];
-    for (int j = t; j < K; j += nt) vs[j] = v[j];
-    __syncthreads();
-    if (iter) {
-        // v = normalize(W^T u): column j is owned by the threads {j, j+K', ...}: each sums a strided subset of rows
-        // (consecutive threads read consecutive columns), partial sums meet in LDS
-        const int KP = (K + 63) / 64 * 64;            // columns padded to whole waves
-        const int G = nt / KP > 0 ? nt / KP : 1;      // row groups
-        const int j = t % KP, gidx = t / KP;
+// Spectral norm, multi-block: the matrix (up to 1024 x 240 fp32 = 1 MB) is streamed by ~64 workgroups instead of one.
+//   A: v_raw[j] += sum_{i in block rows} W[i][j] u[i]                      (atomics into a zeroed K-vector)
+//   B: v = v_raw / max(|v_raw|, eps);  wv[i] = W[i] . v  for the block's rows; block 0 stores v
+//   C: u = wv / max(|wv|, eps); sigma = u . wv;  w_sn = W / sigma; block 0 stores u and sigma
+// Every block recomputes the tiny norms (K resp. Cout values) itself, so no grid-wide sync is needed.
+#define SN_ROWS 16
+__global__ __launch_bounds__(256) void spectral_A_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ vraw, int Cout, int K) {
+    const int r0 = blockIdx.x * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+    for (int j = threadIdx.x; j < K; j += 256) {
         float s = 0.f;
-        if (j < K && gidx < G)
-            for (int i = gidx; i < Cout; i += G) s += w[(int64_t)i * K + j] * us[i];
-        __syncthreads();
-        if (gidx == 0 && j < K) vs[j] = 0.f;
-        __syncthreads();
-        if (j < K && gidx < G) atomicAdd(&vs[j], s);
-        __syncthreads();
-        float nrm = 0.f;
-        for (int jj = t; jj < K; jj += nt) nrm += vs[jj] * vs[jj];
-        nrm = sqrtf(block_total(nrm, red));
-        const float dv = fmaxf(nrm, eps);
-        for (int jj = t; jj < K; jj += nt) vs[jj] /= dv;
-        __syncthreads();
+        for (int i = r0; i < r1; ++i) s += w[(int64_t)i * K + j] * u[i];
+        atomicAdd(vraw + j, s);
     }
-    // wv = W v  (one wave per row, lanes over K)
-    const int lane = t & 63, wid = t >> 6, nw = nt >> 6;
-    for (int i = wid; i < Cout; i += nw) {
+}
+__device__ float block_total256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void spectral_B_kernel(const float* __restrict__ w, const float* __restrict__ vraw, float* __restrict__ v, float* __restrict__ wv,
+                                                         int Cout, int K, int iter, float eps) {
+    extern __shared__ float sm[];   // vs[K], red[4]
+    float* vs = sm;
+    float* red = sm + K;
+    float nrm = 0.f;
+    for (int j = threadIdx.x; j < K; j += 256) { const float x = iter ? vraw[j] : v[j]; vs[j] = x; nrm += x * x; }
+    nrm = sqrtf(block_total256(nrm, red));
+    if (iter) {
+        const float d = fmaxf(nrm, eps);
+        for (int j = threadIdx.x; j < K; j += 256) vs[j] /= d;
+        __syncthreads();
+        if (blockIdx.x == 0) for (int j = threadIdx.x; j < K; j += 256) v[j] = vs[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+    for (int i = r0 + wave; i < r1; i += 4) {
         float s = 0.f;
         for (int j = lane; j < K; j += 64) s += w[(int64_t)i * K + j] * vs[j];
         s = wave_sum(s);
         if (lane == 0) wv[i] = s;
     }
-    __syncthreads();
+}
+__global__ __launch_bounds__(256) void spectral_C_kernel(const float* __restrict__ w, const float* __restrict__ wv, float* __restrict__ u, float* __restrict__ sigma,
+                                                         float* __restrict__ wsn, int Cout, int K, int iter, float eps) {
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f;     // |wv|^2 and u_old . wv
+    for (int i = threadIdx.x; i < Cout; i += 256) { const float x = wv[i]; a += x * x; b += u[i] * x; }
+    a = block_total256(a, red);
+    b = block_total256(b, red);
+    float sg;
     if (iter) {
-        float nrm = 0.f;
-        for (int i = t; i < Cout; i += nt) nrm += wv[i] * wv[i];
-        nrm = sqrtf(block_total(nrm, red));
-        const float du = fmaxf(nrm, eps);
-        for (int i = t; i < Cout; i += nt) us[i] = wv[i] / du;
-        __syncthreads();
+        const float d = fmaxf(sqrtf(a), eps);
+        sg = a / d;                                   // u_new . wv with u_new = wv / d
+        if (blockIdx.x == 0) for (int i = threadIdx.x; i < Cout; i += 256) u[i] = wv[i] / d;
+    } else {
+        sg = b;
     }
-    float sg = 0.f;
-    for (int i = t; i < Cout; i += nt) sg += us[i] * wv[i];
-    sg = block_total(sg, red);
-    if (t == 0) sigma[0] = sg;
-    if (iter) {
-        for (int i = t; i < Cout; i += nt) u[i] = us[i];
-        for (int j = t; j < K; j += nt) v[j] = vs[j];
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sigma[0] = sg;
     const float inv = 1.f / sg;
-    for (int64_t i = t; i < (int64_t)Cout * K; i += nt) wsn[i] = w[i] * inv;
+    const int64_t n = (int64_t)Cout * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) wsn[i] = w[i] * inv;
 }
 extern "C" int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter, float eps, float* sigma,
-                                      float* w_sn, octa_stream_t stream) {
-    OCTA_REQUIRE(w && u && v && sigma && w_sn && Cout > 0 && K > 0 && K <= 1024, "octa_spectral_norm_fwd: bad arguments (K <= 1024)");
-    const size_t sh = (size_t)(2 * Cout + K + 16) * sizeof(float);
-    OCTA_REQUIRE(sh <= 60000, "octa_spectral_norm_fwd: matrix too large for the single-block kernel");
-    spectral_fwd_kernel<<<1, 1024, sh, (hipStream_t)stream>>>(w, u, v, Cout, K, do_power_iter, eps, sigma, w_sn);
-    OCTA_CHECK_LAUNCH("spectral_fwd");
+                                      float* w_sn, float* ws, octa_stream_t stream) {
+    OCTA_REQUIRE(w && u && v && sigma && w_sn && ws && Cout > 0 && K > 0, "octa_spectral_norm_fwd: bad arguments (ws: K + Cout floats)");
+    hipStream_t st = (hipStream_t)stream;
+    float* vraw = ws;
+    float* wv = ws + K;
+    const int nb = cdiv(Cout, SN_ROWS);
+    if (do_power_iter) {
+        if (hipMemsetAsync(vraw, 0, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
+        spectral_A_kernel<<<nb, 256, 0, st>>>(w, u, vraw, Cout, K);
+        OCTA_CHECK_LAUNCH("spectral_A");
+    }
+    spectral_B_kernel<<<nb, 256, (size_t)(K + 4) * sizeof(float), st>>>(w, vraw, v, wv, Cout, K, do_power_iter, eps);
+    OCTA_CHECK_LAUNCH("spectral_B");
+    int nc = (int)cdiv64((int64_t)Cout * K, 256 * 8);
+    if (nc < 1) nc = 1;
+    spectral_C_kernel<<<nc, 256, 0, st>>>(w, wv, u, sigma, w_sn, Cout, K, do_power_iter, eps);
+    OCTA_CHECK_LAUNCH("spectral_C");
     return OCTA_OK;
 }
-// dw += (dw_sn - (sum dw_sn * w_sn) u v^T) / sigma
-__global__ __launch_bounds__(1024) void spectral_bwd_kernel(const float* __restrict__ dwsn, const float* __restrict__ wsn, const float* __restrict__ u,
-                                                            const float* __restrict__ v, const float* __restrict__ sigma, int Cout, int K,
-                                                            float* __restrict__ dw) {
-    __shared__ float red[16];
-    const int64_t n = (int64_t)Cout * K;
+// backward: dot = sum(dw_sn * w_sn) (atomics into ws[0]), then dw += (dw_sn - dot * u v^T) / sigma
+__global__ __launch_bounds__(256) void spectral_bwd_dot_kernel(const float* __restrict__ dwsn, const float* __restrict__ wsn, int64_t n, float* __restrict__ dot) {
+    __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += dwsn[i] * wsn[i];
-    s = block_total(s, red);
-    const float inv = 1.f / sigma[0];
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += dwsn[i] * wsn[i];
+    s = block_total256(s, red);
+    if (threadIdx.x == 0) atomicAdd(dot, s);
+}
+__global__ __launch_bounds__(256) void spectral_bwd_apply_kernel(const float* __restrict__ dwsn, const float* __restrict__ u, const float* __restrict__ v,
+                                                                 const float* __restrict__ sigma, const float* __restrict__ dot, int K, int64_t n,
+                                                                 float* __restrict__ dw) {
+    const float inv = 1.f / sigma[0], s = dot[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / K), c = (int)(i % K);
         dw[i] += (dwsn[i] - s * u[r] * v[c]) * inv;
     }
 }
 extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma, int Cout, int K,
                                       float* dw, float* ws, octa_stream_t stream) {
-    (void)ws;
-    OCTA_REQUIRE(dw_sn && w_sn && u && v && sigma && dw, "octa_spectral_norm_bwd: bad arguments");
-    spectral_bwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(dw_sn, w_sn, u, v, sigma, Cout, K, dw);
-    OCTA_CHECK_LAUNCH("spectral_bwd");
+    OCTA_REQUIRE(dw_sn && w_sn && u && v && sigma && dw && ws, "octa_spectral_norm_bwd: bad arguments (ws: 1 float)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)Cout * K;
+    int nb = (int)cdiv64(n, 256 * 8);
+    if (nb < 1) nb = 1;
+    if (hipMemsetAsync(ws, 0, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
+    spectral_bwd_dot_kernel<<<nb, 256, 0, st>>>(dw_sn, w_sn, n, ws);
+    OCTA_CHECK_LAUNCH("spectral_bwd_dot");
+    spectral_bwd_apply_kernel<<<nb, 256, 0, st>>>(dw_sn, u, v, sigma, ws, K, n, dw);
+    OCTA_CHECK_LAUNCH("spectral_bwd_apply");
     return OCTA_OK;
 }
 

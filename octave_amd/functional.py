@@ -131,14 +131,32 @@ def dense_nhwc(x: Tensor) -> Tensor:
 
 # ----------------------------------------------------------------------------- packed weights
 _WEIGHT_EPOCH = 0
-_PACK_CACHE = {}
+_PACK_CACHE = {}          # (id(param), kind, dtype, groups, pad_to) -> _PackEntry  (persistent output buffers)
+_PACK_PLANS = {}          # frozenset of cache keys -> (desc table, prefix, n, total) on the device
+
+
+class _PackEntry:
+    __slots__ = ("tag", "out", "wref", "direct", "kind", "dtype", "groups", "pad_to")
 
 
 def bump_weight_epoch():
-    """Call after parameters were modified outside autograd's version counter (fused optimiser)."""
+    """Call after parameters were modified outside autograd's version counter (fused optimiser): every packed
+    operand becomes stale until it is refreshed (individually on next use, or all at once by repack_all)."""
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
-    _PACK_CACHE.clear()
+
+
+def _pack_tag(w: Tensor):
+    return (w._version, _WEIGHT_EPOCH, w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+
+
+def _pack_numel(w: Tensor, kind: str, groups: int, pad_to: int) -> int:
+    O, Ig, KH, KW = w.shape
+    if kind == "fwd":
+        return O * KH * KW * pad_to
+    if kind == "dgrad":
+        return groups * Ig * KH * KW * pad_to
+    return 4 * Ig * pad_to      # convT: w is (CinT, CoutT, 2, 2)
 
 
 def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
@@ -146,38 +164,92 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     # because both id() and data_ptr() are recycled once a tensor dies
     cacheable = isinstance(w, torch.nn.Parameter)
     key = (id(w), kind, dtype, groups, pad_to)
-    tag = (w._version, _WEIGHT_EPOCH, w.data_ptr(), tuple(w.shape), tuple(w.stride()))
-    if cacheable:
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0] == tag and hit[2]() is w:
-            return hit[1]
+    tag = _pack_tag(w)
+    entry = _PACK_CACHE.get(key) if cacheable else None
+    if entry is not None and entry.wref() is not w:
+        entry = None
+    if entry is not None and entry.tag == tag:
+        return entry.out
     L = lib()
     wd = w.detach()
     if wd.dtype != torch.float32:
         wd = wd.float()
     O, Ig, KH, KW = wd.shape
     s = wd.stride()
+    direct = False
+    n = _pack_numel(wd, kind, groups, pad_to)
+    out = entry.out if (entry is not None and not entry.direct and entry.out.numel() == n and entry.tag[2:] == tag[2:]) else None
     if kind == "fwd":
         # already [O][KH][KW][Ig] fp32 with Ig % 8 == 0 -> use the parameter storage itself
         if (dtype == torch.float32 and pad_to == Ig and s[1] == 1 and (KW == 1 or s[3] == Ig) and (KH == 1 or s[2] == KW * Ig)
                 and s[0] == KH * KW * Ig and wd.data_ptr() % 16 == 0):
-            out = wd
+            out, direct = wd, True
         else:
-            out = torch.empty((O * KH * KW * pad_to,), dtype=dtype, device=w.device)
+            out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
             L.octa_pack_weight_fwd(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, groups, pad_to, _dt(dtype), _st())
     elif kind == "dgrad":
-        out = torch.empty((groups * Ig * KH * KW * pad_to,), dtype=dtype, device=w.device)
+        out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
         L.octa_pack_weight_dgrad(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, groups, pad_to, _dt(dtype), _st())
     elif kind == "convT":      # w: (CinT, CoutT, 2, 2)
-        out = torch.empty((4 * Ig * pad_to,), dtype=dtype, device=w.device)
+        out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
         L.octa_pack_weight_convT(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, pad_to, _dt(dtype), _st())
     else:
         raise ValueError(kind)
     if cacheable:
-        if len(_PACK_CACHE) > 4096:
+        if len(_PACK_CACHE) > 8192:
             _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (tag, out, weakref.ref(w))
+            _PACK_PLANS.clear()
+        e = _PackEntry()
+        e.tag, e.out, e.wref, e.direct, e.kind, e.dtype, e.groups, e.pad_to = tag, out, weakref.ref(w), direct, kind, dtype, groups, pad_to
+        _PACK_CACHE[key] = e
     return out
+
+
+def repack_all(params) -> int:
+    """Refresh, with ONE launch, every cached packed operand whose source parameter is in `params` (after the fused
+    optimiser moved the weights).  The descriptor table lives on the device and is rebuilt only when the set of
+    operands changes, so the call is hipGraph-capturable.  Returns the number of operands refreshed."""
+    from ._lib import PackDesc
+    ids = {id(p) for p in params}
+    todo = []
+    for key, e in _PACK_CACHE.items():
+        w = e.wref()
+        if w is None or key[0] not in ids or e.direct:
+            if w is not None and key[0] in ids and e.direct:
+                e.tag = _pack_tag(w)          # the parameter storage is the operand: always current
+            continue
+        todo.append((key, e, w))
+    if not todo:
+        return 0
+    sig = frozenset((k, e.out.data_ptr(), w.data_ptr(), tuple(w.stride())) for k, e, w in todo)
+    plan = _PACK_PLANS.get(sig)
+    if plan is None:
+        table = (PackDesc * len(todo))()
+        prefix, total = [], 0
+        for i, (key, e, w) in enumerate(todo):
+            O, Ig, KH, KW = w.shape
+            d = table[i]
+            d.src, d.dst = w.data_ptr(), e.out.data_ptr()
+            d.s_o, d.s_i, d.s_h, d.s_w = w.stride()
+            d.dtype, d.KH, d.KW, d.groups, d.pad_to = _dt(e.dtype), KH, KW, e.groups, e.pad_to
+            if e.kind == "convT":
+                d.kind, d.Cout_g, d.Cin_g = 2, Ig, O
+            else:
+                d.kind, d.Cout_g, d.Cin_g = (0 if e.kind == "fwd" else 1), O // e.groups, Ig
+            prefix.append(total)
+            total += e.out.numel()
+        dev = todo[0][2].device
+        tb = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+        pf = torch.tensor(prefix, dtype=torch.int64, device=dev)
+        plan = (tb, pf, len(todo), total)
+        if len(_PACK_PLANS) > 16:
+            _PACK_PLANS.clear()
+        _PACK_PLANS[sig] = plan
+    tb, pf, n, total = plan
+    lib().octa_pack_many(_p(tb), _p(pf), n, total, _st())
+    for key, e, w in todo:
+        e.tag = _pack_tag(w)
+    return n
 
 
 # ----------------------------------------------------------------------------- launch recorder (bench.py roofline leg)
@@ -1027,7 +1099,8 @@ class SpectralNormFn(Function):
         K = wd.numel() // Cout
         sigma = torch.empty((1,), dtype=torch.float32, device=w.device)
         wsn = torch.empty_like(wd)
-        lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _st())
+        ws = torch.empty((K + Cout,), dtype=torch.float32, device=w.device)
+        lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _p(ws), _st())
         ctx.save_for_backward(wsn, u.clone(), v.clone(), sigma)
         return wsn
 
@@ -1039,7 +1112,8 @@ class SpectralNormFn(Function):
         K = wsn.numel() // Cout
         dwsn = dwsn.float().contiguous()
         dw = torch.zeros_like(wsn)
-        lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(u), _p(v), _p(sigma), Cout, K, _p(dw), None, _st())
+        ws = torch.empty((1,), dtype=torch.float32, device=wsn.device)
+        lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(u), _p(v), _p(sigma), Cout, K, _p(dw), _p(ws), _st())
         return dw, None, None, None, None
 
 

@@ -66,6 +66,7 @@ class FlatArena:
                              eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
                              torch.cuda.current_stream().cuda_stream)
         F_.bump_weight_epoch()
+        F_.repack_all(self.params)      # one launch refreshes every packed conv operand of this network
 
     def advance_dyn(self, ring, betas):
         self.step_count += 1

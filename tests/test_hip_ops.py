@@ -81,6 +81,10 @@ CONV_CASES = [
     (64, 48, 3, 1, 1, 1, 2, 17, 33),     # 3x3 halo kernel: N<=64, partial tiles in both axes
     (96, 256, 3, 1, 1, 1, 1, 8, 16),     # 3x3 halo kernel: two N tiles, 3 channel chunks
     (128, 256, 3, 1, 1, 2, 2, 13, 13),   # 3x3 halo kernel, grouped (encoder SplAt shape)
+    (128, 512, 1, 1, 0, 1, 8, 6, 6),     # strided-bottleneck conv3 at M = 288 (64x64 tiles, 5 x 8 grid)
+    (256, 128, 1, 1, 0, 1, 8, 12, 12),   # strided-bottleneck conv1
+    (256, 512, 1, 1, 0, 1, 8, 6, 6),     # shortcut 1x1 after the 2x2 average pool
+    (128, 256, 3, 1, 1, 2, 8, 12, 12),   # its split-attention conv
 ]
 
 
