@@ -318,8 +318,9 @@ def test_real_width_stage_fwd_bwd_vs_oracle(dev, stage):
         scale = float(w.abs().max()) + 1e-12
         err = (g - w).abs() / scale
         assert torch.isfinite(g).all(), what
-        frac = float((err > 1e-2).float().mean())
-        assert float(err.median()) <= 3e-3 and frac <= 5e-3 and float(err.max()) <= 0.1, \
+        nbad = int((err > 1e-2).sum())
+        frac = nbad / err.numel()
+        assert float(err.median()) <= 3e-3 and nbad <= max(2, 5e-3 * err.numel()) and float(err.max()) <= 0.1, \
             f"{what}: median {float(err.median()):.2g}, {frac:.2%} of elements off by > 1e-2, max {float(err.max()):.3g} (relative to max|grad|)"
     grad_check(f"{name} grad_x", xd.grad, xr.grad)
     for k, pm in mod.named_parameters():
