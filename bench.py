@@ -203,9 +203,11 @@ def main():
         sys.exit("bench.py needs the MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("OCTA_DIST_ALWAYS") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from architectures.models.octa import OctaScribbleNet
@@ -233,7 +235,7 @@ def main():
     from octave_amd import _lib as _l
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -241,10 +243,10 @@ def main():
         out = step(*batch)
     t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (launch-bound if ~ the total)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -273,7 +275,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline_leg(net_state)
             log("cpu baseline leg done")
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,6 +11,7 @@ discriminator) that are all-reduced over RCCL (torch.distributed backend "nccl" 
 consumed by ONE fused Adam launch each.  BatchNorm statistics and the WPCE class weights are
 per-replica, like DistributedDataParallel on the reference would be.
 """
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -20,6 +21,9 @@ from torch import Tensor, nn
 from . import functional as F_
 from ._lib import lib
 from .layers import defer_bn_counters, flush_bn_counters
+
+
+FORCE_ALLREDUCE = os.environ.get("OCTA_DIST_ALWAYS") == "1"     # exercise the RCCL path with a single rank (tests)
 
 
 class FlatArena:
@@ -53,9 +57,26 @@ class FlatArena:
     def zero_grad(self):
         self.g.zero_()
 
+    def needs_comm(self, world: int) -> bool:
+        return world > 1 or (FORCE_ALLREDUCE and dist.is_available() and dist.is_initialized())
+
     def all_reduce(self, world: int):
-        if world > 1:
+        if self.needs_comm(world):
             dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
+
+    def all_reduce_begin(self, world: int, comm_stream):
+        """Start the all-reduce on `comm_stream` once the gradients written on the current stream are complete;
+        the caller overlaps independent work and calls all_reduce_end() before consuming the gradients."""
+        if not self.needs_comm(world):
+            return
+        cur = torch.cuda.current_stream()
+        comm_stream.wait_stream(cur)
+        with torch.cuda.stream(comm_stream):
+            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
+
+    def all_reduce_end(self, world: int, comm_stream):
+        if self.needs_comm(world):
+            torch.cuda.current_stream().wait_stream(comm_stream)
 
     def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None):
         """One fused Adam launch over the arena.  `dyn` (device, 2 floats) carries the bias corrections when the
@@ -166,6 +187,7 @@ class TrainStep:
         F_.set_grad_sink(True)
         defer_bn_counters(True)
         self._graphs = None
+        self._comm_stream = None
 
     # ------------------------------------------------------------------ the three phases of a step
     # (split at the two gradient all-reduces so that the collectives stay OUTSIDE any captured graph)
@@ -187,8 +209,9 @@ class TrainStep:
         flush_bn_counters()
         return [a.detach() for a in att]
 
-    def _phase_discriminator(self, att, real_pyramid, out, dyn=None):
-        self.seg_arena.adam(self.lr, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+    def _phase_discriminator(self, att, real_pyramid, out):
+        """The discriminator's forward/backward.  It depends on the segmentor step only through the (detached)
+        attention maps, not on the reduced segmentor gradients, so it runs WHILE those are being all-reduced."""
         if self.adversarial:
             self.disc_arena.zero_grad()          # drop what the generator step left in D's gradients
             d_real = self.disc(real_pyramid)
@@ -197,9 +220,17 @@ class TrainStep:
             l_d.backward()
             out["loss_disc"] = l_d.detach()
 
+    def _phase_seg_update(self, dyn=None):
+        self.seg_arena.adam(self.lr, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+
     def _phase_finish(self, dyn=None):
         if self.adversarial:
             self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+
+    def _comm(self):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        return self._comm_stream
 
     def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
         if self.adversarial and real_pyramid is None:
@@ -208,8 +239,10 @@ class TrainStep:
             return self._replay(x, ys, real_pyramid)
         out: Dict[str, Tensor] = {}
         att = self._phase_segmentor(x, ys, out)
-        self.seg_arena.all_reduce(self.world)
+        self.seg_arena.all_reduce_begin(self.world, self._comm())      # 286 MB over xGMI, hidden behind the D step
         self._phase_discriminator(att, real_pyramid, out)
+        self.seg_arena.all_reduce_end(self.world, self._comm())
+        self._phase_seg_update()
         if self.adversarial:
             self.disc_arena.all_reduce(self.world)
         self._phase_finish()
@@ -245,11 +278,14 @@ class TrainStep:
             self._att = self._phase_segmentor(self._sx, self._sys, self._out)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool()):
-            self._phase_discriminator(self._att, self._sreal, self._out, dyn=self._dyn_dev[0])
+            self._phase_discriminator(self._att, self._sreal, self._out)
+        g2b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2b, pool=g1.pool()):
+            self._phase_seg_update(dyn=self._dyn_dev[0])
         g3 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g3, pool=g1.pool()):
             self._phase_finish(dyn=self._dyn_dev[1])
-        self._graphs = (g1, g2, g3)
+        self._graphs = (g1, g2, g2b, g3)
         return self
 
     def _eager_static(self):
@@ -258,8 +294,10 @@ class TrainStep:
             self._feed.refill()
         self.seg_arena.advance_dyn(self._dyn[0], self.betas)
         att = self._phase_segmentor(self._sx, self._sys, out)
-        self.seg_arena.all_reduce(self.world)
-        self._phase_discriminator(att, self._sreal, out, dyn=self._dyn_dev[0])
+        self.seg_arena.all_reduce_begin(self.world, self._comm())
+        self._phase_discriminator(att, self._sreal, out)
+        self.seg_arena.all_reduce_end(self.world, self._comm())
+        self._phase_seg_update(dyn=self._dyn_dev[0])
         if self.adversarial:
             self.disc_arena.advance_dyn(self._dyn[1], self.betas)
             self.disc_arena.all_reduce(self.world)
@@ -277,13 +315,15 @@ class TrainStep:
                     dst.copy_(src, non_blocking=True)
         if self.adversarial:
             self._feed.refill()
-        g1, g2, g3 = self._graphs
+        g1, g2, g2b, g3 = self._graphs
         self.seg_arena.advance_dyn(self._dyn[0], self.betas)
-        g1.replay()
-        self.seg_arena.all_reduce(self.world)
         if self.adversarial:
             self.disc_arena.advance_dyn(self._dyn[1], self.betas)
-        g2.replay()
+        g1.replay()
+        self.seg_arena.all_reduce_begin(self.world, self._comm())
+        g2.replay()                                  # D step overlaps the segmentor gradient all-reduce
+        self.seg_arena.all_reduce_end(self.world, self._comm())
+        g2b.replay()
         if self.adversarial:
             self.disc_arena.all_reduce(self.world)
         g3.replay()
