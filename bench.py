@@ -15,6 +15,7 @@ algorithmic FLOPs / HIP-event time of its launches) and "cpu_baseline" (the CPU 
 the host cores, a bounded sample).
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -251,6 +252,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss_seg"].item())
+    if not all(math.isfinite(float(v.item())) for v in out.values()):
+        sys.exit(f"bench.py: non-finite losses after the timed steps ({ {k: float(v.item()) for k, v in out.items()} }): the measurement is void")
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host enqueue {t_enq / args.steps * 1e3:.1f} ms/step)")
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)

@@ -105,3 +105,19 @@ __device__ __forceinline__ float act_apply(float v, int act) {
         default: return v;
     }
 }
+
+// Stream-ordered zero fill as a KERNEL.  hipMemsetAsync is not used anywhere in this library: captured into a hipGraph it
+// becomes a memset node, and memset nodes were observed (ROCm 7.2, gfx950) to lose their ordering against the neighbouring
+// kernel nodes when graphs are replayed back-to-back without host synchronisation - accumulators were cleared AFTER the
+// atomics that fill them (spectral-norm v = 0 -> 0/0).  A kernel node keeps the stream order.
+__global__ static void octa_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t octa_zero_async(void* p, size_t bytes /* multiple of 4 */, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    size_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    octa_zero_words_kernel<<<(unsigned)nb, 256, 0, st>>>((uint32_t*)p, n);
+    return hipGetLastError();
+}

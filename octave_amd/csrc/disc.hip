@@ -151,7 +151,7 @@ extern "C" int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Co
     float* wv = ws + K;
     const int nb = cdiv(Cout, SN_ROWS);
     if (do_power_iter) {
-        if (hipMemsetAsync(vraw, 0, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
+        if (octa_zero_async(vraw, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
         spectral_A_kernel<<<nb, 256, 0, st>>>(w, u, vraw, Cout, K);
         OCTA_CHECK_LAUNCH("spectral_A");
     }
@@ -187,7 +187,7 @@ extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, con
     const int64_t n = (int64_t)Cout * K;
     int nb = (int)cdiv64(n, 256 * 8);
     if (nb < 1) nb = 1;
-    if (hipMemsetAsync(ws, 0, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
+    if (octa_zero_async(ws, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
     spectral_bwd_dot_kernel<<<nb, 256, 0, st>>>(dw_sn, w_sn, n, ws);
     OCTA_CHECK_LAUNCH("spectral_bwd_dot");
     spectral_bwd_apply_kernel<<<nb, 256, 0, st>>>(dw_sn, u, v, sigma, ws, K, n, dw);

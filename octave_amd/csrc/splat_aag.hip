@@ -47,7 +47,7 @@ static void splat_map(int cpr, int& TX, int& gridx) {
 extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, octa_stream_t stream) {
     OCTA_REQUIRE(x && gap && B > 0 && HW > 0 && C % 8 == 0, "octa_splat_gap: bad arguments (C %% 8)");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(gap, 0, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_gap: memset failed");
+    if (octa_zero_async(gap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_gap: memset failed");
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     int TX, gx;
     splat_map(C / epc, TX, gx);
@@ -211,7 +211,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     if (phase == 0) {
         OCTA_REQUIRE(x && dlogits, "octa_splat_bwd(phase 0): null pointer");
-        if (hipMemsetAsync(dlogits, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bwd: memset failed");
+        if (octa_zero_async(dlogits, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bwd: memset failed");
         int TX, gx;
         splat_map(C / epc, TX, gx);
         const int RY = 256 / TX;
@@ -449,7 +449,7 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
     OCTA_CHECK_LAUNCH("splat_mlp_bwdA");
     splat_mlp_bwdB_kernel<<<2 * C, 64, 0, st>>>(dlogits, h2, dw2, db2, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdB");
-    if (hipMemsetAsync(dgap, 0, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
+    if (octa_zero_async(dgap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
     {
         const int Ig = inter / groups;
         int js = Ig / 32;                 // >= 32 rows of W1 per block

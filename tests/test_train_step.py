@@ -218,3 +218,35 @@ def test_train_step_hipgraph_replay_matches_eager():
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     d = max((pa[k] - pb[k]).abs().max().item() for k in pa)
     assert d <= 4.5e-4, d       # 2 Adam steps of lr 1e-4: identical up to sign flips of near-zero gradients
+
+
+def test_train_step_hipgraph_back_to_back_replays_stay_finite():
+    """Replays enqueued WITHOUT host synchronisation (how bench.py and a real training loop drive the step): the host
+    runs several steps ahead of the GPU, so the pinned staging rings, the device-side Adam corrections and every node
+    of the graphs must stay ordered.  Regression test: hipMemsetAsync calls captured as memset NODES lost their order
+    against the neighbouring kernel nodes in exactly this mode (accumulators cleared after the atomics that fill them;
+    spectral-norm v = 0 -> 0/0 -> non-finite discriminator within a few steps).  The library now zero-fills with
+    kernels (csrc/common.hpp: octa_zero_async); tools/nan_hunt.py is the step-by-step diagnostic."""
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    Bn, H = 8, 128
+    x, ys, real = _inputs(Bn, H, dev)
+    pyr = mask_pyramid(real)
+    torch.manual_seed(0)
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False).to(dev).train()
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.bfloat16)
+    try:
+        st.capture(x, ys, pyr)
+        hist = []
+        for _ in range(24):
+            hist.append({k: v.clone() for k, v in st(x, ys, pyr).items()})
+        torch.cuda.synchronize()
+        for i, h in enumerate(hist):
+            vals = {k: v.item() for k, v in h.items()}
+            assert all(np.isfinite(v) for v in vals.values()), (i, vals)
+            assert 0.0 <= vals["loss_disc"] < 50 and abs(vals["g_adv"]) < 50, (i, vals)
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+        assert st.seg_arena.step_count == 2 + 24
+    finally:
+        st.close()
