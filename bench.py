@@ -63,7 +63,7 @@ def synth_batch(B, H, rank, device):
 def conv_flops(d):
     if d.upshuffle:
         return 2.0 * d.B * d.H * d.W * d.Cin * d.Cout
-    return 2.0 * d.B * d.OH * d.OW * d.Cout * (d.Cin // d.groups) * d.KH * d.KW
+    return 2.0 * d.B * d.OH * d.OW * d.Cout * (d.Cin // getattr(d, "alg_groups", d.groups)) * d.KH * d.KW    # algorithmic (densified layers too)
 
 
 def kernel_name(kind, d):

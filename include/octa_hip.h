@@ -72,7 +72,10 @@ int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
 
 /* One launch for many packs (all operands of a network after the optimiser step).  kind 0: forward
  * operand, 1: data-gradient operand, 2: ConvTranspose up-shuffle operand (Cout_g = Cout_t, Cin_g = Cin_t,
- * strides = (s_ci, s_co, s_h, s_w)).  `prefix` = exclusive prefix sum of the operands' element counts. */
+ * strides = (s_ci, s_co, s_h, s_w)), 3 / 4: a GROUPED weight laid out as the dense block-diagonal forward
+ * operand [Cout][KH][KW][pad_to >= Cin] / data-gradient operand [Cin][KH][KW][pad_to >= Cout] (zeros off the
+ * diagonal blocks), for small-channel grouped 3x3 layers that run faster as one dense conv on the halo kernel.
+ * `prefix` = exclusive prefix sum of the operands' element counts. */
 typedef struct octa_pack_desc {
     const float* src;
     void* dst;

@@ -790,11 +790,19 @@ __device__ __forceinline__ float pack_value(const octa_pack_desc& d, int64_t idx
         const int co = (int)(n % d.Cout_g), dd = (int)(n / d.Cout_g);
         return ci < d.Cin_g ? d.src[ci * d.s_o + co * d.s_i + (dd >> 1) * d.s_h + (dd & 1) * d.s_w] : 0.f;
     }
-    const int rows = d.kind == 1 ? d.Cin_g : d.Cout_g;
     const int inner = (int)(idx % d.pad_to);
     int64_t tq = idx / d.pad_to;
     const int kw = (int)(tq % d.KW); tq /= d.KW;
     const int kh = (int)(tq % d.KH); tq /= d.KH;
+    if (d.kind == 3) {   // grouped weight as a DENSE block-diagonal forward operand [Cout][KH][KW][Cin_total <= pad_to]
+        const int co = (int)tq, g = co / d.Cout_g, ci = inner - g * d.Cin_g;
+        return (ci >= 0 && ci < d.Cin_g) ? d.src[(int64_t)co * d.s_o + ci * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
+    }
+    if (d.kind == 4) {   // ... and as a dense data-gradient operand [Cin_total][KH][KW][Cout_total <= pad_to]
+        const int cin = (int)tq, g = cin / d.Cin_g, ci = cin - g * d.Cin_g, cog = inner - g * d.Cout_g;
+        return (cog >= 0 && cog < d.Cout_g) ? d.src[(int64_t)inner * d.s_o + ci * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
+    }
+    const int rows = d.kind == 1 ? d.Cin_g : d.Cout_g;
     const int row = (int)(tq % rows);
     const int g = (int)(tq / rows);
     if (d.kind == 0) return inner < d.Cin_g ? d.src[(int64_t)(g * d.Cout_g + row) * d.s_o + inner * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;

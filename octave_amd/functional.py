@@ -4,6 +4,7 @@ runs in libocta_hip.so.  Activations are torch tensors of logical shape (B, C, H
 is NHWC (channels-last) with a per-pixel stride `ld` that is a multiple of 8.
 """
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -136,7 +137,7 @@ _PACK_PLANS = {}          # frozenset of cache keys -> (desc table, prefix, n, t
 
 
 class _PackEntry:
-    __slots__ = ("tag", "out", "wref", "direct", "kind", "dtype", "groups", "pad_to")
+    __slots__ = ("tag", "out", "wref", "direct", "kind", "dtype", "groups", "pad_to", "aux")
 
 
 def bump_weight_epoch():
@@ -156,7 +157,26 @@ def _pack_numel(w: Tensor, kind: str, groups: int, pad_to: int) -> int:
         return O * KH * KW * pad_to
     if kind == "dgrad":
         return groups * Ig * KH * KW * pad_to
+    if kind == "fwd_dense":
+        return O * KH * KW * pad_to
+    if kind == "dgrad_dense":
+        return groups * Ig * KH * KW * pad_to
     return 4 * Ig * pad_to      # convT: w is (CinT, CoutT, 2, 2)
+
+
+_PACK_KIND = {"fwd": 0, "dgrad": 1, "convT": 2, "fwd_dense": 3, "dgrad_dense": 4}
+
+
+def _pack_desc_fill(d, kind: str, w: Tensor, out: Tensor, dtype, groups: int, pad_to: int):
+    O, Ig, KH, KW = w.shape
+    d.src, d.dst = w.data_ptr(), out.data_ptr()
+    d.s_o, d.s_i, d.s_h, d.s_w = w.stride()
+    d.dtype, d.KH, d.KW, d.groups, d.pad_to = _dt(dtype), KH, KW, groups, pad_to
+    d.kind = _PACK_KIND[kind]
+    if kind == "convT":
+        d.Cout_g, d.Cin_g = Ig, O
+    else:
+        d.Cout_g, d.Cin_g = O // groups, Ig
 
 
 def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
@@ -177,6 +197,7 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     O, Ig, KH, KW = wd.shape
     s = wd.stride()
     direct = False
+    aux = None
     n = _pack_numel(wd, kind, groups, pad_to)
     out = entry.out if (entry is not None and not entry.direct and entry.out.numel() == n and entry.tag[2:] == tag[2:]) else None
     if kind == "fwd":
@@ -193,6 +214,19 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     elif kind == "convT":      # w: (CinT, CoutT, 2, 2)
         out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
         L.octa_pack_weight_convT(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, pad_to, _dt(dtype), _st())
+    elif kind in ("fwd_dense", "dgrad_dense"):
+        # one-entry multi-pack (first use only; afterwards repack_all refreshes it with every other operand)
+        from ._lib import PackDesc
+        if out is not None and entry.aux is not None:
+            tb, pf = entry.aux                 # device-resident descriptor: the refresh is capturable
+        else:
+            out = torch.empty((n,), dtype=dtype, device=w.device)
+            table = (PackDesc * 1)()
+            _pack_desc_fill(table[0], kind, wd, out, dtype, groups, pad_to)
+            tb = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(w.device)
+            pf = torch.zeros(1, dtype=torch.int64, device=w.device)
+        aux = (tb, pf)
+        L.octa_pack_many(_p(tb), _p(pf), 1, n, _st())
     else:
         raise ValueError(kind)
     if cacheable:
@@ -201,6 +235,7 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
             _PACK_PLANS.clear()
         e = _PackEntry()
         e.tag, e.out, e.wref, e.direct, e.kind, e.dtype, e.groups, e.pad_to = tag, out, weakref.ref(w), direct, kind, dtype, groups, pad_to
+        e.aux = aux
         _PACK_CACHE[key] = e
     return out
 
@@ -227,15 +262,7 @@ def repack_all(params) -> int:
         table = (PackDesc * len(todo))()
         prefix, total = [], 0
         for i, (key, e, w) in enumerate(todo):
-            O, Ig, KH, KW = w.shape
-            d = table[i]
-            d.src, d.dst = w.data_ptr(), e.out.data_ptr()
-            d.s_o, d.s_i, d.s_h, d.s_w = w.stride()
-            d.dtype, d.KH, d.KW, d.groups, d.pad_to = _dt(e.dtype), KH, KW, e.groups, e.pad_to
-            if e.kind == "convT":
-                d.kind, d.Cout_g, d.Cin_g = 2, Ig, O
-            else:
-                d.kind, d.Cout_g, d.Cin_g = (0 if e.kind == "fwd" else 1), O // e.groups, Ig
+            _pack_desc_fill(table[i], e.kind, w, e.out, e.dtype, e.groups, e.pad_to)
             prefix.append(total)
             total += e.out.numel()
         dev = todo[0][2].device
@@ -307,6 +334,17 @@ def _conv_input(x: Tensor, cin_g_pad: int, groups: int) -> Tuple[Tensor, int]:
     return x, ld
 
 
+def _densify(groups: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int, H: int, W: int, dtype) -> bool:
+    """Small-channel grouped 3x3/s1/p1 layers at high resolution (decoder_0's split-attention conv: 32 -> 64, groups 4,
+    400x400) are loader-bound on the grouped gather kernel: each group re-reads its 16-byte slice of every pixel for 9
+    taps.  Run as ONE dense conv with block-diagonal weights they go through the halo-reuse kernel (pixel patch loaded
+    once, 4x the MFMA work, which is free here) - 2-3x faster.  Algorithmic FLOPs are still counted with the groups."""
+    if groups == 1 or (KH, KW, stride, pad) != (3, 3, 1, 1) or os.environ.get("OCTA_NO_DENSIFY") == "1":
+        return False
+    ck = 32 if dtype == torch.bfloat16 else 16
+    return Cin // groups <= 8 and Cout // groups <= 16 and Cin % ck == 0 and Cout % ck == 0 and H * W >= 128 * 128
+
+
 def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, groups: int, act: int = ACT_NONE,
                  out: Optional[Tensor] = None) -> Tensor:
     B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
@@ -315,8 +353,13 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     x, ldx = _conv_input(x, round8(Cin_g), groups)
     y = out if out is not None else nhwc_empty(B, Cout, OH, OW, x.dtype, x.device)
     ldy = nhwc_ld(y)
-    d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
-    wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
+    if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, x.dtype):
+        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, ldx, ldy, x.dtype, act)
+        d.alg_groups = groups
+        wp = _packed(w, "fwd_dense", x.dtype, groups, d.cin_g_pad)
+    else:
+        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
+        wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
     lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
     _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
     return y
@@ -333,6 +376,13 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         dy = to_nhwc(dy.contiguous(), cpad=need)
         ldy = nhwc_ld(dy)
     dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device)
+    if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, dy.dtype):
+        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, nhwc_ld(dx), ldy, dy.dtype)
+        d.alg_groups = groups
+        wt = _packed(w, "dgrad_dense", dy.dtype, groups, d.cout_g_pad)
+        lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
+        _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
+        return dx
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
     if stride > 1 and groups == 1 and (Cin * KH * KW) % 8 == 0:

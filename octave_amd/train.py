@@ -270,7 +270,8 @@ class TrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._out: Dict[str, Tensor] = {}
-        F_.bump_weight_epoch()
+        # the warm-up steps ended with Adam + repack_all: every cached operand is current, so no per-weight pack launch
+        # is captured (a stale cache here would put ~180 redundant pack kernels into every replay)
         if self.adversarial:
             self._feed.rewind()
         g1 = torch.cuda.CUDAGraph()

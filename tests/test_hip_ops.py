@@ -85,6 +85,7 @@ CONV_CASES = [
     (256, 128, 1, 1, 0, 1, 8, 12, 12),   # strided-bottleneck conv1
     (256, 512, 1, 1, 0, 1, 8, 6, 6),     # shortcut 1x1 after the 2x2 average pool
     (128, 256, 3, 1, 1, 2, 8, 12, 12),   # its split-attention conv
+    (32, 64, 3, 1, 1, 4, 1, 130, 140),   # decoder_0 SplAt conv at high resolution: densified (block-diagonal) halo path
 ]
 
 

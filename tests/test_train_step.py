@@ -170,54 +170,66 @@ def test_train_step_bf16_runs_and_learns():
 
 
 def test_train_step_hipgraph_replay_matches_eager():
-    """TrainStep.capture(): three hipGraphs around the two all-reduces; a replay must reproduce the eager step
-    (same CPU random draws, same Adam bias corrections).  Float atomics make even two EAGER runs differ and
-    Adam's first steps (update = lr * sign(g)) amplify that, so the band is calibrated on an eager twin."""
+    """TrainStep.capture(): four hipGraphs around the two all-reduces.  One replay must reproduce the SAME step launched
+    eagerly from the SAME state (weights, BN/spectral buffers, Adam moments, step counters, CPU generator state): the
+    state is snapshotted after capture, the replay runs, the state is restored and the step runs again kernel by kernel.
+    Only float-atomic ordering differs, so losses agree to 1e-4 relative; Adam turns a sign flip of a near-zero
+    gradient into a 2*lr difference, hence the update bound.  (Comparing trajectories from different runs instead is
+    ill-conditioned: two EAGER runs already differ by 0.3 % in g_adv after two steps with these weights.)"""
     from architectures.models.octa import OctaScribbleNet
     from octave_amd.train import TrainStep, mask_pyramid
+    from octave_amd import functional as F_
     dev = torch.device("cuda:0")
-    Bn, H = 6, 48
+    Bn, H, lr = 6, 48, 1e-4
     x, ys, real = _inputs(Bn, H, dev)
     pyr = mask_pyramid(real)
-
-    def make():
-        net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
-        fill_state_dict(net.state_dict())
-        return net.to(dev).train()
-
-    def eager(n):
-        net = make()
-        st = TrainStep(net, lr=1e-4, compute_dtype=torch.float32)
-        try:
-            torch.manual_seed(11)
-            for _ in range(n):
-                o = {k: v.clone() for k, v in st(x, ys, pyr).items()}
-        finally:
-            st.close()
-        return net, st, o
-    a, sa, oa = eager(2)
-    a2, _, oa2 = eager(2)
-    b = make()
-    sb = TrainStep(b, lr=1e-4, compute_dtype=torch.float32)
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    st = TrainStep(net, lr=lr, compute_dtype=torch.float32)
     try:
         torch.manual_seed(11)
-        sb.capture(x, ys, pyr, warmup=1)          # one real (eager) step on the static buffers, then capture
-        ob = {k: v.clone() for k, v in sb(x, ys, pyr).items()}
+        st.capture(x, ys, pyr, warmup=1)          # one real (eager) step on the static buffers, then capture
+        torch.cuda.synchronize()
+        arenas = (st.seg_arena, st.disc_arena)
+        snap_sd = {k: v.clone() for k, v in net.state_dict().items()}
+        snap_mv = [(a.m.clone(), a.v.clone(), a.step_count) for a in arenas]
+        rng = torch.get_rng_state()
+
+        og = {k: v.clone() for k, v in st(x, ys, pyr).items()}
+        torch.cuda.synchronize()
+        pg = {k: v.detach().clone() for k, v in net.named_parameters()}
+        bg = {k: v.clone() for k, v in net.named_buffers()}
+        assert st.seg_arena.step_count == 2 and st.disc_arena.step_count == 2
+
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(snap_sd[k])                # in place: parameters stay views of the arenas
+        for a, (m, v, n) in zip(arenas, snap_mv):
+            a.m.copy_(m), a.v.copy_(v)
+            a.step_count = n
+        torch.set_rng_state(rng)
+        F_.bump_weight_epoch()
+        oe = {k: v.clone() for k, v in st._eager_static().items()}
+        torch.cuda.synchronize()
     finally:
-        sb.close()
-    torch.cuda.synchronize()
-    for k in oa:
-        band = 3 * abs(oa[k].item() - oa2[k].item()) + 2e-3 * abs(oa[k].item()) + 1e-5
-        assert abs(oa[k].item() - ob[k].item()) <= band, (k, {n: (oa[n].item(), oa2[n].item(), ob[n].item()) for n in oa})
-    assert sa.seg_arena.step_count == sb.seg_arena.step_count == 2 and sb.disc_arena.step_count == 2
-    ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
+        st.close()
+    for k in oe:
+        a, b = oe[k].item(), og[k].item()
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-6, (k, a, b)
+    pe = dict(net.named_parameters())
+    worst, moved = 0.0, 0
+    for k in pg:
+        d = (pg[k] - pe[k]).abs()
+        worst = max(worst, d.max().item())
+        moved += int((d > 1e-6 + 1e-5 * pe[k].abs()).sum())
+    total = sum(p.numel() for p in pg.values())
+    print(f"[graph vs eager] max |dp| {worst:.2e} (2*lr = {2 * lr:.0e}); {moved}/{total} parameters differ")
+    assert worst <= 2.2 * lr and moved <= 0.04 * total, (worst, moved, total)     # measured 0.2-1.5 %: near-zero gradients
     for k in ("segmentor.encoder_0_1_2.1.running_mean", "segmentor.decoder_0.conv.1.running_var",
               "discriminator.spectral_dict.spectral_3.0.weight_u"):
-        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=5e-3, atol=1e-5), k
-    assert int(bb["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == 2
-    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
-    d = max((pa[k] - pb[k]).abs().max().item() for k in pa)
-    assert d <= 4.5e-4, d       # 2 Adam steps of lr 1e-4: identical up to sign flips of near-zero gradients
+        assert torch.allclose(bg[k].float(), dict(net.named_buffers())[k].float(), rtol=1e-4, atol=1e-6), k
+    assert int(bg["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == 2
 
 
 def test_train_step_hipgraph_back_to_back_replays_stay_finite():

@@ -17,6 +17,11 @@ LAYERS = {
     "enc2_splat": (16, 128, 50, 50, 256, 3, 1, 1, 2),
     "dec0_splat": (16, 32, 400, 400, 64, 3, 1, 1, 4),
     "dec2_splat": (16, 256, 100, 100, 512, 3, 1, 1, 4),
+    "disc0": (16, 2, 400, 400, 64, 4, 2, 1, 1),
+    "disc1": (16, 15, 200, 200, 128, 4, 2, 1, 1),
+    "disc2": (16, 141, 100, 100, 256, 4, 2, 1, 1),
+    "dec0_1x1": (16, 64, 400, 400, 32, 1, 1, 0, 1),
+    "up1": (16, 64, 200, 200, 256, 1, 1, 0, 1),
 }
 
 

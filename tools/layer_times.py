@@ -20,6 +20,7 @@ F_.start_recording(); step(*batch); rec = F_.stop_recording()
 torch.cuda.synchronize()
 L = lib(); st = torch.cuda.current_stream().cuda_stream
 rows = []
+excess = []
 scratch = {}
 for kind, d, ptrs, keep in rec:
     def launch():
@@ -35,6 +36,11 @@ for kind, d, ptrs, keep in rec:
     e0.record(); launch(); launch(); launch(); e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) / 3 * 1e3
     fl = bench.conv_flops(d)
+    esz = 2 if d.dtype else 4
+    up = 4 if d.upshuffle else 1
+    byt = esz * d.B * (d.H * d.W * d.Cin + d.OH * d.OW * up * (d.Cout // up if d.upshuffle else d.Cout)) + esz * d.Cout * (d.Cin // d.groups) * d.KH * d.KW
+    ideal = max(fl / 650e12, byt / 5.0e12) * 1e6
+    excess.append((us - ideal, us, ideal, kind, f"B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}"))
     rows.append((us, kind, f"{'bf16' if d.dtype else 'f32'} B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}", fl))
 tot = sum(r[0] for r in rows)
 print(f"total conv time {tot/1e3:.2f} ms over {len(rows)} launches")
@@ -43,3 +49,15 @@ for us, kind, desc, fl in rows:
     a = agg.setdefault((kind, desc), [0.0, 0, 0.0]); a[0] += us; a[1] += 1; a[2] += fl
 for (kind, desc), (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
     print(f"{us:9.1f} us {n:3d}x  {kind:6s} {desc:44s} {fl / us / 1e6:7.1f} TF/s")
+
+print("\n== excess over max(flops/650T, bytes/5TB/s), aggregated per (kind, layer) ==")
+ex = {}
+for e, us, ideal, kind, desc in excess:
+    a = ex.setdefault((kind, desc), [0.0, 0.0, 0.0, 0]); a[0] += e; a[1] += us; a[2] += ideal; a[3] += 1
+print(f"total excess {sum(v[0] for v in ex.values())/1e3:.2f} ms, total ideal {sum(v[2] for v in ex.values())/1e3:.2f} ms")
+for (kind, desc), (e, us, ideal, n) in sorted(ex.items(), key=lambda kv: -kv[1][0])[:60]:
+    print(f"{e:9.1f} us excess  {us:9.1f} us actual {ideal:8.1f} ideal {n:3d}x {kind:6s} {desc}")
+bykind = {}
+for e, us, ideal, kind, desc in excess:
+    a = bykind.setdefault(kind, [0.0, 0.0]); a[0] += us; a[1] += ideal
+print({k: (round(v[0] / 1e3, 2), round(v[1] / 1e3, 2)) for k, v in bykind.items()})
