@@ -75,13 +75,15 @@ int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
  * strides = (s_ci, s_co, s_h, s_w)), 3 / 4: a GROUPED weight laid out as the dense block-diagonal forward
  * operand [Cout][KH][KW][pad_to >= Cin] / data-gradient operand [Cin][KH][KW][pad_to >= Cout] (zeros off the
  * diagonal blocks), for small-channel grouped 3x3 layers that run faster as one dense conv on the halo kernel.
- * `prefix` = exclusive prefix sum of the operands' element counts. */
+ * `prefix` = exclusive prefix sum of the operands' TILE counts (octa_pack_tile_count; `total` = their sum): 2048
+ * consecutive elements per tile for kinds 0/3/4, one 32x32 LDS-transposed tile for kinds 1/2. */
 typedef struct octa_pack_desc {
     const float* src;
     void* dst;
     int64_t s_o, s_i, s_h, s_w;
     int32_t kind, dtype, Cout_g, Cin_g, KH, KW, groups, pad_to;
 } octa_pack_desc;
+size_t octa_pack_tile_count(const octa_pack_desc* desc_host);
 int octa_pack_many(const octa_pack_desc* desc_dev, const int64_t* prefix_dev, int n, int64_t total,
                    octa_stream_t stream);
 

@@ -782,47 +782,140 @@ extern "C" int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, 
 
 // Multi-tensor pack: one launch refreshes EVERY packed operand of a network after the optimiser step (the
 // per-weight launches above cost ~190 launches per step).  desc[d] describes one operand, prefix[d] is the
-// exclusive prefix sum of the element counts; a thread finds its descriptor by binary search.
-__device__ __forceinline__ float pack_value(const octa_pack_desc& d, int64_t idx) {
-    if (d.kind == 2) {   // conv-transpose GEMM operand [(di*2+dj)*CoutT + co][ci < pad_to]: rows = 4*CoutT, Cin_g = CinT, Cout_g = CoutT
-        const int ci = (int)(idx % d.pad_to);
-        const int64_t n = idx / d.pad_to;
-        const int co = (int)(n % d.Cout_g), dd = (int)(n / d.Cout_g);
-        return ci < d.Cin_g ? d.src[ci * d.s_o + co * d.s_i + (dd >> 1) * d.s_h + (dd & 1) * d.s_w] : 0.f;
-    }
-    const int inner = (int)(idx % d.pad_to);
-    int64_t tq = idx / d.pad_to;
-    const int kw = (int)(tq % d.KW); tq /= d.KW;
-    const int kh = (int)(tq % d.KH); tq /= d.KH;
-    if (d.kind == 3) {   // grouped weight as a DENSE block-diagonal forward operand [Cout][KH][KW][Cin_total <= pad_to]
-        const int co = (int)tq, g = co / d.Cout_g, ci = inner - g * d.Cin_g;
-        return (ci >= 0 && ci < d.Cin_g) ? d.src[(int64_t)co * d.s_o + ci * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
-    }
-    if (d.kind == 4) {   // ... and as a dense data-gradient operand [Cin_total][KH][KW][Cout_total <= pad_to]
-        const int cin = (int)tq, g = cin / d.Cin_g, ci = cin - g * d.Cin_g, cog = inner - g * d.Cout_g;
-        return (cog >= 0 && cog < d.Cout_g) ? d.src[(int64_t)inner * d.s_o + ci * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
-    }
-    const int rows = d.kind == 1 ? d.Cin_g : d.Cout_g;
-    const int row = (int)(tq % rows);
-    const int g = (int)(tq / rows);
-    if (d.kind == 0) return inner < d.Cin_g ? d.src[(int64_t)(g * d.Cout_g + row) * d.s_o + inner * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
-    return inner < d.Cout_g ? d.src[(int64_t)(g * d.Cout_g + inner) * d.s_o + row * d.s_i + kh * d.s_h + kw * d.s_w] : 0.f;
+// exclusive prefix sum of the operands' TILE counts; a block finds its descriptor by binary search.
+// Work decomposition of one operand into 256-thread tiles (host and device agree through this one function):
+//  kinds 0/3/4 (destination order = a strided gather whose inner axis is the source's fast axis or small): 2048
+//  consecutive destination elements per tile, 8 per thread (one 16-byte bf16 store);
+//  kinds 1/2 (data-gradient / conv-transpose operands = a cout<->cin TRANSPOSE of the channels-last parameter): 32x32
+//  tiles staged through LDS so that both the fp32 reads and the packed writes are contiguous runs.
+__host__ __device__ static inline int64_t pack_tiles(const octa_pack_desc& d) {
+    const int64_t kk = (int64_t)d.KH * d.KW;
+    if (d.kind == 1) return (int64_t)d.groups * kk * ((d.Cin_g + 31) / 32) * ((d.pad_to + 31) / 32);
+    if (d.kind == 2) return 4ll * ((d.Cout_g + 31) / 32) * ((d.pad_to + 31) / 32);
+    const int64_t rows = d.kind == 4 ? (int64_t)d.groups * d.Cin_g : (int64_t)d.groups * d.Cout_g;
+    return (rows * kk * d.pad_to + 2047) / 2048;
 }
+extern "C" size_t octa_pack_tile_count(const octa_pack_desc* d) { return d ? (size_t)pack_tiles(*d) : 0; }
+
+template <typename T> __device__ __forceinline__ void pack_store8(T* dst, const float (&v)[8]);
+template <> __device__ __forceinline__ void pack_store8<float>(float* dst, const float (&v)[8]) {
+    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void pack_store8<bf16_t>(bf16_t* dst, const float (&v)[8]) {
+    uint4 o;
+    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(uint4*)dst = o;
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_tile_linear(const octa_pack_desc& d, unsigned tl) {
+    const unsigned kk = (unsigned)(d.KH * d.KW);
+    const unsigned rows = d.kind == 4 ? (unsigned)(d.groups * d.Cin_g) : (unsigned)(d.groups * d.Cout_g);
+    const unsigned total = rows * kk * (unsigned)d.pad_to;
+    const unsigned base = tl * 2048u + threadIdx.x * 8u;
+    if (base >= total) return;
+    const unsigned inner = base % (unsigned)d.pad_to;       // pad_to % 8 == 0: the 8 elements share (row, tap)
+    unsigned tq = base / (unsigned)d.pad_to;
+    const unsigned tap = tq % kk; tq /= kk;
+    const int kh = (int)(tap / (unsigned)d.KW), kw = (int)(tap % (unsigned)d.KW);
+    const int64_t toff = (int64_t)kh * d.s_h + (int64_t)kw * d.s_w;
+    float v[8];
+    if (d.kind == 0 || d.kind == 3) {
+        const int co = (int)tq;                              // global output channel (groups are consecutive row blocks)
+        const int g = co / d.Cout_g;
+        const int shift = d.kind == 3 ? g * d.Cin_g : 0;     // kind 3: dense inner axis, this group's block starts at g*Cin_g
+        const float* src = d.src + (int64_t)co * d.s_o + toff;
+        const int c0 = (int)inner - shift;
+        if (d.s_i == 1 && c0 >= 0 && c0 + 7 < d.Cin_g && (((size_t)(src + c0)) & 15) == 0) {
+            const float4 a = *(const float4*)(src + c0), b = *(const float4*)(src + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = c0 + e; v[e] = (c >= 0 && c < d.Cin_g) ? src[(int64_t)c * d.s_i] : 0.f; }
+        }
+    } else {                                                 // kind 4: [Cin_total][tap][Cout_total <= pad_to], block diagonal
+        const int cin = (int)tq, g = cin / d.Cin_g, ci = cin - g * d.Cin_g;
+        const float* src = d.src + (int64_t)ci * d.s_i + toff;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = (int)inner + e, cog = co - g * d.Cout_g;
+            v[e] = (cog >= 0 && cog < d.Cout_g) ? src[(int64_t)co * d.s_o] : 0.f;
+        }
+    }
+    pack_store8<T>((T*)d.dst + base, v);
+}
+
+// kinds 1 and 2: dst[row r][col c] = src[c * s_o + r * s_i + tap offset]; columns (c) are the destination's contiguous axis
+// and the source's SLOW axis, rows (r) the source's fast axis for channels-last parameters.
+template <typename T>
+__device__ __forceinline__ void pack_tile_transpose(const octa_pack_desc& d, unsigned tl, float (*tile)[33]) {
+    const int t = threadIdx.x;
+    const int nC = d.kind == 1 ? d.Cout_g : d.Cin_g;         // real columns (kind 2: ci)
+    const int nR = d.kind == 1 ? d.Cin_g : d.Cout_g;         // rows (kind 2: co)
+    const unsigned nct = (unsigned)(d.pad_to + 31) / 32, nrt = (unsigned)(nR + 31) / 32;
+    const unsigned ct = tl % nct; tl /= nct;
+    const unsigned rt = tl % nrt; tl /= nrt;
+    const unsigned kk = d.kind == 1 ? (unsigned)(d.KH * d.KW) : 4u;
+    const unsigned tap = tl % kk;
+    const int g = (int)(tl / kk);                            // kind 2: always 0
+    int64_t toff;
+    if (d.kind == 1) toff = (int64_t)(tap / (unsigned)d.KW) * d.s_h + (int64_t)(tap % (unsigned)d.KW) * d.s_w + (int64_t)g * d.Cout_g * d.s_o;
+    else toff = (int64_t)(tap >> 1) * d.s_h + (int64_t)(tap & 1) * d.s_w;
+    {   // load: thread = (column cl, 4 consecutive rows r4..r4+3): contiguous along the source's fast axis
+        const int cl = t >> 3, r4 = (t & 7) * 4;
+        const int c = (int)ct * 32 + cl, r = (int)rt * 32 + r4;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (c < nC) {
+            const float* src = d.src + (int64_t)c * d.s_o + toff;
+            if (d.s_i == 1 && r + 3 < nR && (((size_t)(src + r)) & 15) == 0) {
+                const float4 a = *(const float4*)(src + r);
+                v0 = a.x; v1 = a.y; v2 = a.z; v3 = a.w;
+            } else {
+                if (r < nR) v0 = src[(int64_t)r * d.s_i];
+                if (r + 1 < nR) v1 = src[(int64_t)(r + 1) * d.s_i];
+                if (r + 2 < nR) v2 = src[(int64_t)(r + 2) * d.s_i];
+                if (r + 3 < nR) v3 = src[(int64_t)(r + 3) * d.s_i];
+            }
+        }
+        tile[cl][r4] = v0; tile[cl][r4 + 1] = v1; tile[cl][r4 + 2] = v2; tile[cl][r4 + 3] = v3;
+    }
+    __syncthreads();
+    {   // store: thread = (row rl, 4 consecutive columns)
+        const int rl = t >> 3, c4 = (t & 7) * 4;
+        const int r = (int)rt * 32 + rl, c = (int)ct * 32 + c4;
+        if (r < nR && c < d.pad_to) {                        // pad_to % 8 == 0: whole groups of 4 inside the padded row
+            int64_t drow;
+            if (d.kind == 1) drow = ((int64_t)(g * d.Cin_g + r) * kk + tap);
+            else drow = (int64_t)tap * d.Cout_g + r;
+            T* dst = (T*)d.dst + drow * d.pad_to + c;
+            const float a = tile[c4][rl], b = tile[c4 + 1][rl], cc = tile[c4 + 2][rl], dd = tile[c4 + 3][rl];
+            if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(a, b, cc, dd);
+            else *(uint2*)dst = make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(cc) | ((unsigned)f2bf(dd) << 16));
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void pack_many_kernel(const octa_pack_desc* __restrict__ desc, const int64_t* __restrict__ prefix, int n, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= i) lo = mid; else hi = mid - 1; }
+    __shared__ float tile[32][33];
+    for (int64_t tb = blockIdx.x; tb < total; tb += gridDim.x) {
+        int lo = 0, hi = n - 1;                              // block-uniform search: which operand owns tile tb
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= tb) lo = mid; else hi = mid - 1; }
         const octa_pack_desc d = desc[lo];
-        const int64_t idx = i - prefix[lo];
-        const float v = pack_value(d, idx);
-        if (d.dtype == OCTA_F32) ((float*)d.dst)[idx] = v;
-        else ((bf16_t*)d.dst)[idx] = f2bf(v);
+        const unsigned tl = (unsigned)(tb - prefix[lo]);
+        if (d.kind == 1 || d.kind == 2) {
+            if (d.dtype == OCTA_F32) pack_tile_transpose<float>(d, tl, tile); else pack_tile_transpose<bf16_t>(d, tl, tile);
+        } else {
+            if (d.dtype == OCTA_F32) pack_tile_linear<float>(d, tl); else pack_tile_linear<bf16_t>(d, tl);
+        }
     }
 }
 extern "C" int octa_pack_many(const octa_pack_desc* desc_dev, const int64_t* prefix_dev, int n, int64_t total, octa_stream_t stream) {
     OCTA_REQUIRE(desc_dev && prefix_dev && n > 0 && total > 0, "octa_pack_many: bad arguments");
-    const int blocks = (int)(cdiv64(total, 256 * 4) > 8192 ? 8192 : cdiv64(total, 256 * 4));
-    pack_many_kernel<<<blocks < 1 ? 1 : blocks, 256, 0, (hipStream_t)stream>>>(desc_dev, prefix_dev, n, total);
+    const int blocks = (int)(total > 16384 ? 16384 : total);
+    pack_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(desc_dev, prefix_dev, n, total);
     OCTA_CHECK_LAUNCH("pack_many");
     return OCTA_OK;
 }

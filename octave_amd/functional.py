@@ -218,15 +218,16 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
         # one-entry multi-pack (first use only; afterwards repack_all refreshes it with every other operand)
         from ._lib import PackDesc
         if out is not None and entry.aux is not None:
-            tb, pf = entry.aux                 # device-resident descriptor: the refresh is capturable
+            tb, pf, tiles = entry.aux          # device-resident descriptor: the refresh is capturable
         else:
             out = torch.empty((n,), dtype=dtype, device=w.device)
             table = (PackDesc * 1)()
             _pack_desc_fill(table[0], kind, wd, out, dtype, groups, pad_to)
+            tiles = int(L.octa_pack_tile_count(ctypes.byref(table[0])))
             tb = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(w.device)
             pf = torch.zeros(1, dtype=torch.int64, device=w.device)
-        aux = (tb, pf)
-        L.octa_pack_many(_p(tb), _p(pf), 1, n, _st())
+        aux = (tb, pf, tiles)
+        L.octa_pack_many(_p(tb), _p(pf), 1, tiles, _st())
     else:
         raise ValueError(kind)
     if cacheable:
@@ -264,7 +265,7 @@ def repack_all(params) -> int:
         for i, (key, e, w) in enumerate(todo):
             _pack_desc_fill(table[i], e.kind, w, e.out, e.dtype, e.groups, e.pad_to)
             prefix.append(total)
-            total += e.out.numel()
+            total += int(lib().octa_pack_tile_count(ctypes.byref(table[i])))
         dev = todo[0][2].device
         tb = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         pf = torch.tensor(prefix, dtype=torch.int64, device=dev)

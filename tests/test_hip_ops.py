@@ -300,3 +300,55 @@ def test_losses_vs_oracle_random(dev):
     g2.backward()
     check("wpce strided", g2, w2, 2e-5, 1e-6)
     check("wpce strided grad", pd.grad, pr.grad, 2e-4, 1e-8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_repack_all_matches_per_weight_packs(dev, dtype):
+    """octa_pack_many (one launch, linear + LDS-transposed tiles) must reproduce the per-weight pack kernels bit for bit:
+    forward, data-gradient and conv-transpose operands, channels-last and plain OIHW parameters, grouped, padded, odd sizes;
+    the dense block-diagonal kinds are checked against an explicitly densified weight."""
+    from octave_amd import functional as F_
+    g = torch.Generator().manual_seed(3)
+    specs = [  # (Cout, Cin_g, k, groups, channels_last)
+        (64, 32, 3, 1, True), (48, 24, 3, 1, False), (256, 64, 1, 1, True), (128, 64, 3, 2, True), (64, 8, 3, 4, True),
+        (13, 64, 1, 1, True), (40, 3, 3, 1, True), (96, 15, 4, 1, True), (200, 136, 1, 1, True), (32, 70, 3, 1, True)]
+    params, jobs = [], []
+    for O, Ig, k, gr, cl in specs:
+        w = torch.randn(O, Ig, k, k, generator=g).to(dev)
+        if cl:
+            w = w.contiguous(memory_format=torch.channels_last)
+        p = torch.nn.Parameter(w)
+        params.append(p)
+        jobs += [(p, "fwd", gr, F_.round8(Ig)), (p, "dgrad", gr, F_.round8(O // gr))]
+    wt = torch.nn.Parameter(torch.randn(72, 40, 2, 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last))
+    params.append(wt)
+    jobs.append((wt, "convT", 1, F_.round8(72)))
+    wd = params[4]                                          # (64, 8, 3, 3), groups 4 -> dense 32 -> 64
+    jobs += [(wd, "fwd_dense", 4, 32), (wd, "dgrad_dense", 4, 64)]
+    first = [F_._packed(p, kind, dtype, gr, pad).clone() for p, kind, gr, pad in jobs]      # per-weight kernels
+    with torch.no_grad():
+        for p in params:
+            p.mul_(1.5).add_(0.25)
+    F_.bump_weight_epoch()
+    n = F_.repack_all(params)
+    assert n == sum(not F_._PACK_CACHE[(id(p), kind, dtype, gr, pad)].direct for p, kind, gr, pad in jobs)
+    torch.cuda.synchronize()
+    multi = [F_._PACK_CACHE[(id(p), kind, dtype, gr, pad)].out.clone() for p, kind, gr, pad in jobs]
+    F_._PACK_CACHE.clear()
+    F_._PACK_PLANS.clear()
+    single = [F_._packed(p, kind, dtype, gr, pad) for p, kind, gr, pad in jobs]
+    for (p, kind, gr, pad), a, b, f in zip(jobs, multi, single, first):
+        if F_._PACK_CACHE[(id(p), kind, dtype, gr, pad)].direct:
+            continue
+        assert a.shape == b.shape and torch.equal(a, b), (kind, tuple(p.shape), gr, pad, (a.float() - b.float()).abs().max().item())
+        assert not torch.equal(a, f)
+    # dense kinds against an explicitly block-diagonal weight packed as an ordinary dense conv
+    dense = torch.zeros(64, 32, 3, 3, device=dev)
+    for gi in range(4):
+        dense[gi * 16:(gi + 1) * 16, gi * 8:(gi + 1) * 8] = wd.detach()[gi * 16:(gi + 1) * 16]
+    dense = dense.contiguous(memory_format=torch.channels_last)
+    ref_fwd = F_._packed(dense, "fwd", dtype, 1, 32)
+    if ref_fwd.dim() == 4:          # fp32: the channels-last parameter storage itself is the operand ([O][KH][KW][I] in memory)
+        ref_fwd = ref_fwd.permute(0, 2, 3, 1)
+    assert torch.equal(ref_fwd.reshape(-1), single[-2].reshape(-1))
+    assert torch.equal(F_._packed(dense, "dgrad", dtype, 1, 64).reshape(-1), single[-1].reshape(-1))
