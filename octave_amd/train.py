@@ -86,8 +86,10 @@ class FlatArena:
         lib().octa_adam_step(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.numel, lr, betas[0], betas[1],
                              eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
                              torch.cuda.current_stream().cuda_stream)
-        F_.bump_weight_epoch()
-        F_.repack_all(self.params)      # one launch refreshes every packed conv operand of this network
+        # one launch refreshes every cached packed conv operand of THIS network; nothing else went stale, so the global
+        # weight epoch is left alone (bumping it here made the other network's operands look stale: ~170 redundant
+        # per-weight pack launches were captured into every replayed step)
+        F_.repack_all(self.params)
 
     def advance_dyn(self, ring, betas):
         self.step_count += 1
@@ -198,13 +200,21 @@ class TrainStep:
         loss = l[0] + l[1] if self.use_dice else l[0]
         out["wpce"], out["dice"] = l[0].detach(), l[1].detach()
         if self.adversarial:
-            self.disc_arena.zero_grad()
             p = F_.class_softmax(agg)
             kl = F_.interlayer_kl([p, *att], [1] * len(att))[0]
+            # the generator pass only needs dL/d(att) through D: D's own weight gradients of this pass are discarded
+            # (zeroed before D's step, here and in the reference), so they are not computed at all
+            for q in self.disc_arena.params:
+                q.requires_grad_(False)
             g_adv = F_.lsgan_generator(self.disc(att))
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
-        loss.backward()
+        try:
+            loss.backward()
+        finally:
+            if self.adversarial:
+                for q in self.disc_arena.params:
+                    q.requires_grad_(True)
         out["loss_seg"] = loss.detach()
         flush_bn_counters()
         return [a.detach() for a in att]
@@ -213,7 +223,7 @@ class TrainStep:
         """The discriminator's forward/backward.  It depends on the segmentor step only through the (detached)
         attention maps, not on the reduced segmentor gradients, so it runs WHILE those are being all-reduced."""
         if self.adversarial:
-            self.disc_arena.zero_grad()          # drop what the generator step left in D's gradients
+            self.disc_arena.zero_grad()
             d_real = self.disc(real_pyramid)
             d_fake = self.disc(att)
             l_d = F_.lsgan_discriminator(d_real, d_fake)
