@@ -1279,8 +1279,54 @@ __global__ void colsum_kernel(const T* __restrict__ src, int64_t rows, int C, in
     __syncthreads();
     if (threadIdx.y == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// 16-byte loads: thread t owns chunk column t % TX (EPC channels) and row lane t / TX; LDS tree over the row lanes,
+// one atomic per channel and block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ src, int64_t rows, int cpr, int TX, int ld, int off,
+                                                         float* __restrict__ out, int rows_per_block) {
+    constexpr int EPC = DT<T>::EPC;
+    __shared__ float red[256 * EPC];
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX, RY = 256 / TX;
+    const int col = blockIdx.x * TX + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    if (col < cpr)
+        for (int64_t r = r0 + ry; r < r1; r += RY) {
+            float v[EPC];
+            unpack16<T>(*(const uint4*)(src + r * ld + off + col * EPC), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[(ry * TX + cx) * EPC + e] = s[e];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= cpr * EPC) continue;
+        float a = 0.f;
+        for (int yy = 0; yy < RY; ++yy) a += red[yy * TX * EPC + ch];
+        atomicAdd(out + c, a);
+    }
+}
 extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out, octa_stream_t stream) {
     OCTA_REQUIRE(src && out && rows > 0 && C > 0, "octa_colsum: bad arguments");
+    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_colsum: bad dtype");
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    if (C % epc == 0 && ld % epc == 0 && off % epc == 0 && ((size_t)src & 15) == 0) {
+        const int cpr = C / epc;
+        int TX = 1;
+        while (TX < cpr && TX < 256) TX <<= 1;            // power of two >= cpr (<= 256): 256 / TX row lanes
+        const int RY = 256 / TX;
+        int64_t rpb = cdiv64(rows, 2048);
+        if (rpb < (int64_t)RY * 8) rpb = (int64_t)RY * 8;
+        dim3 grid(cdiv(cpr, TX), (unsigned)cdiv64(rows, rpb));
+        if (dtype == OCTA_F32) colsum_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, rows, cpr, TX, ld, off, out, (int)rpb);
+        else colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb);
+        OCTA_CHECK_LAUNCH("colsum_vec");
+        return OCTA_OK;
+    }
     int rpb = (int)cdiv64(rows, 512);
     if (rpb < 64) rpb = 64;
     dim3 grid(cdiv(C, 64), (unsigned)cdiv64(rows, rpb)), block(64, 4);

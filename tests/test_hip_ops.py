@@ -352,3 +352,19 @@ def test_repack_all_matches_per_weight_packs(dev, dtype):
         ref_fwd = ref_fwd.permute(0, 2, 3, 1)
     assert torch.equal(ref_fwd.reshape(-1), single[-2].reshape(-1))
     assert torch.equal(F_._packed(dense, "dgrad", dtype, 1, 64).reshape(-1), single[-1].reshape(-1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 32, 37, 29), (2, 13, 9, 7), (2, 264, 5, 6), (1, 2048, 3, 3), (4, 8, 50, 50)])
+def test_colsum(dev, dtype, shape):
+    """bias-gradient column sums (16-byte vector kernel when C % 8 == 0, scalar kernel otherwise); accumulates into `out`."""
+    from octave_amd import functional as F_
+    B, C, H, W = shape
+    x = rnd(shape, 21)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    out = torch.full((C,), 0.5, dtype=torch.float32, device=dev)
+    F_.raw_colsum(xd, out)
+    ref = x.double().sum(dim=(0, 2, 3)).float() + 0.5
+    check(f"colsum {shape}", out, ref, rtol=1e-4, atol=1e-4 * (B * H * W) ** 0.5)
