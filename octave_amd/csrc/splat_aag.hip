@@ -556,65 +556,89 @@ __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, c
 #pragma unroll
             for (int e = 0; e < EPC; ++e) dwa[k][j][e] = 0.f;
     }
-    for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / LPP; pix < npix + ppb; pix += (int64_t)gridDim.x * ppb) {
-        const bool live = pix < npix;
-        float xv[CPL][EPC], dm[CPL][EPC];
-        float dmask = 0.f;
+    // two pixel rounds per iteration: all loads of both rounds are issued before the first dependent shuffle (the loop is
+    // latency-bound otherwise); block-uniform trip count keeps whole waves in the shuffles; 32-bit pixel decode
+    const int64_t G = (int64_t)gridDim.x * ppb;
+    for (int64_t base = (int64_t)blockIdx.x * ppb; base < npix; base += 2 * G) {
+        int64_t pixs[2];
+        bool lives[2];
+        float xv[2][CPL][EPC], dm[2][CPL][EPC];
+        float dmask[2], ykv[2][K], dyv[2][K];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            const int ch = lp + j * LPP;
-            if (live && ch < cpr) {
-                unpack16<T>(*(const uint4*)(x + pix * C + ch * EPC), xv[j]);
-                if (mode == 0) {
-                    unpack16<T>(*(const uint4*)(dmasked + pix * C + ch * EPC), dm[j]);
+        for (int u = 0; u < 2; ++u) {
+            pixs[u] = base + u * G + threadIdx.x / LPP;
+            lives[u] = pixs[u] < npix;
+            dmask[u] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) dmask += dm[j][e] * xv[j][e];
+            for (int j = 0; j < CPL; ++j) {
+                const int ch = lp + j * LPP;
+                if (lives[u] && ch < cpr) {
+                    unpack16<T>(*(const uint4*)(x + pixs[u] * C + ch * EPC), xv[u][j]);
+                    if (mode == 0) unpack16<T>(*(const uint4*)(dmasked + pixs[u] * C + ch * EPC), dm[u][j]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { xv[u][j][e] = 0.f; dm[u][j][e] = 0.f; }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) { xv[j][e] = 0.f; dm[j][e] = 0.f; }
             }
-        }
-        if (mode == 0)
-            for (int o = LPP >> 1; o > 0; o >>= 1) dmask += __shfl_xor(dmask, o, 64);
-        if (!live) continue;
-        const int64_t b = pix / HW, hw = pix % HW;
-        float dl[K];
-        float mask = 1.f;
-        if (mode == 1) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) dl[k] = dy ? dy[(b * K + k) * HW + hw] : 0.f;
-        } else {
-            float yk[K], g[K];
-            float dot = 0.f;
+            const unsigned p32 = lives[u] ? (unsigned)pixs[u] : 0u;
+            const unsigned b = p32 / (unsigned)HW, hw = p32 - b * (unsigned)HW;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                yk[k] = y[(b * K + k) * HW + hw];
-                g[k] = (dy ? dy[(b * K + k) * HW + hw] : 0.f) + (k >= 1 ? dmask : 0.f);
-                dot += yk[k] * g[k];
+                const size_t idx = ((size_t)b * K + k) * HW + hw;
+                ykv[u][k] = (mode == 0 && lives[u]) ? y[idx] : 0.f;
+                dyv[u][k] = (dy && lives[u]) ? dy[idx] : 0.f;
             }
-            mask = 1.f - yk[0];
-#pragma unroll
-            for (int k = 0; k < K; ++k) dl[k] = yk[k] * (g[k] - dot);
         }
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            const int ch = lp + j * LPP;
-            if (ch < cpr) {
-                float o[EPC];
+        for (int u = 0; u < 2; ++u) {
+            if (mode == 0) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    float v = mode == 0 ? dm[j][e] * mask : 0.f;
+                for (int j = 0; j < CPL; ++j)
 #pragma unroll
-                    for (int k = 0; k < K; ++k) { v += dl[k] * ws[k * C + ch * EPC + e]; dwa[k][j][e] += dl[k] * xv[j][e]; }
-                    o[e] = v;
+                    for (int e = 0; e < EPC; ++e) dmask[u] += dm[u][j][e] * xv[u][j][e];
+                for (int o = LPP >> 1; o > 0; o >>= 1) dmask[u] += __shfl_xor(dmask[u], o, 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!lives[u]) continue;
+            const int64_t pix = pixs[u];
+            float dl[K];
+            float mask = 1.f;
+            if (mode == 1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) dl[k] = dyv[u][k];
+            } else {
+                float g[K];
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    g[k] = dyv[u][k] + (k >= 1 ? dmask[u] : 0.f);
+                    dot += ykv[u][k] * g[k];
                 }
-                *(uint4*)(dx + pix * C + ch * EPC) = pack16<T>(o);
-            }
-        }
-        if (lp == 0)
+                mask = 1.f - ykv[u][0];
 #pragma unroll
-            for (int k = 0; k < K; ++k) dba[k] += dl[k];
+                for (int k = 0; k < K; ++k) dl[k] = ykv[u][k] * (g[k] - dot);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int ch = lp + j * LPP;
+                if (ch < cpr) {
+                    float o[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float v = mode == 0 ? dm[u][j][e] * mask : 0.f;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { v += dl[k] * ws[k * C + ch * EPC + e]; dwa[k][j][e] += dl[k] * xv[u][j][e]; }
+                        o[e] = v;
+                    }
+                    *(uint4*)(dx + pix * C + ch * EPC) = pack16<T>(o);
+                }
+            }
+            if (lp == 0)
+#pragma unroll
+                for (int k = 0; k < K; ++k) dba[k] += dl[k];
+        }
     }
     // block reduction of the weight gradient through LDS atomics, then one global atomic per element
 #pragma unroll
