@@ -244,29 +244,34 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
 // channels, B <= 32 accumulators per lane, wavefront shuffles for the sums).
 #define SPLAT_MAXB 32
 
-// block (= 1 wave) per fc1 output channel j
-__global__ __launch_bounds__(64) void splat_mlp_fwd1_kernel(const float* __restrict__ gap, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rm,
-                                                            float* __restrict__ rv, float momentum, float eps, int training, float* __restrict__ h1,
-                                                            float* __restrict__ h2, float* __restrict__ mean, float* __restrict__ invstd, int B, int C,
-                                                            int inter, int groups) {
-    const int j = blockIdx.x, lane = threadIdx.x;
+// block (4 waves splitting the input channels) per fc1 output channel j
+__global__ __launch_bounds__(256) void splat_mlp_fwd1_kernel(const float* __restrict__ gap, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rm,
+                                                             float* __restrict__ rv, float momentum, float eps, int training, float* __restrict__ h1,
+                                                             float* __restrict__ h2, float* __restrict__ mean, float* __restrict__ invstd, int B, int C,
+                                                             int inter, int groups) {
+    __shared__ float red[4][SPLAT_MAXB];
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Cg = C / groups, grp = j / (inter / groups);
     const float* wr = w1 + (size_t)j * Cg;
     float acc[SPLAT_MAXB];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int c = lane; c < Cg; c += 64) {
+    for (int c = tid; c < Cg; c += 256) {
         const float wv = wr[c];
 #pragma unroll
         for (int b = 0; b < SPLAT_MAXB; ++b)
             if (b < B) acc[b] += wv * gap[(size_t)b * C + grp * Cg + c];
     }
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
+    __syncthreads();
     const float bias = b1 ? b1[j] : 0.f;
     float m = 0.f;
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { acc[b] = wave_sum(acc[b]) + bias; m += acc[b]; }
+        if (b < B) { acc[b] = ((red[0][b] + red[1][b]) + (red[2][b] + red[3][b])) + bias; m += acc[b]; }
     float mu, is;
     if (training) {
         mu = m / (float)B;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(64) void splat_mlp_fwd1_kernel(const float* __restr
             if (b < B) { const float d = acc[b] - mu; var += d * d; }
         var /= (float)B;
         is = 1.f / sqrtf(var + eps);
-        if (lane == 0) {
+        if (tid == 0) {
             if (rm) rm[j] = (1.f - momentum) * rm[j] + momentum * mu;
             if (rv) rv[j] = (1.f - momentum) * rv[j] + momentum * (B > 1 ? var * (float)B / (float)(B - 1) : var);
         }
@@ -284,11 +289,11 @@ __global__ __launch_bounds__(64) void splat_mlp_fwd1_kernel(const float* __restr
         mu = rm[j];
         is = 1.f / sqrtf(rv[j] + eps);
     }
-    if (lane == 0) { mean[j] = mu; invstd[j] = is; }
+    if (tid == 0) { mean[j] = mu; invstd[j] = is; }
     const float g = gamma[j], be = beta[j];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B && lane == (b & 63)) {
+        if (b < B && tid == b) {
             h1[(size_t)b * inter + j] = acc[b];
             const float o = (acc[b] - mu) * is * g + be;
             h2[(size_t)b * inter + j] = o > 0.f ? o : 0.f;
@@ -321,7 +326,7 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
     OCTA_REQUIRE(B >= 1 && B <= SPLAT_MAXB && groups >= 1 && C % groups == 0 && inter % groups == 0, "octa_splat_mlp_fwd: needs 1 <= B <= 32 (got %d)", B);
     OCTA_REQUIRE(training ? B > 1 : (rm && rv), "octa_splat_mlp_fwd: batch statistics need B > 1, eval needs running stats");
     hipStream_t st = (hipStream_t)stream;
-    splat_mlp_fwd1_kernel<<<inter, 64, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
+    splat_mlp_fwd1_kernel<<<inter, 256, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd1");
     splat_mlp_fwd2_kernel<<<2 * C, 64, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd2");
@@ -329,29 +334,36 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
 }
 
 // backward A: block per j.  dh2[b][j] = sum_n dl[b][n] W2[n][j]  -> relu mask -> bn1 backward -> dh1[b][j]; dgamma/dbeta +=
-__global__ __launch_bounds__(64) void splat_mlp_bwdA_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+__global__ __launch_bounds__(256) void splat_mlp_bwdA_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
                                                             const float* __restrict__ h2, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dh1,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1, int B,
                                                             int inter, int N, int groups) {
-    const int j = blockIdx.x, lane = threadIdx.x;
+    // 4 waves split the n range (the kernel is a chain of dependent memory round trips: 4x fewer of them), partials meet in LDS
+    __shared__ float red[4][SPLAT_MAXB];
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Ig = inter / groups, Ng = N / groups, grp = j / Ig, jl = j - grp * Ig;
     float acc[SPLAT_MAXB];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int nn = lane; nn < Ng; nn += 64) {
+    for (int nn = threadIdx.x; nn < Ng; nn += 256) {
         const int n = grp * Ng + nn;
         const float wv = w2[(size_t)n * Ig + jl];
 #pragma unroll
         for (int b = 0; b < SPLAT_MAXB; ++b)
             if (b < B) acc[b] += wv * dl[(size_t)b * N + n];
     }
+#pragma unroll
+    for (int b = 0; b < SPLAT_MAXB; ++b)
+        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
+    __syncthreads();
+    if (wave != 0) return;
     const float mu = mean[j], is = invstd[j], g = gamma[j];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b)
         if (b < B) {
-            float d = wave_sum(acc[b]);
+            float d = (red[0][b] + red[1][b]) + (red[2][b] + red[3][b]);
             if (!(h2[(size_t)b * inter + j] > 0.f)) d = 0.f;
             acc[b] = d;
             s1 += d;
@@ -423,14 +435,14 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdC_kernel(const float* __rest
         if (live) atomicAdd(dgap + (size_t)b * C + c, red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]);
 }
 // backward D: block per j.  dW1[j][c] += sum_b dh1[b][j] gap[b][c]
-__global__ __launch_bounds__(64) void splat_mlp_bwdD_kernel(const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
+__global__ __launch_bounds__(256) void splat_mlp_bwdD_kernel(const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
                                                             int C, int inter, int groups) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const int Cg = C / groups, grp = j / (inter / groups);
     float d[SPLAT_MAXB];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b) d[b] = b < B ? dh1[(size_t)b * inter + j] : 0.f;
-    for (int c = lane; c < Cg; c += 64) {
+    for (int c = lane; c < Cg; c += 256) {
         float a = 0.f;
 #pragma unroll
         for (int b = 0; b < SPLAT_MAXB; ++b)
@@ -445,7 +457,7 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
                  "octa_splat_mlp_bwd: null pointer");
     OCTA_REQUIRE(B > 1 && B <= SPLAT_MAXB && groups >= 1, "octa_splat_mlp_bwd: needs 2 <= B <= 32");
     hipStream_t st = (hipStream_t)stream;
-    splat_mlp_bwdA_kernel<<<inter, 64, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, B, inter, 2 * C, groups);
+    splat_mlp_bwdA_kernel<<<inter, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdA");
     splat_mlp_bwdB_kernel<<<2 * C, 64, 0, st>>>(dlogits, h2, dw2, db2, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdB");
@@ -458,7 +470,7 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
         splat_mlp_bwdC_kernel<<<dim3(cdiv(C, 64), js), 256, 0, st>>>(dh1_ws, w1, dgap, B, C, inter, groups);
     }
     OCTA_CHECK_LAUNCH("splat_mlp_bwdC");
-    splat_mlp_bwdD_kernel<<<inter, 64, 0, st>>>(dh1_ws, gap, dw1, B, C, inter, groups);
+    splat_mlp_bwdD_kernel<<<inter, 256, 0, st>>>(dh1_ws, gap, dw1, B, C, inter, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdD");
     return OCTA_OK;
 }
