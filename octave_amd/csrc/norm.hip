@@ -120,13 +120,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
 
 // one wavefront per channel: lanes merge a strided subset of the block partials, then a butterfly of
 // Chan merges combines the 64 lane results (the merge is associative)
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int rpb, int C, int64_t rows, float eps,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int rpb, int C, int64_t rows, float eps,
                                                                float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                                float* __restrict__ rm, float* __restrict__ rv) {
+    __shared__ double wred[4][3];
     const int c = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double n = 0.0, m = 0.0, m2 = 0.0;
-    for (int b = lane; b < nby; b += 64) {
+    for (int b = threadIdx.x; b < nby; b += 256) {       // 4 waves: a quarter of the dependent round trips
         const int64_t lo = (int64_t)b * rpb;
         const double nb = (double)((rows - lo) < rpb ? (rows - lo) : rpb);
         const double mb = (double)partial[((size_t)b * 2) * C + c], m2b = (double)partial[((size_t)b * 2 + 1) * C + c];
@@ -146,7 +147,19 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
         }
         n = tot;
     }
-    if (lane != 0) return;
+    if (lane == 0) { wred[wave][0] = n; wred[wave][1] = m; wred[wave][2] = m2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < 4; ++w) {
+        const double n2 = wred[w][0], mm2 = wred[w][1], q2 = wred[w][2];
+        const double tot = n + n2;
+        if (tot > 0.0) {
+            const double delta = mm2 - m;
+            m2 = m2 + q2 + delta * delta * n * n2 / tot;
+            m = m + delta * n2 / tot;
+        }
+        n = tot;
+    }
     double var = m2 / n;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
@@ -172,7 +185,7 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     else
         bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(stats)");
-    bn_stats_finalize_kernel<<<C, 64, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    bn_stats_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
     OCTA_CHECK_LAUNCH("bn_stats_finalize");
     return OCTA_OK;
 }
@@ -221,14 +234,19 @@ extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean
 }
 
 // ws layout after finalize: fin[0][c] = sum dy' / N ; fin[1][c] = sum dy' xhat / N
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float* __restrict__ fin,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float* __restrict__ fin,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double wred[4][2];
     const int c = blockIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int b = threadIdx.x; b < nby; b += 64) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = threadIdx.x; b < nby; b += 256) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = s; wred[threadIdx.x >> 6][1] = ss; }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    s = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
+    ss = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
     if (dbeta) dbeta[c] += (float)s;
     if (dgamma) dgamma[c] += (float)ss;
     fin[c] = (float)(s / (double)rows);
@@ -287,7 +305,7 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     else
         bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
-    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");
     if (dtype == OCTA_F32)
         bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);

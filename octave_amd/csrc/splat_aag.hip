@@ -300,24 +300,26 @@ __global__ __launch_bounds__(256) void splat_mlp_fwd1_kernel(const float* __rest
         }
 }
 // block per fc2 output channel n: logits[b][n]
-__global__ __launch_bounds__(64) void splat_mlp_fwd2_kernel(const float* __restrict__ h2, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                            float* __restrict__ logits, int B, int inter, int N, int groups) {
-    const int n = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void splat_mlp_fwd2_kernel(const float* __restrict__ h2, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ logits, int B, int inter, int N, int groups) {
+    __shared__ float red[4][SPLAT_MAXB];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ig = inter / groups, grp = n / (N / groups);
     const float* wr = w2 + (size_t)n * Ig;
     float acc[SPLAT_MAXB];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int j = lane; j < Ig; j += 64) {
+    for (int j = tid; j < Ig; j += 256) {
         const float wv = wr[j];
 #pragma unroll
         for (int b = 0; b < SPLAT_MAXB; ++b)
             if (b < B) acc[b] += wv * h2[(size_t)b * inter + grp * Ig + j];
     }
-    const float bias = b2 ? b2[n] : 0.f;
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { const float v = wave_sum(acc[b]) + bias; if (lane == (b & 63)) logits[(size_t)b * N + n] = v; }
+        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
+    __syncthreads();
+    if (tid < B) logits[(size_t)tid * N + n] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + (b2 ? b2[n] : 0.f);
 }
 extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* gamma, const float* beta, float* rm, float* rv,
                                   float momentum, float eps, int training, const float* w2, const float* b2, float* h1, float* h2, float* mean,
@@ -328,7 +330,7 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
     hipStream_t st = (hipStream_t)stream;
     splat_mlp_fwd1_kernel<<<inter, 256, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd1");
-    splat_mlp_fwd2_kernel<<<2 * C, 64, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
+    splat_mlp_fwd2_kernel<<<2 * C, 256, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd2");
     return OCTA_OK;
 }
