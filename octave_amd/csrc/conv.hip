@@ -1169,6 +1169,190 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient with halo reuse (bf16), for the high-resolution, small-channel layers
+// (decoder_0/1: 400x400 and 200x200 images, N*K of a few 10^4).  The generic kernel above re-gathers every input
+// pixel once per tap from L2 (9x the traffic; it runs at 45-150 TFLOP/s there).  Here a block walks over 8x16 pixel
+// tiles: the (8+2)x(16+2) input patch of its 32-channel chunk(s) and the tile's dy rows are staged in LDS ONCE, and all
+// nine taps read the patch at shifted rows.  The contraction index is the pixel, so both MFMA operands are read
+// transposed (ds_read_b64_tr_b16).  One block owns the whole [N <= 64] x [9 taps] x [64 / 32 channels] gradient slab in
+// registers (18 accumulator tiles per wave) and adds it to dW with fp32 atomics once, at the end.
+//   NT = 4: N <= 64, one 32-channel chunk per block (wave w <-> n-tile w)
+//   NT = 2: N <= 32, two chunks per block            (wave w <-> n-tile w & 1, chunk w >> 1)
+// diagNg/diagCg != 0: a GROUPED conv run densely (decoder_0's 8-in/16-out groups): only the block-diagonal is written.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(const WgradArgs a, int tiles_per_block, int Ctot, int Ntot, int diagNg, int diagCg) {
+    constexpr int CCH = 4 / NT;
+    constexpr int TH = 8, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;
+    constexpr int XROWB = 64 + 16, DYROWB = NT * 32 + 16;     // padded LDS rows (bytes)
+    constexpr int NX = CCH * PROWS * 4, NDY = TH * TW * NT * 2;   // 16-byte chunks per tile
+    constexpr int LX = (NX + 255) / 256, LD = (NDY + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char sX[CCH * PROWS * XROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sDY[TH * TW * DYROWB];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ntile = NT == 4 ? wave : (wave & 1);
+    const int cch = NT == 4 ? 0 : (wave >> 1);
+    const int cbase = blockIdx.y * 32 * CCH;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = a.B * tiles_x * tiles_y;
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+    const bf16_t* __restrict__ xg = (const bf16_t*)a.x + a.xoff + cbase;
+    const bf16_t* __restrict__ dyg = (const bf16_t*)a.dy + a.yoff;
+    const bool do_bias = a.dbias != nullptr && blockIdx.y == 0;
+    float bacc = 0.f;
+
+    uint4 rx[LX], rd_[LD];
+    auto load_tile = [&](int tile) {
+        const int tx = tile % tiles_x;
+        const int tq = tile / tiles_x;
+        const int ty = tq % tiles_y, b = tq / tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = t + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < NX) {
+                const int ch = idx / (PROWS * 4), rem = idx - ch * (PROWS * 4);
+                const int prow = rem >> 2, k16 = rem & 3;
+                const int py = prow / PW, px = prow - py * PW;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cbase + ch * 32 + k16 * 8 < Ctot)
+                    v = *(const uint4*)(xg + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + ch * 32 + k16 * 8);
+            }
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int idx = t + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < NDY) {
+                const int p = idx / (NT * 2), k16 = idx - p * (NT * 2);
+                const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+                if (oy < a.H && ox < a.W && k16 * 8 < Ntot) v = *(const uint4*)(dyg + ((size_t)(b * a.H + oy) * a.W + ox) * a.ldy + k16 * 8);
+            }
+            rd_[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int idx = t + i * 256;
+            if (idx < NX) {
+                const int ch = idx / (PROWS * 4), rem = idx - ch * (PROWS * 4);
+                *(uint4*)(sX + (ch * PROWS + (rem >> 2)) * XROWB + (rem & 3) * 16) = rx[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int idx = t + i * 256;
+            if (idx < NDY) {
+                const int p = idx / (NT * 2), k16 = idx - p * (NT * 2);
+                *(uint4*)(sDY + p * DYROWB + k16 * 16) = rd_[i];
+            }
+        }
+    };
+
+    f32x4_t acc[2][9];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[c][tp] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment of 32 contraction rows x 16 columns: this lane reads 8 bytes at rows mrow and mrow + 4
+    const int mrow = 8 * q + (r >> 2), csub = 4 * (r & 3);
+    auto frag = [&](const unsigned char* row0, int rowb, int colbase) -> uint4 {
+        const unsigned char* p1 = row0 + (colbase + csub) * 2;
+        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+        s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p1 + 4 * rowb));
+        uint2 u1 = __builtin_bit_cast(uint2, v1), u2 = __builtin_bit_cast(uint2, v2);
+        return make_uint4(u1.x, u1.y, u2.x, u2.y);
+    };
+    // patch row of this lane's first contraction row for tap (0,0) of pixel chunk 0; chunk mc adds 2 tile rows
+    const int xrow_lane = ((mrow >> 4) * PW + (mrow & 15)) * XROWB;
+    const int dyrow_lane = mrow * DYROWB;
+
+    if (t0 < t1) load_tile(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();                       // every wave is done with the previous tile's LDS image
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);    // in flight during the MFMAs below
+        if (do_bias && t < NT * 16) {
+            float sacc = 0.f;
+            for (int p = 0; p < TH * TW; ++p) sacc += bf2f(*(const bf16_t*)(sDY + p * DYROWB + t * 2));
+            bacc += sacc;
+        }
+#pragma unroll
+        for (int mc = 0; mc < 4; ++mc) {
+            const uint4 pf = frag(sDY + mc * 32 * DYROWB + dyrow_lane, DYROWB, ntile * 16);
+            const unsigned char* xb = sX + cch * PROWS * XROWB + mc * 2 * PW * XROWB + xrow_lane;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int kh = tp / 3, kw = tp - kh * 3;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint4 qf = frag(xb + (kh * PW + kw) * XROWB, XROWB, c * 16);
+                    acc[c][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, qf), acc[c][tp], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (t0 >= t1) return;
+    // D[row = n (q*4+e)][col = c (r)]
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int cg = cbase + cch * 32 + c * 16 + r;
+        if (cg >= Ctot) continue;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int kh = tp / 3, kw = tp - kh * 3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = ntile * 16 + q * 4 + e;
+                if (n >= Ntot) continue;
+                int ci = cg;
+                if (diagNg) {
+                    const int g = n / diagNg;
+                    if (cg / diagCg != g) continue;
+                    ci = cg - g * diagCg;
+                }
+                atomicAdd(a.dw + (int64_t)n * a.s_o + (int64_t)ci * a.s_i + kh * a.s_h + kw * a.s_w, acc[c][tp][e]);
+            }
+        }
+    }
+    if (do_bias && t < NT * 16 && t < Ntot) atomicAdd(a.dbias + t, bacc);
+}
+
+// eligibility + launch of the halo weight-gradient kernel; returns false when the generic kernel should run
+static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout, hipStream_t st) {
+    if (getenv("OCTA_NO_WGRAD_HALO")) return false;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW) return false;
+    int diagNg = 0, diagCg = 0;
+    if (groups > 1) {                                  // only the small-channel grouped layers that also run densified forward
+        if (Cin / groups > 8 || Cout / groups > 16) return false;
+        diagNg = Cout / groups; diagCg = Cin / groups;
+    }
+    if (Cout > 64 || Cout % 8 != 0 || Cin % 32 != 0 || Cin > 128) return false;
+    const int NT = (Cout > 32 || Cin % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
+    if ((int64_t)a.H * a.W < 128 * 128) return false;  // small images: the generic kernel's split-M has enough reuse per byte
+    const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
+    if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
+    if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;
+    const int ntiles = a.B * th * tw;
+    const int ychunks = Cin / (32 * (4 / NT));
+    int nblk = 1024 / ychunks;                         // ~4 blocks per CU in total; each ends with up to 18432 atomics
+    if (nblk > ntiles) nblk = ntiles;
+    const int tpb = cdiv(ntiles, nblk);
+    nblk = cdiv(ntiles, tpb);
+    dim3 grid(nblk, ychunks);
+    if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
+    else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
+    return true;
+}
+
 template <typename T>
 static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     constexpr int MT = WgLds<T>::MT;
@@ -1214,6 +1398,10 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
     a.M = d->B * d->OH * d->OW; a.Kpad = d->KH * d->KW * a.Cg;
     a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
     a.dbias = dbias;
+    if (d->dtype == OCTA_BF16 && launch_wgrad_halo(a, d->groups, d->Cin, d->Cout, (hipStream_t)stream)) {
+        OCTA_CHECK_LAUNCH("conv3x3_wgrad_halo");
+        return OCTA_OK;
+    }
     return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
                                 : launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream);
 }

@@ -86,6 +86,10 @@ CONV_CASES = [
     (256, 512, 1, 1, 0, 1, 8, 6, 6),     # shortcut 1x1 after the 2x2 average pool
     (128, 256, 3, 1, 1, 2, 8, 12, 12),   # its split-attention conv
     (32, 64, 3, 1, 1, 4, 1, 130, 140),   # decoder_0 SplAt conv at high resolution: densified (block-diagonal) halo path
+    (64, 32, 3, 1, 1, 1, 1, 130, 140),   # halo weight-gradient kernel, N <= 32 (two channel chunks per block), partial tiles
+    (128, 64, 3, 1, 1, 1, 1, 128, 136),  # halo weight-gradient kernel, N <= 64, four channel-chunk blocks
+    (32, 48, 3, 1, 1, 1, 2, 128, 128),   # halo weight-gradient kernel, N = 48 (partial n-tile), batch 2
+    (32, 32, 3, 1, 1, 1, 1, 136, 128),   # halo weight-gradient kernel, stem shape (N = 32 with one channel chunk)
 ]
 
 
