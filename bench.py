@@ -66,20 +66,10 @@ def conv_flops(d):
     return 2.0 * d.B * d.OH * d.OW * d.Cout * (d.Cin // getattr(d, "alg_groups", d.groups)) * d.KH * d.KW    # algorithmic (densified layers too)
 
 
-def kernel_name(kind, d):
-    """The template instance the host dispatcher picks (octave_amd/csrc/conv.hip launch_igemm / launch_wgrad)."""
-    t = "bf16" if d.dtype == 1 else "f32"
-    if kind == "wgrad":
-        ng = d.Cout // d.groups
-        return f"conv_wgrad_kernel<{t},{'128' if ng > 64 else ('64' if ng > 32 else '32')}>"
-    ng = (d.Cin if kind == "dgrad" else d.Cout) // d.groups
-    tile = "128x128" if ng > 64 else ("256x64" if ng > 32 else ("256x32" if ng > 16 else "256x16"))
-    return f"conv_igemm_kernel<{t},{tile}>"
-
-
 def roofline_leg(step, batch, dtype_name):
-    """Record one step's conv-engine launches, then replay each launch REP times between HIP events on
-    the stream it is launched on (torch's current stream) and aggregate per kernel instance."""
+    """Record one step's conv-engine launches, then replay them once, in order, each between two HIP events on the stream
+    it is launched on (torch's current stream), and aggregate per kernel instance (the name is the template instance the
+    library reports it dispatched: octa_last_conv_kernel)."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import lib
@@ -91,8 +81,8 @@ def roofline_leg(step, batch, dtype_name):
     step._graphs = graphs
     torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
-    REP = 3
     agg = {}
+    pending = []
     dw_scratch = {}
     for kind, d, ptrs, keep in rec:
         def launch():
@@ -107,16 +97,18 @@ def roofline_leg(step, batch, dtype_name):
                     n = sum((s - 1) * t for s, t in zip(shape, stride)) + 1
                     dw_scratch[key] = torch.zeros(n, dtype=torch.float32, device="cuda")
                 L.octa_conv2d_wgrad(ctypes.byref(d), ptrs[0], ptrs[1], dw_scratch[key].data_ptr(), (ctypes.c_int64 * 4)(*stride), None, st)
-        launch()
+        # ONE launch per recorded call, in program order and without a warm-up launch, so the caches are in about the state
+        # the kernel finds inside the step (back-to-back repeats of one launch run 10 % faster out of a warm L2 / MALL)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(REP):
-            launch()
+        launch()
         e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / REP
-        a = agg.setdefault(kernel_name(kind, d), [0.0, 0.0, 0])
-        a[0] += conv_flops(d)
+        pending.append((e0, e1, L.octa_last_conv_kernel().decode(), conv_flops(d)))
+    torch.cuda.synchronize()
+    for e0, e1, kname, fl in pending:
+        ms = e0.elapsed_time(e1)
+        a = agg.setdefault(kname, [0.0, 0.0, 0])
+        a[0] += fl
         a[1] += ms * 1e-3
         a[2] += 1
     tot_f = sum(a[0] for a in agg.values())

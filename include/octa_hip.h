@@ -111,6 +111,11 @@ int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, fl
                       const int64_t* dw_strides /* o,i,h,w element strides of dw */,
                       float* dbias /* optional: dbias[Cout] += sum_pixels dy (fused bias gradient) */,
                       octa_stream_t stream);
+/* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
+ * call dispatched, e.g. "conv_igemm_kernel<bf16,128x128>", "conv3x3_halo_kernel<bf16,128x64>",
+ * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline
+ * leg keys its per-kernel timings with it, so they line up with the rocprofv3 kernel names). */
+const char* octa_last_conv_kernel(void);
 /* out[c] += sum over rows of src[row*ld + off + c]  (bias gradients; fp32 accumulate). */
 int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out,
                 octa_stream_t stream);

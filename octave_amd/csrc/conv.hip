@@ -593,6 +593,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     }
 }
 
+// Name of the kernel template instance the last conv-engine entry point of this thread dispatched, in the naming of
+// tools/pmc_traffic.py (bench.py attributes its per-launch timings with it instead of re-implementing the dispatcher).
+static thread_local char g_last_kernel[96] = "";
+template <typename T> static void note_kernel(const char* family, int bm, int bn) {
+    if (bn > 0) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%dx%d>", family, sizeof(T) == 2 ? "bf16" : "f32", bm, bn);
+    else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%d>", family, sizeof(T) == 2 ? "bf16" : "f32", bm);
+}
+extern "C" const char* octa_last_conv_kernel(void) { return g_last_kernel; }
+
 template <typename T, int MODE>
 static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
     // eligibility: 3x3, stride 1, pad 1 (same image in and out), 64-byte channel chunks, 32-bit offsets
@@ -607,15 +616,19 @@ static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
     if (a.Ng > 64) {
         dim3 grid(tiles, cdiv(a.Ng, 128), groups);
         conv3x3_halo_kernel<T, 2, 2, 4, 4, MODE><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv3x3_halo_kernel", 128, 128);
     } else if (a.Ng > 32) {
         dim3 grid(tiles, 1, groups);
         conv3x3_halo_kernel<T, 4, 1, 2, 4, MODE><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv3x3_halo_kernel", 128, 64);
     } else if (a.Ng > 16) {
         dim3 grid(tiles, 1, groups);
         conv3x3_halo_kernel<T, 4, 1, 2, 2, MODE><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv3x3_halo_kernel", 128, 32);
     } else {
         dim3 grid(tiles, 1, groups);
         conv3x3_halo_kernel<T, 4, 1, 2, 1, MODE><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv3x3_halo_kernel", 128, 16);
     }
     return true;
 }
@@ -650,20 +663,21 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
             // too few 128x128 tiles to fill 256 CUs (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
             dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
             conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
-        } else if (dma) launch_dma<T, 2, 2, 4, 4>(a, grid, st);
-        else conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
+            note_kernel<T>("conv_igemm_kernel", 64, 64);
+        } else if (dma) { launch_dma<T, 2, 2, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 128, 128); }
+        else { conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 128); }
     } else if (a.Ng > 32) {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) launch_dma<T, 4, 1, 4, 4>(a, grid, st);
-        else conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a);
+        if (dma) { launch_dma<T, 4, 1, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 64); }
+        else { conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 64); }
     } else if (a.Ng > 16) {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) launch_dma<T, 4, 1, 4, 2>(a, grid, st);
-        else conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a);
+        if (dma) { launch_dma<T, 4, 1, 4, 2>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 32); }
+        else { conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 32); }
     } else {
         dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) launch_dma<T, 4, 1, 4, 1>(a, grid, st);
-        else conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a);
+        if (dma) { launch_dma<T, 4, 1, 4, 1>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 16); }
+        else { conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 16); }
     }
     OCTA_CHECK_LAUNCH("conv_igemm");
     return OCTA_OK;
@@ -1350,6 +1364,7 @@ static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout,
     dim3 grid(nblk, ychunks);
     if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
     else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>", NT);
     return true;
 }
 
@@ -1374,6 +1389,7 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     if (bnn == 128) conv_wgrad_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
     else if (bnn == 64) conv_wgrad_kernel<T, 1, 4, 4, 2><<<grid, block, 0, st>>>(a);
     else conv_wgrad_kernel<T, 1, 4, 2, 2><<<grid, block, 0, st>>>(a);
+    note_kernel<T>("conv_wgrad_kernel", bnn, 0);
     OCTA_CHECK_LAUNCH("conv_wgrad");
     return OCTA_OK;
 }
