@@ -145,18 +145,22 @@ size_t octa_bn_workspace_floats(int64_t rows, int C);
 int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off, int dtype, float eps,
                   float momentum, float* mean, float* invstd, float* running_mean,
                   float* running_var, float* workspace, octa_stream_t stream);
-/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).
+ * relu_mask (optional, relu != 0): rows * C / (8 bf16 | 4 fp32) bytes, one per 16-byte chunk of y in
+ * row-major (row, chunk) order, bit e = output e of the chunk is > 0.  The backward pass reads it
+ * instead of y (1/16 of the bytes). */
 int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, const void* residual, int ldr, int roff,
                   void* y, int ldy, int yoff, int64_t rows, int C, int dtype, int relu,
-                  octa_stream_t stream);
-/* backward.  y is the forward output (only read when relu != 0, for the mask).
+                  uint8_t* relu_mask, octa_stream_t stream);
+/* backward.  With relu != 0 the ReLU mask comes from relu_mask (as written by octa_bn_apply) when it
+ * is given, else from the forward output y (y may be NULL when relu_mask is given).
  * dgamma/dbeta are ACCUMULATED (+=).  dres (optional) receives the masked dy. */
 int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, int ldx, int xoff, const void* y,
                 int ldy, int yoff, const float* mean, const float* invstd, const float* gamma,
                 void* dx, int lddx, int dxoff, void* dres, int lddr, int droff, float* dgamma,
-                float* dbeta, int64_t rows, int C, int dtype, int relu, float* workspace,
-                octa_stream_t stream);
+                float* dbeta, int64_t rows, int C, int dtype, int relu, const uint8_t* relu_mask,
+                float* workspace, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling (compose.py:45 maxpool 3/2/1; resnest.py:189 avgpool 3/s/1 count_include_pad;

@@ -31,7 +31,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, int ldx, int xoff, const T* __restrict__ dy, int lddy,
                                                         int dyoff, const T* __restrict__ y, int ldy, int yoff,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                        int64_t rows, int C, int TX, int rpb, float* __restrict__ partial) {
+                                                        const uint8_t* __restrict__ rmask, int64_t rows, int C, int TX, int rpb,
+                                                        float* __restrict__ partial) {
     constexpr int EPC = DT<T>::EPC;
     extern __shared__ float red[];   // [RY][TX*EPC][2 or 3]
     const int RY = 256 / TX;
@@ -63,7 +64,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
             } else {
                 float dv[EPC], yv[EPC];
                 unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
-                if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + col * EPC), yv);
+                if (relu && rmask) {
+                    // one byte per 16-byte chunk written by bn_apply: bit e = "output e passed the ReLU" (a 1/16-size read instead of y)
+                    const unsigned mb = rmask[r * cpr + col];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
+                } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + col * EPC), yv);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
@@ -181,9 +187,9 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     dim3 grid(cm.gridx, nby);
     const size_t sh = (size_t)256 * epc * 3 * sizeof(float);
     if (dtype == OCTA_F32)
-        bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
     else
-        bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(stats)");
     bn_stats_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
     OCTA_CHECK_LAUNCH("bn_stats_finalize");
@@ -194,24 +200,44 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, int xoff, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res, int ldr, int roff,
-                                                       T* __restrict__ y, int ldy, int yoff, int64_t rows, int cpr, int relu) {
+                                                       T* __restrict__ y, int ldy, int yoff, int64_t rows, int cpr, int relu,
+                                                       uint8_t* __restrict__ rmask) {
     constexpr int EPC = DT<T>::EPC;
     const int64_t total = rows * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / cpr;
-        const int c0 = (int)(i - r * cpr) * EPC;
+    // block-uniform trip count: the mask bytes of 4 neighbouring lanes leave as ONE dword (byte stores ran 5x slower)
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < total;
+        const int64_t r = live ? i / cpr : 0;
+        const int c0 = live ? (int)(i - r * cpr) * EPC : 0;
         float v[EPC], rr[EPC];
+        unsigned mb = 0u;
         unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), v);
         if (res) unpack16<T>(*(const uint4*)(res + r * ldr + roff + c0), rr);
+        // per-channel parameters as 16-byte loads issued together (32 scalar loads were being serialised)
+        float mu[EPC], isd[EPC], ga[EPC], be[EPC];
+#pragma unroll
+        for (int k = 0; k < EPC / 4; ++k) {
+            *(float4*)&mu[4 * k] = *(const float4*)(mean + c0 + 4 * k);
+            *(float4*)&isd[4 * k] = *(const float4*)(invstd + c0 + 4 * k);
+            *(float4*)&ga[4 * k] = *(const float4*)(gamma + c0 + 4 * k);
+            *(float4*)&be[4 * k] = *(const float4*)(beta + c0 + 4 * k);
+        }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float sc = gamma[c0 + e] * invstd[c0 + e];
-            float o = (v[e] - mean[c0 + e]) * sc + beta[c0 + e];
+            const float sc = ga[e] * isd[e];
+            float o = (v[e] - mu[e]) * sc + be[e];
             if (res) o += rr[e];
-            if (relu) o = o > 0.f ? o : 0.f;
+            if (relu) { if (o > 0.f) mb |= 1u << e; else o = 0.f; }
             v[e] = o;
         }
-        *(uint4*)(y + r * ldy + yoff + c0) = pack16<T>(v);
+        if (live) *(uint4*)(y + r * ldy + yoff + c0) = pack16<T>(v);
+        if (rmask) {
+            unsigned w = live ? (mb << (8 * (threadIdx.x & 3))) : 0u;
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            if ((threadIdx.x & 3) == 0 && live) *(unsigned*)(rmask + i) = w;     // buffer is padded to a multiple of 4 bytes
+        }
     }
 }
 
@@ -219,15 +245,15 @@ static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int
 
 extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, const void* residual, int ldr, int roff, void* y, int ldy, int yoff, int64_t rows,
-                             int C, int dtype, int relu, octa_stream_t stream) {
+                             int C, int dtype, int relu, uint8_t* relu_mask, octa_stream_t stream) {
     OCTA_REQUIRE(x && y && mean && invstd && gamma && beta, "octa_bn_apply: null pointer");
     OCTA_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && (!residual || (ldr % 8 == 0 && roff % 8 == 0)),
                  "octa_bn_apply: C/ld/off must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32)
-        bn_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu);
+        bn_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu, relu_mask);
     else if (dtype == OCTA_BF16)
-        bn_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu);
+        bn_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_bn_apply: bad dtype");
     OCTA_CHECK_LAUNCH("bn_apply");
     return OCTA_OK;
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int xoff, const T* __restrict__ y, int ldy, int yoff,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ fin,
-                                                           T* __restrict__ dx, int lddx, int dxoff, T* __restrict__ dres, int lddr,
+                                                           const uint8_t* __restrict__ rmask, T* __restrict__ dx, int lddx, int dxoff, T* __restrict__ dres, int lddr,
                                                            int droff, int64_t rows, int C, int relu) {
     constexpr int EPC = DT<T>::EPC;
     const int cpr = C / EPC;
@@ -269,7 +295,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float dv[EPC], xv[EPC], yv[EPC], o[EPC];
         unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + c0), dv);
         unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), xv);
-        if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + c0), yv);
+        if (relu && rmask) {
+            const unsigned mb = rmask[i];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
+        } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + c0), yv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
@@ -285,10 +315,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, int ldx, int xoff, const void* y, int ldy, int yoff,
                            const float* mean, const float* invstd, const float* gamma, void* dx, int lddx, int dxoff, void* dres,
-                           int lddr, int droff, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, int relu, float* ws,
-                           octa_stream_t stream) {
+                           int lddr, int droff, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, int relu,
+                           const uint8_t* relu_mask, float* ws, octa_stream_t stream) {
     OCTA_REQUIRE(dy && x && mean && invstd && gamma && dx && ws, "octa_bn_bwd: null pointer");
-    OCTA_REQUIRE(!relu || y, "octa_bn_bwd: relu needs the forward output");
+    OCTA_REQUIRE(!relu || y || relu_mask, "octa_bn_bwd: relu needs the forward output or the mask octa_bn_apply wrote");
     OCTA_REQUIRE(C % 8 == 0 && lddy % 8 == 0 && dyoff % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddx % 8 == 0 && dxoff % 8 == 0,
                  "octa_bn_bwd: C/ld/off must be multiples of 8");
     OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_bn_bwd: bad dtype");
@@ -301,16 +331,16 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
     float* fin = ws + (size_t)1026 * 2 * C;
     if (dtype == OCTA_F32)
-        bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
     else
-        bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");
     if (dtype == OCTA_F32)
-        bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
+        bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
     else
-        bn_bwd_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
+        bn_bwd_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
     OCTA_CHECK_LAUNCH("bn_bwd_apply");
     return OCTA_OK;
 }
