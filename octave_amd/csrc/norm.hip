@@ -300,13 +300,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
         } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + c0), yv);
+        float mu[EPC], isd[EPC], ga[EPC], f0[EPC], f1[EPC];
+#pragma unroll
+        for (int k = 0; k < EPC / 4; ++k) {
+            *(float4*)&mu[4 * k] = *(const float4*)(mean + c0 + 4 * k);
+            *(float4*)&isd[4 * k] = *(const float4*)(invstd + c0 + 4 * k);
+            *(float4*)&ga[4 * k] = *(const float4*)(gamma + c0 + 4 * k);
+            *(float4*)&f0[4 * k] = *(const float4*)(fin + c0 + 4 * k);
+            *(float4*)&f1[4 * k] = *(const float4*)(fin + C + c0 + 4 * k);
+        }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
             dv[e] = d;
-            const float is = invstd[c0 + e];
-            const float xh = (xv[e] - mean[c0 + e]) * is;
-            o[e] = gamma[c0 + e] * is * (d - fin[c0 + e] - xh * fin[C + c0 + e]);
+            const float is = isd[e];
+            const float xh = (xv[e] - mu[e]) * is;
+            o[e] = ga[e] * is * (d - f0[e] - xh * f1[e]);
         }
         *(uint4*)(dx + r * lddx + dxoff + c0) = pack16<T>(o);
         if (dres) *(uint4*)(dres + r * lddr + droff + c0) = pack16<T>(dv);
