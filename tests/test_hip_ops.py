@@ -372,3 +372,81 @@ def test_colsum(dev, dtype, shape):
     F_.raw_colsum(xd, out)
     ref = x.double().sum(dim=(0, 2, 3)).float() + 0.5
     check(f"colsum {shape}", out, ref, rtol=1e-4, atol=1e-4 * (B * H * W) ** 0.5)
+
+
+# --------------------------------------------------------------------------- full-size properties (BASELINE sizes: B=16, 400x400)
+FULL_SIZE_CONVS = [
+    # Cin, Cout, k, s, p, g, B, H, W                     the kernels this shape goes through
+    (64, 32, 3, 1, 1, 1, 16, 400, 400),    # decoder_0 3x3: halo fwd/dgrad 128x32 / 128x64, halo weight-gradient kernel <2>
+    (32, 64, 3, 1, 1, 4, 16, 400, 400),    # decoder_0 split-attention conv: densified block-diagonal fwd/dgrad, halo wgrad <4> (diagonal)
+    (2, 64, 4, 2, 1, 1, 16, 400, 400),     # discriminator stack_0: generic 256x64, strided dgrad = GEMM + col2im
+    (64, 32, 1, 1, 0, 1, 16, 400, 400),    # decoder_0 shortcut 1x1
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_CONVS)
+def test_conv_adjoint_identities_full_size(dev, case):
+    """Size-independent parity at the benchmark's real tensor sizes, where a CPU oracle would take minutes: the three conv
+    kernels of a layer are tied together by the adjoint identities  <conv(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(x, dy)>
+    (all three are the same trilinear form), evaluated with the same bf16 operands and fp32 accumulation; plus linearity of the
+    forward in x.  Any tap/halo/edge/grouping error in one kernel breaks an identity."""
+    from octave_amd import functional as F_
+    Cin, Cout, k, s, p, g, B, H, W = case
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dev).to(torch.bfloat16)
+    x2 = torch.randn(B, Cin, H, W, generator=gen).to(dev).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * (1.0 / (k * k * Cin / g) ** 0.5)).to(dev)
+    wq = torch.nn.Parameter(w.bfloat16().float().contiguous(memory_format=torch.channels_last))
+    y = F_.raw_conv_fwd(x, wq, None, s, p, g)
+    dy = torch.randn(tuple(y.shape), generator=gen).to(dev).to(torch.bfloat16)
+    dyn = F_.to_nhwc(dy)
+    dx = F_.raw_conv_dgrad(dyn, wq, tuple(x.shape), s, p, g)
+    dw = F_.raw_conv_wgrad(x, dyn, wq, s, p, g)
+    yf, dyf = F_.to_nchw_f32(y).double(), dy.double()
+    t_fwd = (yf * dyf).sum().item()
+    t_dgrad = (F_.to_nchw_f32(dx).double() * x.double()).sum().item()
+    t_wgrad = (dw.double() * wq.detach().double()).sum().item()
+    scale = (yf.abs() * dyf.abs()).sum().item()
+    print(f"[adjoint {case}] fwd {t_fwd:.6e} dgrad {t_dgrad:.6e} wgrad {t_wgrad:.6e} (|terms| sum {scale:.3e})")
+    # y and dx are rounded to bf16 on store (relative 2^-9 per element, random sign): the sums agree far better than that
+    assert abs(t_fwd - t_dgrad) <= 2e-4 * scale and abs(t_fwd - t_wgrad) <= 2e-4 * scale, (t_fwd, t_dgrad, t_wgrad, scale)
+    # linearity in x (exact in fp32 accumulation up to the bf16 rounding of the three outputs)
+    y2 = F_.raw_conv_fwd(x2, wq, None, s, p, g)
+    xs = (x.float() + x2.float()).to(torch.bfloat16)       # the sum is rounded: compare against conv of the ROUNDED sum's parts
+    ys = F_.raw_conv_fwd(xs, wq, None, s, p, g)
+    exact = (xs.float() - x.float() - x2.float()).abs().max().item()
+    lin = (F_.to_nchw_f32(ys) - F_.to_nchw_f32(y) - F_.to_nchw_f32(y2)).abs().max().item()
+    ymax = F_.to_nchw_f32(ys).abs().max().item()
+    assert lin <= 0.03 * ymax + 8 * exact, (lin, ymax, exact)
+
+
+def test_batch_norm_full_size(dev):
+    """Train-mode BatchNorm at 16 x 64 x 400 x 400 (bf16), forward and backward against a float64 evaluation of the same
+    formulas on the same bf16 inputs (torch ops on the GPU: the CPU oracle would need minutes at this size).  Outputs are
+    stored in bf16, so the bound is one bf16 ulp of the value (2^-8 relative); with gamma = 1, beta = 0 the output channels
+    must come out with mean 0 / variance 1.  (sum_i dx_i is NOT ~0 after the bf16 store: the float64 reference rounded to
+    bf16 shows the same +-200 per channel.)"""
+    from octave_amd import functional as F_
+    B, C, H, W = 16, 64, 400, 400
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.randn(B, C, H, W, generator=gen) * 3.0 + 1.5).to(dev).to(torch.bfloat16).requires_grad_(True)
+    gam = torch.ones(C, device=dev, requires_grad=True)
+    bet = torch.zeros(C, device=dev, requires_grad=True)
+    y = F_.batch_norm(x, gam, bet, None, None, 0.1, 1e-5, True)
+    yf = F_.to_nchw_f32(y.detach())
+    m, v = yf.mean(dim=(0, 2, 3)), yf.var(dim=(0, 2, 3), unbiased=False)
+    assert m.abs().max().item() < 2e-3 and (v - 1).abs().max().item() < 5e-3, (m.abs().max().item(), (v - 1).abs().max().item())
+    g = torch.randn(B, C, H, W, generator=gen).to(dev).to(torch.bfloat16)
+    (y.float() * g.float()).sum().backward()
+    dx = F_.to_nchw_f32(x.grad).double()
+    xd, gd = x.detach().double(), g.double()
+    mu = xd.mean(dim=(0, 2, 3), keepdim=True)
+    isd = 1.0 / torch.sqrt(xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+    xh = (xd - mu) * isd
+    assert (yf.double() - xh).abs().max().item() <= 2.0 ** -8 * xh.abs().max().item() + 1e-6
+    ref = isd * (gd - gd.mean(dim=(0, 2, 3), keepdim=True) - xh * (gd * xh).mean(dim=(0, 2, 3), keepdim=True))
+    err = (dx - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), err.max().item()
+    n = B * H * W
+    assert (gam.grad.double() - (gd * xh).sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2
+    assert (bet.grad.double() - gd.sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2
