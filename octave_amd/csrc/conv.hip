@@ -659,8 +659,12 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
     if (a.Ng > 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
         static const bool small_tiles = getenv("OCTA_NO_SMALL_TILES") == nullptr;
-        if (small_tiles && !dma && (int64_t)grid.x * grid.y * grid.z < 320) {
-            // too few 128x128 tiles to fill 256 CUs (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
+        // short-K launches (K <= 256: 1x1 convs on <= 256 channels, the strided-dgrad GEMMs) are bound by memory latency, not
+        // MFMA: the 64x64 tile keeps 7 waves per SIMD resident instead of 3 (measured -0.57 ms/step; 0 disables)
+        static const int smallk = getenv("OCTA_SMALLK_TILES") ? atoi(getenv("OCTA_SMALLK_TILES")) : 256;
+        const bool mem_bound = smallk > 0 && a.Kc * DT<T>::EPC <= smallk;
+        if (small_tiles && !dma && ((int64_t)grid.x * grid.y * grid.z < 320 || mem_bound)) {
+            // also: too few 128x128 tiles to fill 256 CUs (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
             dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
             conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
             note_kernel<T>("conv_igemm_kernel", 64, 64);
