@@ -670,18 +670,20 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
             note_kernel<T>("conv_igemm_kernel", 64, 64);
         } else if (dma) { launch_dma<T, 2, 2, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 128, 128); }
         else { conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 128); }
-    } else if (a.Ng > 32) {
-        dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) { launch_dma<T, 4, 1, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 64); }
-        else { conv_igemm_kernel<T, 4, 1, 4, 4><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 64); }
-    } else if (a.Ng > 16) {
-        dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) { launch_dma<T, 4, 1, 4, 2>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 32); }
-        else { conv_igemm_kernel<T, 4, 1, 4, 2><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 32); }
     } else {
-        dim3 grid(cdiv(a.M, 256), 1, groups);
-        if (dma) { launch_dma<T, 4, 1, 4, 1>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 16); }
-        else { conv_igemm_kernel<T, 4, 1, 4, 1><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 256, 16); }
+        // Ng <= 64: 128-row tiles (4-5 waves per SIMD instead of 3: measured faster than the 256-row tiles on every launch of
+        // the step, -0.4 ms/step); the LDS-DMA variant keeps its 256-row shapes
+        dim3 grid(cdiv(a.M, 256), 1, groups), g128(cdiv(a.M, 128), 1, groups);
+        if (a.Ng > 32) {
+            if (dma) { launch_dma<T, 4, 1, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 64); }
+            else { conv_igemm_kernel<T, 4, 1, 2, 4><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 64); }
+        } else if (a.Ng > 16) {
+            if (dma) { launch_dma<T, 4, 1, 4, 2>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 32); }
+            else { conv_igemm_kernel<T, 4, 1, 2, 2><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 32); }
+        } else {
+            if (dma) { launch_dma<T, 4, 1, 4, 1>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 16); }
+            else { conv_igemm_kernel<T, 4, 1, 2, 1><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 16); }
+        }
     }
     OCTA_CHECK_LAUNCH("conv_igemm");
     return OCTA_OK;
@@ -1381,7 +1383,7 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     const int base = tilesK * tilesN * groups;
     // every block ends with BNn x 128 fp32 atomics (~13 us per block at the chip-wide atomic rate): give it at
     // least 16 m-tiles of MFMA work, and no more blocks than ~2 per CU
-    int split = cdiv(512, base);
+    int split = cdiv(512, base);          // (512 blocks, >= 16 m-tiles) re-checked against 384..1024 x 8..16: still the best
     const int maxsplit = max(1, a.M / (MT * 16));
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
