@@ -613,7 +613,14 @@ static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
     // partial 8x16 tiles waste MFMA work: below ~80 % tile utilisation the generic gather kernel is faster
     if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
     const int tiles = a.B * th * tw;
-    if (a.Ng > 64) {
+    static const bool halo128 = getenv("OCTA_HALO_BN128") != nullptr;
+    if (a.Ng > 64 && !halo128) {
+        // 64-channel n-tiles, two (or more) of them per pixel tile: 4 waves per SIMD instead of 2 for the 128x128 shape (56 KB of
+        // LDS, 197 registers); the patch of the second n-tile comes out of L2.  Measured -0.2 ms/step over all halo launches.
+        dim3 grid(tiles, cdiv(a.Ng, 64), groups);
+        conv3x3_halo_kernel<T, 4, 1, 2, 4, MODE><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv3x3_halo_kernel", 128, 64);
+    } else if (a.Ng > 64) {
         dim3 grid(tiles, cdiv(a.Ng, 128), groups);
         conv3x3_halo_kernel<T, 2, 2, 4, 4, MODE><<<grid, 256, 0, st>>>(a);
         note_kernel<T>("conv3x3_halo_kernel", 128, 128);
