@@ -1370,7 +1370,8 @@ static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout,
     if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;
     const int ntiles = a.B * th * tw;
     const int ychunks = Cin / (32 * (4 / NT));
-    int nblk = 1024 / ychunks;                         // ~4 blocks per CU in total; each ends with up to 18432 atomics
+    int nblk = 512 / ychunks;                          // 2 blocks per CU are resident (178 registers): one full round; each block ends
+                                                       // with up to 18432 atomics (512 beat 1024 / 2048 / 4096 by 6 / 25 / 50 %)
     if (nblk > ntiles) nblk = ntiles;
     const int tpb = cdiv(ntiles, nblk);
     nblk = cdiv(ntiles, tpb);
