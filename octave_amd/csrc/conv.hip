@@ -670,8 +670,9 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
         // MFMA: the 64x64 tile keeps 7 waves per SIMD resident instead of 3 (measured -0.57 ms/step; 0 disables)
         static const int smallk = getenv("OCTA_SMALLK_TILES") ? atoi(getenv("OCTA_SMALLK_TILES")) : 256;
         const bool mem_bound = smallk > 0 && a.Kc * DT<T>::EPC <= smallk;
-        if (small_tiles && !dma && ((int64_t)grid.x * grid.y * grid.z < 320 || mem_bound)) {
-            // also: too few 128x128 tiles to fill 256 CUs (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
+        if (small_tiles && !dma && ((int64_t)grid.x * grid.y * grid.z < 512 || mem_bound)) {
+            // also: too few 128x128 tiles to fill 256 CUs twice (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
+            // (threshold swept 320 / 520 / 800 / 1300: 520 best)
             dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
             conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
             note_kernel<T>("conv_igemm_kernel", 64, 64);
@@ -1471,7 +1472,7 @@ extern "C" int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, in
                            int pad, int dtype, octa_stream_t stream) {
     OCTA_REQUIRE(z && dx && B > 0 && Cin > 0 && stride > 0, "octa_col2im: bad arguments");
     const int64_t total = (int64_t)B * H * W * Cin;
-    const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+    const int blocks = (int)(cdiv64(total, 256) > 131072 ? 131072 : cdiv64(total, 256));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) col2im_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
     else if (dtype == OCTA_BF16) col2im_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);

@@ -2,7 +2,7 @@
 // kernels: 16-byte chunks, wavefront shuffles for the per-pixel and per-channel sums.
 #include "common.hpp"
 
-static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 131072 ? 131072 : (b < 1 ? 1 : b)); }   // see norm.hip
 
 // =========================================================================================== SplAt
 // gap[b][c] += (1/HW) sum_hw (x[b,hw,c] + x[b,hw,C+c]);  grid (colblocks, hw splits, B)
