@@ -213,10 +213,14 @@ int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, 
  * ---------------------------------------------------------------------------------------- */
 int octa_aag_fwd(const void* x, const float* w, const float* bias, void* masked, float* y, int64_t B,
                  int HW, int C, int K, int dtype, int mode, octa_stream_t stream);
-/* dx = dmasked*mask + W^T dlogits; dw/dbias ACCUMULATED (fp32). dy may be NULL (no grad). */
+/* dx = dmasked*mask + W^T dlogits; dw/dbias ACCUMULATED (fp32). dy may be NULL (no grad).
+ * workspace (optional, octa_aag_workspace_floats(C, K) floats, no initialisation needed): the blocks then
+ * leave per-block partials that a second small launch folds into dw/dbias, instead of ~1000 blocks adding
+ * into the same few cache lines with float atomics (50-100 us per launch). */
+size_t octa_aag_workspace_floats(int C, int K);
 int octa_aag_bwd(const void* x, const float* w, const float* y, const void* dmasked, const float* dy,
                  void* dx, float* dw, float* dbias, int64_t B, int HW, int C, int K, int dtype,
-                 int mode, octa_stream_t stream);
+                 int mode, float* workspace, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise activations (discriminator/blocks.py:51,94,110): backward from the OUTPUT.

@@ -550,12 +550,13 @@ template <typename T, int K, int CPL>
 __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ y,
                                                       const T* __restrict__ dmasked, const float* __restrict__ dy, T* __restrict__ dx,
                                                       float* __restrict__ dw, float* __restrict__ dbias, int64_t npix, int HW, int C, int LPP,
-                                                      int mode) {
+                                                      int mode, float* __restrict__ part /* [gridDim.x][K*C + K] or null */) {
     constexpr int EPC = DT<T>::EPC;
-    extern __shared__ float sm[];   // ws[K][C] then dwred[K][C]
+    extern __shared__ float sm[];   // ws[K][C] then dwred[K][C + 1]
     float* ws = sm;
     float* dwred = sm + K * C;
     for (int i = threadIdx.x; i < K * C; i += 256) { ws[i] = w[i]; dwred[i] = 0.f; }
+    if (threadIdx.x < K) dwred[K * C + threadIdx.x] = 0.f;
     __syncthreads();
     const int lp = threadIdx.x % LPP;
     const int ppb = 256 / LPP;
@@ -664,12 +665,42 @@ __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, c
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) atomicAdd(&dwred[k * C + ch * EPC + e], dwa[k][j][e]);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw + i, dwred[i]);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float s = wave_sum(dba[k]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(dbias + k, s);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&dwred[K * C + k], s);
+    }
+    __syncthreads();
+    if (part) {
+        // per-block partials, summed by aag_partial_reduce_kernel: 1024 blocks adding into the same few cache lines with global
+        // float atomics cost 50-100 us per launch (measured: 944 -> 513 us/step over the six launches without them)
+        float* my = part + (size_t)blockIdx.x * (K * C + K);
+        for (int i = threadIdx.x; i < K * C + K; i += 256) my[i] = dwred[i];
+    } else {
+        for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw + i, dwred[i]);
+        if (threadIdx.x < K) atomicAdd(dbias + threadIdx.x, dwred[K * C + threadIdx.x]);
+    }
+}
+
+// dw[i] += sum_b part[b][i] (i < nw), dbias[i - nw] += ... (nw <= i < n): 64 elements x 16 partial ranges per block
+__global__ __launch_bounds__(1024) void aag_partial_reduce_kernel(const float* __restrict__ part, int nb, int n, int nw, float* __restrict__ dw,
+                                                                  float* __restrict__ dbias) {
+    __shared__ float red[16][64];
+    const int il = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    const int per = (nb + 15) / 16, b0 = pr * per, b1 = min(nb, b0 + per);
+    float a = 0.f;
+    if (i < n) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) a += part[(size_t)b * n + i];
+    }
+    red[pr][il] = a;
+    __syncthreads();
+    if (pr == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][il];
+        if (i < nw) dw[i] += t; else dbias[i - nw] += t;
     }
 }
 
@@ -696,21 +727,29 @@ static int aag_fwd_launch(const void* x, const float* w, const float* bias, void
     OCTA_CHECK_LAUNCH("aag_fwd");
     return OCTA_OK;
 }
+static int64_t aag_bwd_blocks(int64_t npix, int ppb) {
+    int64_t nb = cdiv64(npix, (int64_t)ppb * 16);
+    if (nb > 1024) nb = 1024;
+    return nb < 1 ? 1 : nb;
+}
 template <typename T, int K>
 static int aag_bwd_launch(const void* x, const float* w, const float* y, const void* dmasked, const float* dy, void* dx, float* dw, float* dbias,
-                          int64_t npix, int HW, int C, int mode, hipStream_t st) {
+                          int64_t npix, int HW, int C, int mode, float* part, hipStream_t st) {
     int cpl;
     const int lpp = aag_lpp(C / DT<T>::EPC, cpl);
     const int ppb = 256 / lpp;
-    int64_t nb = cdiv64(npix, (int64_t)ppb * 16);
-    if (nb > 1024) nb = 1024;
-    if (nb < 1) nb = 1;
-    const size_t sh = (size_t)2 * K * C * sizeof(float);
-#define AAG_B(CPLV) aag_bwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, y, (const T*)dmasked, dy, (T*)dx, dw, dbias, npix, HW, C, lpp, mode)
+    const int64_t nb = aag_bwd_blocks(npix, ppb);
+    const size_t sh = (size_t)(2 * K * C + K) * sizeof(float);
+#define AAG_B(CPLV) aag_bwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, y, (const T*)dmasked, dy, (T*)dx, dw, dbias, npix, HW, C, lpp, mode, part)
     if (cpl <= 1) AAG_B(1); else if (cpl <= 2) AAG_B(2); else if (cpl <= 4) AAG_B(4);
     else OCTA_FAIL(OCTA_ERR_UNSUPPORTED, "octa_aag_bwd: C=%d too large", C);
 #undef AAG_B
     OCTA_CHECK_LAUNCH("aag_bwd");
+    if (part) {
+        const int n = K * C + K;
+        aag_partial_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(part, (int)nb, n, K * C, dw, dbias);
+        OCTA_CHECK_LAUNCH("aag_partial_reduce");
+    }
     return OCTA_OK;
 }
 
@@ -728,15 +767,16 @@ extern "C" int octa_aag_fwd(const void* x, const float* w, const float* bias, vo
     return AAG_K(4);
 #undef AAG_K
 }
+extern "C" size_t octa_aag_workspace_floats(int C, int K) { return (size_t)1024 * (size_t)(K * C + K); }
 extern "C" int octa_aag_bwd(const void* x, const float* w, const float* y, const void* dmasked, const float* dy, void* dx, float* dw,
-                            float* dbias, int64_t B, int HW, int C, int K, int dtype, int mode, octa_stream_t stream) {
+                            float* dbias, int64_t B, int HW, int C, int K, int dtype, int mode, float* part, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && dx && dw && dbias && (mode == 1 || (y && dmasked)), "octa_aag_bwd: null pointer");
     OCTA_REQUIRE(C % 8 == 0 && K >= 2 && K <= 4, "octa_aag_bwd: needs C %% 8 == 0 and 2 <= num_classes <= 4");
     OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_aag_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int64_t npix = B * HW;
-#define AAG_K(KV) (dtype == OCTA_F32 ? aag_bwd_launch<float, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, st) \
-                                     : aag_bwd_launch<bf16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, st))
+#define AAG_K(KV) (dtype == OCTA_F32 ? aag_bwd_launch<float, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st) \
+                                     : aag_bwd_launch<bf16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st))
     if (K == 2) return AAG_K(2);
     if (K == 3) return AAG_K(3);
     return AAG_K(4);

@@ -901,7 +901,8 @@ class AagFn(Function):
         if dw is None or db is None or dw.stride(0) != C or dw.stride(1) != 1:
             dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=x.device)
             db = torch.zeros((K,), dtype=torch.float32, device=x.device)
-        lib().octa_aag_bwd(_p(x), _p(w2), _p(y), _p(dmasked), _p(dy), _p(dx), _p(dw), _p(db), B, H * W, C, K, _dt(x), ctx.mode, _st())
+        part = torch.empty((int(lib().octa_aag_workspace_floats(C, K)),), dtype=torch.float32, device=x.device)
+        lib().octa_aag_bwd(_p(x), _p(w2), _p(y), _p(dmasked), _p(dy), _p(dx), _p(dw), _p(db), B, H * W, C, K, _dt(x), ctx.mode, _p(part), _st())
         return dx, _ret(wp, dw), _ret(bp, db), None
 
 
