@@ -116,9 +116,12 @@ int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, fl
  * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline
  * leg keys its per-kernel timings with it, so they line up with the rocprofv3 kernel names). */
 const char* octa_last_conv_kernel(void);
-/* out[c] += sum over rows of src[row*ld + off + c]  (bias gradients; fp32 accumulate). */
+/* out[c] += sum over rows of src[row*ld + off + c]  (bias gradients; fp32 accumulate).  workspace: optional,
+ * octa_colsum_workspace_floats(C) floats, uninitialised: per-block partials + a fold launch instead of
+ * thousands of blocks adding into the one or two cache lines of out[] with float atomics. */
+size_t octa_colsum_workspace_floats(int C);
 int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out,
-                octa_stream_t stream);
+                float* workspace, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / copy helpers (compose.py:125-130 pad, 141-147 cat+crop, 155,162,169 cat).

@@ -1502,7 +1502,7 @@ __global__ void colsum_kernel(const T* __restrict__ src, int64_t rows, int C, in
 // one atomic per channel and block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ src, int64_t rows, int cpr, int TX, int ld, int off,
-                                                         float* __restrict__ out, int rows_per_block) {
+                                                         float* __restrict__ out, int rows_per_block, float* __restrict__ part /* [gridDim.y][C] or null */) {
     constexpr int EPC = DT<T>::EPC;
     __shared__ float red[256 * EPC];
     const int cx = threadIdx.x % TX, ry = threadIdx.x / TX, RY = 256 / TX;
@@ -1526,10 +1526,32 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ s
         if (c >= cpr * EPC) continue;
         float a = 0.f;
         for (int yy = 0; yy < RY; ++yy) a += red[yy * TX * EPC + ch];
-        atomicAdd(out + c, a);
+        if (part) part[(size_t)blockIdx.y * (cpr * EPC) + c] = a;       // folded by colsum_fold_kernel (no atomic pile-up on out[])
+        else atomicAdd(out + c, a);
     }
 }
-extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out, octa_stream_t stream) {
+// out[c] += sum_b part[b][c]: 64 channels x 16 partial ranges per block
+__global__ __launch_bounds__(1024) void colsum_fold_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int il = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + il;
+    const int per = (nb + 15) / 16, b0 = pr * per, b1 = min(nb, b0 + per);
+    float a = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) a += part[(size_t)b * C + c];
+    }
+    red[pr][il] = a;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][il];
+        out[c] += t;
+    }
+}
+extern "C" size_t octa_colsum_workspace_floats(int C) { return (size_t)2048 * (size_t)((C + 7) / 8 * 8); }
+extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out, float* part, octa_stream_t stream) {
     OCTA_REQUIRE(src && out && rows > 0 && C > 0, "octa_colsum: bad arguments");
     OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_colsum: bad dtype");
     const int epc = dtype == OCTA_F32 ? 4 : 8;
@@ -1541,8 +1563,10 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
         int64_t rpb = cdiv64(rows, 2048);
         if (rpb < (int64_t)RY * 8) rpb = (int64_t)RY * 8;
         dim3 grid(cdiv(cpr, TX), (unsigned)cdiv64(rows, rpb));
-        if (dtype == OCTA_F32) colsum_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, rows, cpr, TX, ld, off, out, (int)rpb);
-        else colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb);
+        if (grid.y < 64) part = nullptr;                  // few blocks: plain atomics are cheaper than a second launch
+        if (dtype == OCTA_F32) colsum_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
+        else colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
+        if (part) colsum_fold_kernel<<<cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>(part, (int)grid.y, C, out);
         OCTA_CHECK_LAUNCH("colsum_vec");
         return OCTA_OK;
     }

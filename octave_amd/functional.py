@@ -425,7 +425,8 @@ def raw_colsum(t: Tensor, out: Optional[Tensor] = None) -> Tensor:
     B, C, H, W = t.shape
     if out is None:
         out = torch.zeros((C,), dtype=torch.float32, device=t.device)
-    lib().octa_colsum(_p(t), B * H * W, C, nhwc_ld(t), 0, _dt(t), _p(out), _st())
+    part = torch.empty((int(lib().octa_colsum_workspace_floats(C)),), dtype=torch.float32, device=t.device) if B * H * W >= (1 << 16) else None
+    lib().octa_colsum(_p(t), B * H * W, C, nhwc_ld(t), 0, _dt(t), _p(out), _p(part), _st())
     return out
 
 
