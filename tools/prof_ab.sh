@@ -1,4 +1,5 @@
 # kernel-time A/B (robust against host/box noise): rocprofv3 kernel trace of _ab_old/ and of the working tree
+# prepare once:  git worktree add -f _ab_old HEAD~0 && (cd _ab_old && bash octave_amd/csrc/build.sh); add _ab_old/ to .git/info/exclude
 set -e
 export TMPDIR=/tmp
 R=$PWD
