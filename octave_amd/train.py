@@ -284,17 +284,20 @@ class TrainStep:
         # is captured (a stale cache here would put ~180 redundant pack kernels into every replay)
         if self.adversarial:
             self._feed.rewind()
+        # "thread_local": RCCL's watchdog thread keeps polling the events of the warm-up all-reduces with hipEventQuery while this
+        # thread captures; under the default global mode that query is an error and the watchdog aborts the process
+        mode = "thread_local"
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode=mode):
             self._att = self._phase_segmentor(self._sx, self._sys, self._out)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
             self._phase_discriminator(self._att, self._sreal, self._out)
         g2b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2b, pool=g1.pool()):
+        with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=mode):
             self._phase_seg_update(dyn=self._dyn_dev[0])
         g3 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g3, pool=g1.pool()):
+        with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
             self._phase_finish(dyn=self._dyn_dev[1])
         self._graphs = (g1, g2, g2b, g3)
         return self
