@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--seg-only", action="store_true", help="BASELINE configs[1]: segmentor-only (WPCE+Dice)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="after capture: replay the hipGraphs, launch the same static step from Python, or time both and pick (default)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -224,6 +226,11 @@ def main():
     if not args.no_graph:
         step.capture(*batch)
         log("step captured into hipGraphs (2 eager warm-up steps)")
+        if args.launch == "auto":
+            step.autotune_launch(*batch)
+            log(f"launch path: {step.launch} (ms/step graph {step.launch_timing['graph'] * 1e3:.1f}, eager {step.launch_timing['eager'] * 1e3:.1f})")
+        else:
+            step.launch = args.launch
     for i in range(args.warmup):
         step(*batch)
         torch.cuda.synchronize()
@@ -263,7 +270,8 @@ def main():
                                     if not args.seg_only else "OctaScribbleNet segmentor-only step (WeightedPartialCE + Dice), ")
                        + f"batch {B}/GPU, {H}x{H}", "global_batch": world * B, "image": H, "parallelism": f"dp{world}",
                        "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)",
-                       "launch": "eager" if args.no_graph else "hipGraph replay (3 graphs around the 2 gradient all-reduces)"},
+                       "launch": "eager" if args.no_graph else ("hipGraph replay (4 graphs around the 2 gradient all-reduces)" if step.launch == "graph"
+                                                               else "eager launches of the captured static step (auto-tuned: faster than graph replay on this host)")},
             "final_loss_seg": round(loss, 5),
         }
         if not args.no_roofline:

@@ -190,6 +190,7 @@ class TrainStep:
         defer_bn_counters(True)
         self._graphs = None
         self._comm_stream = None
+        self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
 
     # ------------------------------------------------------------------ the three phases of a step
     # (split at the two gradient all-reduces so that the collectives stay OUTSIDE any captured graph)
@@ -246,6 +247,9 @@ class TrainStep:
         if self.adversarial and real_pyramid is None:
             raise ValueError("the adversarial step needs the real mask pyramid")
         if self._graphs is not None:
+            if self.launch == "eager":          # same step, same static buffers / staged random draws, launched kernel by kernel
+                self._load_static(x, ys, real_pyramid)
+                return self._eager_static()
             return self._replay(x, ys, real_pyramid)
         out: Dict[str, Tensor] = {}
         att = self._phase_segmentor(x, ys, out)
@@ -318,7 +322,7 @@ class TrainStep:
         self._phase_finish(dyn=self._dyn_dev[1])
         return out
 
-    def _replay(self, x, ys, real_pyramid):
+    def _load_static(self, x, ys, real_pyramid):
         if x is not self._sx:
             self._sx.copy_(x, non_blocking=True)
         if ys is not self._sys:
@@ -327,6 +331,33 @@ class TrainStep:
             for dst, src in zip(self._sreal, real_pyramid):
                 if dst is not src:
                     dst.copy_(src, non_blocking=True)
+
+    def autotune_launch(self, x, ys, real_pyramid=None, rounds: int = 3, steps: int = 4) -> str:
+        """Pick the faster launch path for THIS process on THIS host: hipGraph replay needs almost no host time but pays a few
+        microseconds of dependency handling per node and stalls when the box is busy; launching the ~1100 kernels from Python
+        costs the host ~35 ms/step, which is enough to keep an otherwise quiet GPU fed (measured 39.6 vs 40.5-56 ms/step on
+        one box, the opposite on another).  Both paths run the identical step on the same static buffers; `rounds` alternating
+        timings of `steps` real training steps each, the medians decide."""
+        import time
+        if self._graphs is None:
+            return self.launch
+        t = {"graph": [], "eager": []}
+        for _ in range(rounds):
+            for mode in ("graph", "eager"):
+                self.launch = mode
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self(x, ys, real_pyramid)
+                torch.cuda.synchronize()
+                t[mode].append((time.perf_counter() - t0) / steps)
+        med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
+        self.launch = "eager" if med["eager"] < med["graph"] else "graph"
+        self.launch_timing = med
+        return self.launch
+
+    def _replay(self, x, ys, real_pyramid):
+        self._load_static(x, ys, real_pyramid)
         if self.adversarial:
             self._feed.refill()
         g1, g2, g2b, g3 = self._graphs
