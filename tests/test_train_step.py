@@ -263,3 +263,32 @@ def test_train_step_hipgraph_back_to_back_replays_stay_finite():
         assert st.seg_arena.step_count == 2 + 24
     finally:
         st.close()
+
+
+def test_train_step_launch_paths_are_interchangeable():
+    """After capture() the step can be replayed as hipGraphs or launched kernel by kernel on the same static buffers
+    (TrainStep.launch / autotune_launch): both advance the same state (Adam step counters, BN counters, staged random draws)
+    and can be mixed freely."""
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    Bn, H = 4, 64
+    x, ys, real = _inputs(Bn, H, dev)
+    pyr = mask_pyramid(real)
+    torch.manual_seed(0)
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False).to(dev).train()
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.bfloat16)
+    try:
+        st.capture(x, ys, pyr)
+        n0 = st.seg_arena.step_count
+        assert st.autotune_launch(x, ys, pyr, rounds=1, steps=1) in ("graph", "eager")
+        assert st.seg_arena.step_count == n0 + 2
+        for mode in ("eager", "graph", "eager", "graph"):
+            st.launch = mode
+            out = {k: v.clone() for k, v in st(x, ys, pyr).items()}
+            torch.cuda.synchronize()
+            assert all(np.isfinite(v.item()) for v in out.values()), (mode, out)
+        assert st.seg_arena.step_count == n0 + 6 and st.disc_arena.step_count == n0 + 6
+        assert int(dict(net.named_buffers())["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == n0 + 6
+    finally:
+        st.close()
