@@ -246,20 +246,26 @@ class TrainStep:
     def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
         if self.adversarial and real_pyramid is None:
             raise ValueError("the adversarial step needs the real mask pyramid")
-        if self._graphs is not None:
-            if self.launch == "eager":          # same step, same static buffers / staged random draws, launched kernel by kernel
-                self._load_static(x, ys, real_pyramid)
-                return self._eager_static()
+        if self._graphs is not None and self.launch == "graph":
             return self._replay(x, ys, real_pyramid)
+        # launch == "eager" (or nothing captured): the step launched kernel by kernel from Python.  Same arenas, step counters
+        # and global CPU generator as the replayed path, so the two can be mixed freely.
         out: Dict[str, Tensor] = {}
-        att = self._phase_segmentor(x, ys, out)
-        self.seg_arena.all_reduce_begin(self.world, self._comm())      # 286 MB over xGMI, hidden behind the D step
-        self._phase_discriminator(att, real_pyramid, out)
-        self.seg_arena.all_reduce_end(self.world, self._comm())
-        self._phase_seg_update()
-        if self.adversarial:
-            self.disc_arena.all_reduce(self.world)
-        self._phase_finish()
+        feed = getattr(self.disc, "rng_feed", None) if self.disc is not None else None
+        if feed is not None:
+            self.disc.rng_feed = None          # captured earlier: this path draws the discriminator's noise inline, like the reference
+        try:
+            att = self._phase_segmentor(x, ys, out)
+            self.seg_arena.all_reduce_begin(self.world, self._comm())      # 286 MB over xGMI, hidden behind the D step
+            self._phase_discriminator(att, real_pyramid, out)
+            self.seg_arena.all_reduce_end(self.world, self._comm())
+            self._phase_seg_update()
+            if self.adversarial:
+                self.disc_arena.all_reduce(self.world)
+            self._phase_finish()
+        finally:
+            if feed is not None:
+                self.disc.rng_feed = feed
         return out
 
     # ------------------------------------------------------------------ hipGraph capture / replay
@@ -335,9 +341,9 @@ class TrainStep:
     def autotune_launch(self, x, ys, real_pyramid=None, rounds: int = 3, steps: int = 4) -> str:
         """Pick the faster launch path for THIS process on THIS host: hipGraph replay needs almost no host time but pays a few
         microseconds of dependency handling per node and stalls when the box is busy; launching the ~1100 kernels from Python
-        costs the host ~35 ms/step, which is enough to keep an otherwise quiet GPU fed (measured 39.6 vs 40.5-56 ms/step on
-        one box, the opposite on another).  Both paths run the identical step on the same static buffers; `rounds` alternating
-        timings of `steps` real training steps each, the medians decide."""
+        costs the host ~35 ms/step, which is enough to keep an otherwise quiet GPU fed (measured a steady 39.7 ms/step eager
+        against 39.6-66 ms/step replayed across boxes; with a slower or shared host core the order flips).  Both paths run the
+        identical step on the same arenas; `rounds` alternating timings of `steps` real training steps each, the medians decide."""
         import time
         if self._graphs is None:
             return self.launch

@@ -285,9 +285,12 @@ def test_train_step_launch_paths_are_interchangeable():
         assert st.seg_arena.step_count == n0 + 2
         for mode in ("eager", "graph", "eager", "graph"):
             st.launch = mode
+            rng_before = torch.get_rng_state().clone()
             out = {k: v.clone() for k, v in st(x, ys, pyr).items()}
             torch.cuda.synchronize()
             assert all(np.isfinite(v.item()) for v in out.values()), (mode, out)
+            # every step draws fresh discriminator noise from the global CPU generator, whichever path launches it
+            assert not torch.equal(rng_before, torch.get_rng_state()), mode
         assert st.seg_arena.step_count == n0 + 6 and st.disc_arena.step_count == n0 + 6
         assert int(dict(net.named_buffers())["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == n0 + 6
     finally:
