@@ -129,11 +129,25 @@ class _Lib:
             raise OctaError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
 
     def __getattr__(self, name):
+        # first use of an entry point: build its checked wrapper once and cache it on the instance (later lookups never get here;
+        # the step makes ~1100 of these calls, so the wrapper is as thin as it can be)
         if name.startswith("octa_"):
             fn = getattr(self._dll, name)
             if self.signatures[name][0] is ctypes.c_int and name != "octa_version":
-                return lambda *a, _n=name: self.call(_n, *a)
-            return fn
+                if PROFILE is not None:
+                    wrapper = lambda *a, _n=name: self.call(_n, *a)
+                else:
+                    err = self._dll.octa_last_error
+
+                    def wrapper(*a, _fn=fn, _n=name):
+                        rc = _fn(*a)
+                        if rc != 0:
+                            msg = err()
+                            raise OctaError(f"{_n} failed ({rc}): {msg.decode() if msg else '?'}")
+            else:
+                wrapper = fn
+            self.__dict__[name] = wrapper
+            return wrapper
         raise AttributeError(name)
 
 
