@@ -13,7 +13,7 @@ python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline >> $OUT/b
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline >> $OUT/bench_repeat.json 2>> $OUT/bench.log
 grep -o 'ms_per_step": [0-9.]*' $OUT/bench.json $OUT/bench_repeat.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py --steps 5 --warmup 2 --launch graph --no-cpu-baseline --no-roofline > $OUT/stats.log 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/fetch.log 2>&1
 echo "fetch pass done"
