@@ -194,6 +194,21 @@ def main():
     args = ap.parse_args()
 
     t_begin = time.perf_counter()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched without torchrun: start the N ranks ourselves as a CHILD process (never exec: nothing here has touched the
+        # GPU yet, device_count() does not initialise it) and relay its JSON line and exit code.  No fallback to fewer ranks.
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible; refusing to report a smaller run as n_gpus={args.gpus}")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -206,7 +221,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the number of ranks must equal --gpus")
 
     from architectures.models.octa import OctaScribbleNet
     from octave_amd.train import TrainStep, mask_pyramid

@@ -33,7 +33,7 @@ extern "C" {
 typedef void* octa_stream_t; /* hipStream_t */
 
 enum octa_status { OCTA_OK = 0, OCTA_ERR_BAD_ARG = -1, OCTA_ERR_UNSUPPORTED = -2, OCTA_ERR_LAUNCH = -3 };
-enum octa_dtype { OCTA_F32 = 0, OCTA_BF16 = 1 };
+enum octa_dtype { OCTA_F32 = 0, OCTA_BF16 = 1, OCTA_F16 = 2 };
 enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA_ACT_SIGMOID = 3, OCTA_ACT_TANH = 4 };
 
 int octa_version(void);
@@ -111,6 +111,22 @@ int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const void* dy, fl
                       const int64_t* dw_strides /* o,i,h,w element strides of dw */,
                       float* dbias /* optional: dbias[Cout] += sum_pixels dy (fused bias gradient) */,
                       octa_stream_t stream);
+/* MANY weight gradients in one launch.  The weight gradients of a backward pass are consumed only by the
+ * optimiser, so the host queues them (per network stage) and hands the queue over here: every bf16 / f16 job
+ * with >= 128 output channels per group runs on the batched 8-wave kernel (wgrad8.hip: 256x128 / 128x256 output
+ * slabs, LDS-DMA ring), whose M-split is chosen over ALL its jobs; the rest falls through to octa_conv2d_wgrad,
+ * job by job.  `jobs_host` is a HOST array, read before the call returns (the descriptors travel as kernel
+ * arguments); the device buffers it names must stay valid until the stream has run the launch.
+ * Same += semantics as octa_conv2d_wgrad (extra/resnest.py:24,33,83,181,222; discriminator/blocks.py:46,97). */
+typedef struct octa_wgrad_job {
+    octa_conv_desc d;
+    const void* x;
+    const void* dy;
+    float* dw;
+    float* dbias;            /* optional */
+    int64_t dw_strides[4];   /* o,i,h,w element strides of dw */
+} octa_wgrad_job;
+int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, octa_stream_t stream);
 /* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
  * call dispatched, e.g. "conv_igemm_kernel<bf16,128x128>", "conv3x3_halo_kernel<bf16,128x64>",
  * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline

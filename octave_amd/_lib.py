@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "octa_hip.h")
 LIB_PATH = os.environ.get("OCTA_HIP_LIB", os.path.join(_HERE, "libocta_hip.so"))
 
-OCTA_F32, OCTA_BF16 = 0, 1
+OCTA_F32, OCTA_BF16, OCTA_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 
 
@@ -21,6 +21,12 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "H", "W", "OH", "OW", "Cin", "Cout", "KH", "KW", "stride", "pad", "groups",
         "cin_g_pad", "cout_g_pad", "ldx", "xoff", "ldy", "yoff", "dtype", "act", "upshuffle")]
+
+
+class WgradJob(ctypes.Structure):
+    """octa_wgrad_job: one entry of the batched weight-gradient queue (octa_conv2d_wgrad_batch)."""
+    _fields_ = [("d", ConvDesc), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("dw_strides", ctypes.c_int64 * 4)]
 
 
 class PackDesc(ctypes.Structure):

@@ -1,0 +1,432 @@
+// Batched weight-gradient engine (gfx950, bf16/f16): dW[n][k] += sum_m dy[m][n] * im2col(x)[m][k] for MANY layers per launch.
+//
+// Why batched: the weight gradients are off the critical path of the backward pass (nothing downstream reads them
+// before the optimiser), so the host queues them per stage and flushes the queue as ONE launch.  A launch then holds
+// hundreds of output tiles, the split over the pixel axis (and with it the fp32 reduction traffic) shrinks by the
+// number of layers batched, and ~60 launches per step disappear.
+//
+// Kernel shape (one workgroup = 512 threads = 8 waves, one workgroup per CU):
+//   output slab 256(N) x 128(K) or 128(N) x 256(K), every wave owns a 64 x 64 sub-tile (16 MFMA 16x16x32 accumulators);
+//   the contraction index is the PIXEL: 64 pixel rows per stage, 3-stage LDS ring (3 x 48 KB) filled by LDS-DMA
+//   (global_load_lds_dwordx4, 6 wave-instructions per wave and stage) with ONE raw s_barrier per stage and a counted
+//   vmcnt that keeps the next stage in flight across it; no register staging, no ds_write.
+//   Both operands have the contraction index as their slow memory axis, so the MFMA fragments are read transposed with
+//   ds_read_b64_tr_b16.  LDS rows are 256/512 B; the 32-byte pair index of a row is XOR-ed with
+//   f(m) = (m & 3) | ((m >> 3) & 1) << 2, which makes the 32-lane halves of a transposed read hit 8 distinct 32-byte
+//   slots (conflict-free); the LDS-DMA image is lane-linear, so the same involution is applied to the per-lane SOURCE chunk.
+//   Out-of-image taps, the M tail and channel padding are sourced from a 16-byte zero page.
+#include "common.hpp"
+#include <vector>
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 wg_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
+
+__device__ __attribute__((aligned(16))) unsigned int wg8_zero_page[4] = {0u, 0u, 0u, 0u};
+
+struct WgProb {
+    const unsigned short* x; const unsigned short* dy; float* dw; float* dbias;
+    int H, W, OH, OW;
+    int Cg, CgReal, Ng;
+    int KH, KW, stride, pad;
+    int ldx, xoff, ldy, yoff;
+    int M, Kpad;
+    int s_o, s_i, s_h, s_w;
+    unsigned magicOW, magicOH;      // floor(2^32 / d) + 1: exact quotient for n * d < 2^32
+    int tilesN, tilesK, groups, splitM, mPerSplit;
+    int blockStart;
+};
+#define WG_MAXP 20
+struct WgBatch { WgProb p[WG_MAXP]; int n; };
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_base /* wave-uniform */) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned wg_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) void*)p; }
+
+// transposed 8-byte LDS read with an immediate row offset (inline asm: hipcc does not fold integer LDS address arithmetic into
+// the offset field and spent 2 VALU per read on it).  Not counted by hipcc: the caller waits with wg_wait_frags.
+typedef __attribute__((ext_vector_type(2))) unsigned wg_u32x2_t;
+template <int OFF> __device__ __forceinline__ wg_u32x2_t wg_tr(unsigned addr) {
+    wg_u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int PRB, int QRB, int HS>
+__device__ __forceinline__ void wg_load_half(const unsigned (&pa)[4], const unsigned (&qa)[4], wg_u32x2_t (&pf)[4][2], wg_u32x2_t (&qf)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pf[i][0] = wg_tr<HS * 32 * PRB>(pa[i]); pf[i][1] = wg_tr<HS * 32 * PRB + 4 * PRB>(pa[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qf[i][0] = wg_tr<HS * 32 * QRB>(qa[i]); qf[i][1] = wg_tr<HS * 32 * QRB + 4 * QRB>(qa[i]); }
+}
+// wait for every outstanding LDS read; naming the 16 destinations pins the wait between the reads and their consumers
+__device__ __forceinline__ void wg_wait_frags(wg_u32x2_t (&pf)[4][2], wg_u32x2_t (&qf)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]), "+v"(pf[2][0]), "+v"(pf[2][1]), "+v"(pf[3][0]), "+v"(pf[3][1]),
+                   "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[2][0]), "+v"(qf[2][1]), "+v"(qf[3][0]), "+v"(qf[3][1])
+                 :: "memory");
+}
+
+template <int F16> struct WgMma;
+template <> struct WgMma<0> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, wg_f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8_t, a), __builtin_bit_cast(wg_bf16x8_t, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ float cvt(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+};
+template <> struct WgMma<1> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, wg_f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wg_f16x8_t, a), __builtin_bit_cast(wg_f16x8_t, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ float cvt(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+};
+
+template <int WN, int WK, int F16, int STAGGER>
+__global__ __launch_bounds__(512) void wgrad8_kernel(const WgBatch batch) {
+    constexpr int BN = WN * 64, BK = WK * 64, MT = 64, STAGES = 3;
+    constexpr int PRB = BN * 2, QRB = BK * 2;                      // LDS row bytes of the dy / x stage images
+    constexpr int PBYTES = MT * PRB, QBYTES = MT * QRB, SBYTES = PBYTES + QBYTES;
+    constexpr int P_LPR = PRB / 16, P_RPI = 64 / P_LPR, P_IPW = MT / P_RPI / 8;   // lanes per row, rows per DMA instruction, instr per wave
+    constexpr int Q_LPR = QRB / 16, Q_RPI = 64 / Q_LPR, Q_IPW = MT / Q_RPI / 8;
+    constexpr int LPT = P_IPW + Q_IPW;                             // DMA instructions per wave and stage (6)
+    static_assert(WN * WK == 8 && LPT == 6, "8 waves of 64x64");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SBYTES + BN * 4];
+    float* const sBias = (float*)(smem + STAGES * SBYTES);
+
+    // ---- which problem / tile is this workgroup (XCD-contiguous order over the whole launch)
+    const int total = gridDim.x, Lb = blockIdx.x;
+    const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
+    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jq;
+    int pi = 0;
+    for (int i = 1; i < batch.n; ++i) if (batch.p[i].blockStart <= Lp) pi = i;
+    // every field the loop needs is copied to registers once (the kernel-argument struct is not re-read in the loop)
+    const WgProb& Pk = batch.p[pi];
+    const int tilesN = Pk.tilesN, tilesK = Pk.tilesK, groups = Pk.groups, mPerSplit = Pk.mPerSplit, Mtot = Pk.M;
+    const int Ng = Pk.Ng, Kpad = Pk.Kpad, Cg = Pk.Cg, CgReal = Pk.CgReal, KW = Pk.KW;
+    const int H = Pk.H, W = Pk.W, OH = Pk.OH, OW = Pk.OW, stride = Pk.stride, pad = Pk.pad;
+    const int ldx = Pk.ldx, ldy = Pk.ldy;
+    const unsigned magicOW = Pk.magicOW, magicOH = Pk.magicOH;
+    const unsigned short* const xbase = Pk.x;
+    const unsigned short* const dybase = Pk.dy;
+    int bid = Lp - Pk.blockStart;
+    const int nt = bid % tilesN; bid /= tilesN;
+    const int kt = bid % tilesK; bid /= tilesK;
+    const int g = bid % groups;
+    const int sp = bid / groups;
+    const int n0 = nt * BN, k0 = kt * BK;
+    const int mbeg = sp * mPerSplit;
+    const int mend = min(Mtot, mbeg + mPerSplit);
+    const int nsteps = (mend - mbeg + MT - 1) / MT;
+    if (nsteps <= 0) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
+
+    // ---- DMA roles.  Instruction i of this wave fills LDS rows (i*8 + wave)*RPI + lane/LPR: rows of one lane differ by a
+    // multiple of 16, so f(row) -- and with it the data chunk this lane fetches -- is the same for all of them.
+    // VALU budget: this loop is VALU-issue bound (two waves share a SIMD's vector pipe with their own MFMA issue), so the
+    // per-row address work is kept to 32-bit full-rate instructions: dy rows are one 64-bit add per stage (invalid lanes
+    // point at the zero page with a zero step), x rows track (ih, iw, input pixel) incrementally with single-wrap updates.
+    const int prow = wave * P_RPI + lane / P_LPR;
+    const int ppos = lane % P_LPR;
+    const int pf_ = (prow & 3) | (((prow >> 3) & 1) << 2);
+    const int pchunk = (((ppos >> 1) ^ pf_) << 1) | (ppos & 1);
+    const bool pvalid = (n0 + pchunk * 8) < Ng;
+    const unsigned long pstep = pvalid ? (unsigned long)((long)MT * ldy * 2) : 0ul;
+    unsigned long pptr[P_IPW];
+#pragma unroll
+    for (int i = 0; i < P_IPW; ++i)
+        pptr[i] = pvalid ? (unsigned long)(dybase + ((long)(mbeg + prow + i * 8 * P_RPI) * ldy + Pk.yoff + g * Ng + n0 + pchunk * 8)) : zaddr;
+
+    const int qrow = wave * Q_RPI + lane / Q_LPR;
+    const int qpos = lane % Q_LPR;
+    const int qf_ = (qrow & 3) | (((qrow >> 3) & 1) << 2);
+    const int qchunk = (((qpos >> 1) ^ qf_) << 1) | (qpos & 1);
+    const int kel = k0 + qchunk * 8;
+    const bool kvalid = kel < Kpad;
+    const int qtap = kel / Cg, qcc = kel - qtap * Cg;
+    const int qkh = qtap / KW, qkw = qtap - qkh * KW;
+    const int qdh = qkh - pad, qdw = qkw - pad;
+    // byte address of channel chunk qcc of input pixel 0 for this lane's group
+    const unsigned long qbase = (unsigned long)(xbase + (Pk.xoff + g * CgReal + qcc));
+    const bool plain = (Pk.KH == 1 && KW == 1 && pad == 0 && stride == 1);   // 1x1: input pixel == output pixel
+    const int ldx2 = ldx * 2;
+    // incremental pixel state of the Q_IPW rows this lane fetches (general path)
+    const int dq = MT / OW, dr = MT - dq * OW;               // a stage advances the output pixel by dq rows + dr columns
+    const int sdr = stride * dr, sdq = stride * dq, OWs = OW * stride, OHs = OH * stride;
+    const int thrW = OWs + qdw, thrH = OHs + qdh;
+    const int dpix = sdq * W + sdr, cW = stride * W - OWs, cH = H * W - OHs * W;
+    int qih[Q_IPW], qiw[Q_IPW], qpix[Q_IPW];
+#pragma unroll
+    for (int i = 0; i < Q_IPW; ++i) {
+        const int m = mbeg + qrow + i * 8 * Q_RPI;
+        const int ow = m % OW, tq = m / OW, oh = tq % OH, b = tq / OH;
+        qih[i] = oh * stride + qdh; qiw[i] = ow * stride + qdw;
+        qpix[i] = plain ? m : (b * H + qih[i]) * W + qiw[i];
+    }
+
+    const unsigned sbase = wg_lds_addr(smem);
+    auto issue = [&](int stage, int mcur) {
+        const unsigned pb = sbase + (unsigned)(stage * SBYTES), qb = pb + PBYTES;
+        const bool full = (mcur + MT) <= mend;      // uniform: no per-row tail test on full stages
+#pragma unroll
+        for (int i = 0; i < P_IPW; ++i) {
+            unsigned long src = pptr[i];
+            if (!full) src = ((mcur + prow + i * 8 * P_RPI) < mend) ? src : zaddr;
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(pb + (unsigned)((i * 8 + wave) * 1024)));
+            pptr[i] += pstep;
+        }
+#pragma unroll
+        for (int i = 0; i < Q_IPW; ++i) {
+            bool ok = kvalid;
+            if (!full) ok = ok & ((mcur + qrow + i * 8 * Q_RPI) < mend);
+            if (!plain) ok = ok & ((unsigned)qih[i] < (unsigned)H) & ((unsigned)qiw[i] < (unsigned)W);
+            const unsigned off = (unsigned)__mul24(qpix[i], ldx2);          // pixel index < 2^23, ldx2 < 2^17: exact in 24 x 24 bits
+            const unsigned long a = qbase + (unsigned long)off;
+            const unsigned long src = ok ? a : zaddr;
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(qb + (unsigned)((i * 8 + wave) * 1024)));
+            if (plain) qpix[i] += MT;
+            else {
+                qiw[i] += sdr;
+                const bool c1 = qiw[i] >= thrW;
+                qiw[i] -= c1 ? OWs : 0;
+                qih[i] += sdq + (c1 ? stride : 0);
+                const bool c2 = qih[i] >= thrH;
+                qih[i] -= c2 ? OHs : 0;
+                qpix[i] += dpix + (c1 ? cW : 0) + (c2 ? cH : 0);
+            }
+        }
+    };
+
+    wg_f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (wg_f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- transposed fragment addressing: lane (r, q) reads 8 bytes at rows mrow and mrow + 4, f is a lane constant.
+    // LDS byte addresses of stage 0 are kept in 8 registers; a stage adds one scalar, rows are immediate offsets.
+    const int mrow = 8 * q + (r >> 2);
+    const int fr = (mrow & 3) | (((mrow >> 3) & 1) << 2);
+    const int cb = (r & 3) * 8;                  // byte inside the 32-byte pair
+    unsigned pad0[4], qad0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pad0[i] = sbase + (unsigned)(mrow * PRB + ((((wn * 4 + i)) ^ fr) << 5) + cb);
+        qad0[i] = sbase + (unsigned)(PBYTES + mrow * QRB + ((((wk * 4 + i)) ^ fr) << 5) + cb);
+    }
+
+    // ---- fused bias gradient (k-tile 0 only): thread = (chunk position, 4 or 2 rows with equal f) of the dy stage image
+    float* const dbias = Pk.dbias;
+    const bool do_bias = (dbias != nullptr) && (kt == 0);
+    constexpr int B_RG = 512 / P_LPR, B_NJ = MT / B_RG;
+    const int brow = t / P_LPR, bpos = t % P_LPR;
+    const int bf_ = (brow & 3) | (((brow >> 3) & 1) << 2);
+    const int bchunk = (((bpos >> 1) ^ bf_) << 1) | (bpos & 1);
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    if (do_bias && t < BN) sBias[t] = 0.f;
+
+    static_assert(STAGES == 3, "ring depth");
+    const bool late = (wave >= 4) && (STAGGER != 0);
+    issue(0, mbeg);
+    if (nsteps > 1) issue(1, mbeg + MT);
+    for (int it = 0; it < nsteps; ++it) {
+        if (it + 1 < nsteps) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every ds_read of the previous stage has returned (WAR on the ring)
+        __builtin_amdgcn_s_barrier();
+        // the two waves of a SIMD (w and w + 4) take turns: waves 0-3 issue the next DMA stage (address VALU + 6 LDS-DMA) and
+        // then run their MFMAs, waves 4-7 run their MFMAs first and issue afterwards, so one of the pair feeds the matrix pipe
+        // while the other one feeds the memory pipe
+        if (!late && it + 2 < nsteps) issue((it + 2) % STAGES, mbeg + (it + 2) * MT);
+        const unsigned char* sP = smem + (it % STAGES) * SBYTES;
+        const unsigned char* sQ = sP + PBYTES;
+        if (do_bias) {
+#pragma unroll
+            for (int jj = 0; jj < B_NJ; ++jj) {
+                const uint4 v = *(const uint4*)(sP + (brow + jj * B_RG) * PRB + bpos * 16);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += WgMma<F16>::cvt((unsigned short)(w4[e] & 0xffffu));
+                    bsum[2 * e + 1] += WgMma<F16>::cvt((unsigned short)(w4[e] >> 16));
+                }
+            }
+        }
+        const unsigned so = (unsigned)((it % STAGES) * SBYTES);
+        unsigned pa[4], qa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pa[i] = pad0[i] + so; qa[i] = qad0[i] + so; }
+        {
+            wg_u32x2_t pf0[4][2], qf0[4][2], pf1[4][2], qf1[4][2];
+            wg_load_half<PRB, QRB, 0>(pa, qa, pf0, qf0);
+            wg_wait_frags(pf0, qf0);
+            wg_load_half<PRB, QRB, 1>(pa, qa, pf1, qf1);          // in flight under the first 16 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    WgMma<F16>::run(make_uint4(pf0[i][0].x, pf0[i][0].y, pf0[i][1].x, pf0[i][1].y),
+                                    make_uint4(qf0[j][0].x, qf0[j][0].y, qf0[j][1].x, qf0[j][1].y), acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            wg_wait_frags(pf1, qf1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    WgMma<F16>::run(make_uint4(pf1[i][0].x, pf1[i][0].y, pf1[i][1].x, pf1[i][1].y),
+                                    make_uint4(qf1[j][0].x, qf1[j][0].y, qf1[j][1].x, qf1[j][1].y), acc[i][j]);
+        }
+        if (late && it + 2 < nsteps) issue((it + 2) % STAGES, mbeg + (it + 2) * MT);
+    }
+
+    if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
+        __syncthreads();
+        if (t < BN && n0 + t < Ng) atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+    }
+    // ---- epilogue: D[row = n (4q + e)][col = k (r)], fp32 atomics into the (channels-last) gradient tensor
+    float* const dw = Pk.dw;
+    const long s_o = Pk.s_o, s_i = Pk.s_i, s_h = Pk.s_h, s_w = Pk.s_w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + (wk * 4 + j) * 16 + r;
+        if (k >= Kpad) continue;
+        const int tap = k / Cg, ci = k - tap * Cg;
+        if (ci >= CgReal) continue;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const long koff = (long)ci * s_i + (long)kh * s_h + (long)kw * s_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + (wn * 4 + i) * 16 + q * 4 + e;
+                if (n < Ng) atomicAdd(dw + (long)(g * Ng + n) * s_o + koff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static unsigned wg_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
+// can the batched kernel take this job?  (everything else goes to the single-problem kernels of conv.hip)
+static bool wg8_eligible(const octa_wgrad_job& j) {
+    const octa_conv_desc& d = j.d;
+    if (d.dtype != OCTA_BF16 && d.dtype != OCTA_F16) return false;
+    if (d.upshuffle || !j.x || !j.dy || !j.dw) return false;
+    const int Ng = d.Cout / d.groups;
+    if (Ng < 128) return false;                              // tall-skinny problems stay on the slab kernels
+    if (d.OW < 2 || d.OH < 2 || d.OW > 511 || d.OH > 511 || 64 / d.OW + 1 > d.OH) return false;   // single-wrap pixel updates
+    if ((int64_t)d.B * d.H * d.W >= (1 << 23) || d.ldx * 2 >= (1 << 23)) return false;              // 24-bit multiply operands
+    const int64_t M = (int64_t)d.B * d.OH * d.OW;
+    if (M >= (1 << 23) || M < 64) return false;
+    if ((int64_t)d.B * d.H * d.W * d.ldx >= (1ll << 31) || M * d.ldy >= (1ll << 31)) return false;
+    for (int i = 0; i < 4; ++i) if (j.dw_strides[i] >= (1ll << 31) || j.dw_strides[i] < 0) return false;
+    if ((int64_t)d.Cout * j.dw_strides[0] >= (1ll << 31)) return false;
+    if (d.ldy % 8 || d.yoff % 8 || d.ldx % 8 || d.xoff % 8) return false;
+    if (d.groups > 1 && (Ng % 8 || (d.Cin / d.groups) % 8)) return false;
+    return true;
+}
+
+struct WgPlan { WgProb p; int64_t steps; int variant; };
+
+template <int F16>
+static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
+    // steps per workgroup: as few splits as still give every CU ~3 workgroups, never fewer than 8 stages of 64 pixels each
+    size_t i0 = 0;
+    while (i0 < plans.size()) {
+        const size_t i1 = std::min(plans.size(), i0 + (size_t)WG_MAXP);
+        int64_t tiles = 0, maxsteps = 1;
+        for (size_t i = i0; i < i1; ++i) { tiles += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups; maxsteps = std::max(maxsteps, plans[i].steps); }
+        // steps per workgroup S: minimise  rounds(S) * (S + E)  with rounds = ceil(workgroups / 256 CUs) (one workgroup per CU) and
+        // E ~ the prologue + atomic epilogue of a workgroup in units of a 64-pixel stage
+        static const int E = getenv("OCTA_WG8_EPI") ? atoi(getenv("OCTA_WG8_EPI")) : 6;
+        static const int minsteps = getenv("OCTA_WG8_MINSTEPS") ? atoi(getenv("OCTA_WG8_MINSTEPS")) : 4;
+        auto blocks_at = [&](int64_t s) { int64_t b = 0; for (size_t i = i0; i < i1; ++i) b += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups * ((plans[i].steps + s - 1) / s); return b; };
+        int64_t S = maxsteps, best = -1;
+        for (int64_t s = maxsteps; s >= minsteps; s = (s > 64 ? s - s / 32 : s - 1)) {
+            const int64_t rounds = (blocks_at(s) + 255) / 256;
+            const int64_t cost = rounds * (s + E);
+            if (best < 0 || cost < best) { best = cost; S = s; }
+        }
+        (void)tiles;
+        // long workgroups first: the tail of the launch is then made of short ones
+        std::stable_sort(plans.begin() + i0, plans.begin() + i1, [&](const WgPlan& a, const WgPlan& b) { return std::min(a.steps, S) > std::min(b.steps, S); });
+        WgBatch batch;
+        batch.n = (int)(i1 - i0);
+        int64_t nblk = 0;
+        for (size_t i = i0; i < i1; ++i) {
+            WgProb& p = plans[i].p;
+            const int64_t split = (plans[i].steps + S - 1) / S;
+            const int64_t sps = (plans[i].steps + split - 1) / split;      // balanced stages per split
+            p.mPerSplit = (int)(sps * 64);
+            p.splitM = (int)((p.M + p.mPerSplit - 1) / p.mPerSplit);
+            p.blockStart = (int)nblk;
+            nblk += (int64_t)p.tilesN * p.tilesK * p.groups * p.splitM;
+            batch.p[i - i0] = p;
+        }
+        if (nblk <= 0 || nblk >= (1ll << 30)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_conv2d_wgrad_batch: bad grid %lld", (long long)nblk);
+        static const bool stagger = getenv("OCTA_WG8_NOSTAGGER") == nullptr;
+        if (stagger) {
+            if (variant == 0) wgrad8_kernel<4, 2, F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
+            else wgrad8_kernel<2, 4, F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        } else {
+            if (variant == 0) wgrad8_kernel<4, 2, F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
+            else wgrad8_kernel<2, 4, F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        }
+        OCTA_CHECK_LAUNCH("wgrad8");
+        i0 = i1;
+    }
+    return OCTA_OK;
+}
+
+extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_stream_t stream) {
+    OCTA_REQUIRE(jobs != nullptr && n >= 0, "octa_conv2d_wgrad_batch: bad arguments");
+    static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<WgPlan> plans[2][2];   // [f16][variant]
+    for (int i = 0; i < n; ++i) {
+        const octa_wgrad_job& j = jobs[i];
+        if (off || !wg8_eligible(j)) {
+            const int rc = octa_conv2d_wgrad(&j.d, j.x, j.dy, j.dw, j.dw_strides, j.dbias, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const octa_conv_desc& d = j.d;
+        WgPlan pl;
+        WgProb& p = pl.p;
+        p.x = (const unsigned short*)j.x; p.dy = (const unsigned short*)j.dy; p.dw = j.dw; p.dbias = j.dbias;
+        p.H = d.H; p.W = d.W; p.OH = d.OH; p.OW = d.OW;
+        p.Cg = d.cin_g_pad; p.CgReal = d.Cin / d.groups; p.Ng = d.Cout / d.groups;
+        p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
+        p.ldx = d.ldx; p.xoff = d.xoff; p.ldy = d.ldy; p.yoff = d.yoff;
+        p.M = d.B * d.OH * d.OW; p.Kpad = d.KH * d.KW * p.Cg;
+        p.s_o = (int)j.dw_strides[0]; p.s_i = (int)j.dw_strides[1]; p.s_h = (int)j.dw_strides[2]; p.s_w = (int)j.dw_strides[3];
+        p.magicOW = wg_magic(d.OW); p.magicOH = wg_magic(d.OH);
+        p.groups = d.groups;
+        // slab orientation: the one that wastes less padded MFMA work; ties go to 256(N) x 128(K)
+        const int64_t w0 = (int64_t)cdiv(p.Ng, 256) * 256 * cdiv(p.Kpad, 128) * 128, w1 = (int64_t)cdiv(p.Ng, 128) * 128 * cdiv(p.Kpad, 256) * 256;
+        pl.variant = (w1 < w0) ? 1 : 0;
+        p.tilesN = cdiv(p.Ng, pl.variant ? 128 : 256);
+        p.tilesK = cdiv(p.Kpad, pl.variant ? 256 : 128);
+        pl.steps = (p.M + 63) / 64;
+        p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0;
+        plans[d.dtype == OCTA_F16 ? 1 : 0][pl.variant].push_back(pl);
+    }
+    for (int v = 0; v < 2; ++v) {
+        if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
+        if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }
+    }
+    return OCTA_OK;
+}
