@@ -78,37 +78,40 @@ class ResnestUNet(nn.Module):
         dtype = self.compute_dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
         x = F_.to_nhwc(x, dtype=dtype, cpad=8)
         # Top-Down
+        # F_.stage_mark is an identity: it only tells the training step where, in the BACKWARD pass, a stage's parameter
+        # gradients are complete (deferred weight-gradient flush, gradient buckets); a no-op outside a TrainStep
+        mark = F_.stage_mark
         x_0_0 = self._encode_stem(x)
         x_0_1 = self.encoder_0_2_2(x_0_0)
-        x_1 = self.encoder_1(x_0_1)
-        x_2 = self.encoder_2(x_1)
-        x_3 = self.encoder_3(x_2)
+        x_1 = self.encoder_1(mark(x_0_1, "encoder_1"))
+        x_2 = self.encoder_2(mark(x_1, "encoder_2"))
+        x_3 = self.encoder_3(mark(x_2, "encoder_3"))
         pad_h, pad_w = x_3.shape[2] % 2, x_3.shape[3] % 2
         if pad_h or pad_w:                                   # ref :125-130
             x_3 = F_.pad_bottom_right(x_3, pad_h, pad_w)
-        x_4 = self.encoder_4(x_3)
+        x_4 = self.encoder_4(mark(x_3, "encoder_4"))
 
         attentions = []
         # Bottom-Up
         d_4 = self.upsampling_4(x_4)
         d_4 = F_.cat_crop(x_3, d_4, x_3.shape[2] - pad_h, x_3.shape[3] - pad_w)   # cat + crop, ref :141-147
-        d_4 = self.decoder_4(d_4)
+        d_4 = self.decoder_4(mark(d_4, "decoder_4"))
         if self.gating_level >= 4:
             d_4, y_4 = self.aag_4(d_4)
             attentions.append(y_4)
-        d_3 = self.decoder_3(F_.cat_crop(x_2, self.upsampling_3(d_4)))
+        d_3 = self.decoder_3(mark(F_.cat_crop(x_2, self.upsampling_3(d_4)), "decoder_3"))
         if self.gating_level >= 3:
             d_3, y_3 = self.aag_3(d_3)
             attentions.append(y_3)
-        d_2 = self.decoder_2(F_.cat_crop(x_1, self.upsampling_2(d_3)))
+        d_2 = self.decoder_2(mark(F_.cat_crop(x_1, self.upsampling_2(d_3)), "decoder_2"))
         if self.gating_level >= 2:
             d_2, y_2 = self.aag_2(d_2)
             attentions.append(y_2)
-        d_1 = self.decoder_1(F_.cat_crop(x_0_0, self.upsampling_1(d_2)))
+        d_1 = self.decoder_1(mark(F_.cat_crop(x_0_0, self.upsampling_1(d_2)), "decoder_1"))
         if self.gating_level >= 1:
             d_1, y_1 = self.aag_1(d_1)
             attentions.append(y_1)
-        d_0 = self.decoder_0(self.upsampling_0(d_1))
+        d_0 = self.decoder_0(mark(self.upsampling_0(d_1), "decoder_0"))
         if self.gating_level >= 0:
             d_0, y_0 = self.aag_0(d_0)
             attentions.append(y_0)

@@ -87,7 +87,9 @@ def roofline_leg(step, batch, dtype_name):
     dw_scratch = {}
     for kind, d, ptrs, keep in rec:
         def launch():
-            if kind == "fwd":
+            if kind == "wgrad_batch":           # (job array, count): one batched weight-gradient flush, re-run into the same gradient slots
+                L.octa_conv2d_wgrad_batch(d, ptrs, st)
+            elif kind == "fwd":
                 L.octa_conv2d_fwd(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[3], st)
             elif kind == "dgrad":
                 L.octa_conv2d_dgrad(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], st)
@@ -106,7 +108,8 @@ def roofline_leg(step, batch, dtype_name):
         e0.record()
         launch()
         e1.record()
-        pending.append((e0, e1, L.octa_last_conv_kernel().decode(), conv_flops(d)))
+        fl = sum(conv_flops(d[i].d) for i in range(ptrs)) if kind == "wgrad_batch" else conv_flops(d)
+        pending.append((e0, e1, L.octa_last_conv_kernel().decode(), fl))
     torch.cuda.synchronize()
     for e0, e1, kname, fl in pending:
         ms = e0.elapsed_time(e1)

@@ -58,6 +58,10 @@ typedef struct octa_conv_desc {
     int32_t act;           /* octa_act fused into the forward epilogue                         */
     int32_t upshuffle;     /* 1: ConvTranspose2d k2 s2 as a 1x1 GEMM whose output channel
                               n = (di*2+dj)*Cout_t + co is scattered to pixel (2h+di, 2w+dj)   */
+    int32_t algo;          /* fwd / dgrad kernel choice: 0 = library heuristic, 1 = 4-wave kernels (3x3 halo
+                              / generic tiles), 2 / 3 = 8-wave LDS-DMA kernel with 256x128 / 128x256
+                              (pixels x channels) output slabs.  A choice the shape does not allow falls
+                              back to the heuristic.  Results are identical up to fp32 summation order.  */
 } octa_conv_desc;
 
 /* OIHW-logical fp32 weight (any strides, given in elements) -> packed forward operand
@@ -127,6 +131,10 @@ typedef struct octa_wgrad_job {
     int64_t dw_strides[4];   /* o,i,h,w element strides of dw */
 } octa_wgrad_job;
 int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, octa_stream_t stream);
+/* Which kernel family octa_conv2d_wgrad_batch runs this job on: 1 = batched 256(N)x128(K) slabs, 2 = batched 128x256
+ * slabs, 0 = the single-problem kernels (host-side query; lets the caller group a queue so that one call = one family).
+ * Not a status code. */
+size_t octa_wgrad_job_class(const octa_wgrad_job* job_host);
 /* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
  * call dispatched, e.g. "conv_igemm_kernel<bf16,128x128>", "conv3x3_halo_kernel<bf16,128x64>",
  * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline

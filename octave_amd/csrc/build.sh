@@ -8,7 +8,11 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -mcode-obje
 mkdir -p "$HERE/obj"
 pids=()
 for f in conv wgrad8 norm pool_misc splat_aag loss disc; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/octa_hip.h" -nt "$HERE/obj/$f.o" ]; then
+  stale=0
+  for dep in "$HERE/$f.hip" "$HERE"/*.hpp "$HERE/../../include/octa_hip.h"; do
+    if [ ! -f "$HERE/obj/$f.o" ] || [ "$dep" -nt "$HERE/obj/$f.o" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi

@@ -601,6 +601,7 @@ template <typename T> static void note_kernel(const char* family, int bm, int bn
     else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%d>", family, sizeof(T) == 2 ? "bf16" : "f32", bm);
 }
 extern "C" const char* octa_last_conv_kernel(void) { return g_last_kernel; }
+void octa_note_conv_kernel(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
 
 template <typename T, int MODE>
 static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
@@ -640,6 +641,8 @@ static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
     return true;
 }
 
+#include "igemm8.hpp"
+
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
 static int conv_variant() {
     if (g_conv_variant < 0) { const char* e = getenv("OCTA_CONV_VARIANT"); g_conv_variant = e ? atoi(e) : 1; }
@@ -653,9 +656,23 @@ static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
     else conv_igemm_dma_kernel<T, WM, WN, TM, TN, 3, 2><<<grid, 256, 0, st>>>(a);
 }
 
+// algo (octa_conv_desc.algo): 0 = heuristic, 1 = 4-wave kernels (halo / generic), 2 / 3 = 8-wave kernel with 256x128 / 128x256 slabs
 template <typename T>
-static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st) {
+static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo = 0) {
     dim3 block(256);
+    if constexpr (sizeof(T) == 2) {
+        static const int force8 = getenv("OCTA_IGEMM8") ? atoi(getenv("OCTA_IGEMM8")) : 0;
+        int want = algo;
+        if (want == 0 && force8) want = force8;
+        if (want == 0) {
+            // heuristic (a training step overrides it per shape with measured choices, functional.py autotune): the 8-wave kernel
+            // wins once a launch has >= ~60 GFLOP of dense work per group set; below that the 4-wave kernels' occupancy does
+            static const double thr = getenv("OCTA_IGEMM8_GFLOP") ? atof(getenv("OCTA_IGEMM8_GFLOP")) : 60.0;
+            const double gf = 2.0 * (double)a.M * a.Ng * a.Kc * 8.0 * groups * 1e-9;
+            if (gf >= thr && a.Cg % 64 == 0) want = (a.Ng >= 256) ? 3 : 2;
+        }
+        if ((want == 2 || want == 3) && launch_igemm8(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
+    }
     if (conv_variant() >= 1) {
         const bool done = a.mode == 0 ? launch_halo<T, 0>(a, groups, st) : launch_halo<T, 1>(a, groups, st);
         if (done) { OCTA_CHECK_LAUNCH("conv3x3_halo"); return OCTA_OK; }
@@ -735,7 +752,7 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     if (d->upshuffle) OCTA_REQUIRE(d->ldy >= a.CoutT + d->yoff, "octa_conv2d_fwd: ldy too small for upshuffle");
     else OCTA_REQUIRE(d->ldy >= d->Cout + d->yoff, "octa_conv2d_fwd: ldy %d < yoff+Cout", d->ldy);
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
-                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream);
+                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo);
 }
 
 extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
@@ -759,7 +776,7 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
-                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream);
+                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,241 @@
+// 8-wave implicit-GEMM convolution kernel (forward and stride-1 data gradient), bf16 / f16, included by conv.hip.
+//
+// C[m][n] = sum_k im2col(x)[m][k] * W[n][k]: one workgroup (512 threads, one per CU) owns a 256(M) x 128(N) or 128 x 256
+// output slab, every wave a 64 x 64 sub-tile (16 MFMA 16x16x32 accumulators).  K advances 64 elements (8 chunks of 16 B =
+// one 128-byte line per row) per stage through a 3-stage LDS ring (3 x 48 KB) filled by LDS-DMA, one raw s_barrier per
+// stage, counted vmcnt.
+// LDS image of a stage: rows of 128 bytes, rows R and R + 8 share one 256-byte line (line = (R & 7) + 8 (R >> 4), half =
+// (R >> 3) & 1), and the 16-byte chunk c of row R sits at slot 8 half + (c ^ (R & 7)).  (a) One LDS-DMA wave-instruction
+// (1 KiB = 4 lines) therefore fetches 8 FULL 128-byte rows from global memory -- a plane-per-chunk image made every
+// instruction touch 64 different cache lines and ran 30 % slower than the 4-wave kernels; (b) the 16 lanes of a
+// ds_read_b128 group (rows r = 0..15, one logical chunk) hit 16 distinct slots of the 256-byte bank row: conflict-free.
+// Fragment reads are inline-asm ds_read_b128 with immediate offsets (4 address registers per wave).
+// The loop is VALU-issue bound like wgrad8's: waves 0-3 issue the next stage before their MFMAs, waves 4-7 after.
+#pragma once
+
+typedef __attribute__((ext_vector_type(4))) unsigned ig8_u32x4_t;
+template <int OFF> __device__ __forceinline__ ig8_u32x4_t ig8_rd(unsigned addr) {
+    ig8_u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void ig8_wait8(ig8_u32x4_t (&a)[4], ig8_u32x4_t (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+}
+// the four 16-row sub-tiles of a wave's 64 rows are 8 lines (2048 bytes) apart
+__device__ __forceinline__ void ig8_load_sub(unsigned abase, unsigned bbase, ig8_u32x4_t (&xf)[4], ig8_u32x4_t (&wf)[4]) {
+    xf[0] = ig8_rd<0>(abase); xf[1] = ig8_rd<2048>(abase); xf[2] = ig8_rd<4096>(abase); xf[3] = ig8_rd<6144>(abase);
+    wf[0] = ig8_rd<0>(bbase); wf[1] = ig8_rd<2048>(bbase); wf[2] = ig8_rd<4096>(bbase); wf[3] = ig8_rd<6144>(bbase);
+}
+
+template <typename T> struct Mma8;
+template <> struct Mma8<bf16_t> {
+    __device__ static __forceinline__ void run(const ig8_u32x4_t& a, const ig8_u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+// MODE 0: forward gather (any stride); 1: data-gradient gather, stride 1
+template <typename T, int WM, int WN, int MODE>
+__global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
+    constexpr int EPC = 8;
+    constexpr int BM = WM * 64, BN = WN * 64, KP = 8, STAGES = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SBYTES = A_BYTES + B_BYTES;
+    constexpr int A_IPW = BM / 64, B_IPW = BN / 64;        // DMA instructions per wave and stage (8 rows each)
+    constexpr int LPT = A_IPW + B_IPW;
+    static_assert(WM * WN == 8 && LPT == 6, "8 waves of 64x64");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SBYTES];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = blockIdx.z;
+    int mt, nt;
+    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int Kc = a.Kc, CgC = a.Cg / EPC, KW = a.KW, Wimg = a.W, ldx = a.ldx;
+    const unsigned long zaddr = (unsigned long)(const void*)octa_zero_page;
+
+    // ---- DMA roles.  Instruction j of this wave fills lines 4 (wave + 8 j) .. + 3 of the stage image: lane l writes slot
+    // l & 15 of line Lc + 32 j, i.e. row rowc + 64 j, chunk (l & 7) ^ (Lc & 7) -- row offset and chunk are lane constants.
+    const int Lc = 4 * wave + (lane >> 4);
+    const int rowc = (Lc & 7) + 8 * ((lane >> 3) & 1) + 16 * (Lc >> 3);
+    const int chunk = (lane & 7) ^ (Lc & 7);
+    // A: the A_IPW pixels this lane gathers (byte address of tap (0,0), channel 0; in-image tap mask)
+    unsigned long abase[A_IPW];
+    unsigned rmask[A_IPW];
+#pragma unroll
+    for (int j = 0; j < A_IPW; ++j) {
+        const int m = m0 + rowc + 64 * j;
+        const bool rvalid = m < a.M;
+        const int mm = rvalid ? m : 0;
+        const int ow = mm % a.OW;
+        const int tq = mm / a.OW;
+        const int oh = tq % a.OH;
+        const int b = tq / a.OH;
+        int rh, rw;
+        if (MODE == 0) { rh = oh * a.stride - a.pad; rw = ow * a.stride - a.pad; }
+        else { rh = oh + a.pad; rw = ow + a.pad; }
+        unsigned mk = 0;
+        if (rvalid) {
+            const int ntaps = a.KH * KW;
+            for (int tp = 0; tp < ntaps; ++tp) {
+                const int kh_ = tp / KW, kw_ = tp - kh_ * KW;
+                bool ok;
+                if (MODE == 0) ok = ((unsigned)(rh + kh_) < (unsigned)a.H) && ((unsigned)(rw + kw_) < (unsigned)Wimg);
+                else ok = ((unsigned)(rh - kh_) < (unsigned)a.H) && ((unsigned)(rw - kw_) < (unsigned)Wimg);
+                mk |= (ok ? 1u : 0u) << tp;
+            }
+        }
+        rmask[j] = mk;
+        const long roff = ((long)(b * a.H + rh) * Wimg + rw) * ldx + a.xoff + g * a.CgStride;
+        abase[j] = (unsigned long)((const T*)a.x + roff);
+    }
+    // B: the B_IPW weight rows this lane fetches, chunk `chunk` of the current K step (zero page with a zero step when out of range)
+    const size_t Kelem = (size_t)Kc * EPC;
+    unsigned long wptr[B_IPW];
+    unsigned long wstep[B_IPW];
+#pragma unroll
+    for (int j = 0; j < B_IPW; ++j) {
+        const int n = n0 + rowc + 64 * j;
+        const bool wvalid = n < a.Ng;
+        wptr[j] = wvalid ? (unsigned long)((const T*)a.w + ((size_t)g * a.Ng + n) * Kelem + (size_t)chunk * EPC) : zaddr;
+        wstep[j] = wvalid ? 128ul : 0ul;
+    }
+    // per-lane K state of the stage to be issued next: chunk index kc, channel chunk cc inside the tap, tap (kh, kw)
+    int kc = chunk, cc = chunk % CgC, tap = chunk / CgC;
+    int kh = tap / KW, kw = tap - kh * KW;
+
+    const unsigned sbase = lds_addr(smem);
+    auto issue = [&](int stage) {
+        const unsigned ab = sbase + (unsigned)(stage * SBYTES), bb = ab + A_BYTES;
+        const int tpix = kh * Wimg + kw;
+        const long soff = (long)(((MODE == 0 ? tpix : -tpix) * ldx + cc * EPC) * 2);      // byte offset of (tap, channel chunk)
+        const bool kin = kc < Kc;
+        const unsigned tbit = kin ? (1u << tap) : 0u;
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const bool ok = (rmask[j] & tbit) != 0;
+            const unsigned long src = ok ? (abase[j] + soff) : zaddr;
+            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(ab + (unsigned)((wave + 8 * j) * 1024)));
+        }
+#pragma unroll
+        for (int j = 0; j < B_IPW; ++j) {
+            const unsigned long src = kin ? wptr[j] : zaddr;
+            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(bb + (unsigned)((wave + 8 * j) * 1024)));
+            wptr[j] += wstep[j];
+        }
+        // advance by one K step (8 chunks); CgC >= 8 (checked by the launcher): at most one tap wrap
+        kc += KP; cc += KP;
+        const bool wrap = cc >= CgC;
+        cc -= wrap ? CgC : 0;
+        tap += wrap ? 1 : 0;
+        kw += wrap ? 1 : 0;
+        const bool wrap2 = kw >= KW;
+        kw = wrap2 ? 0 : kw;
+        kh += wrap2 ? 1 : 0;
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: lane (r, q), k-substep s reads logical chunk 4 s + q of row (wave tile row + 16 i + r):
+    // line (r & 7) + 8 (4 w + i), slot 8 ((r >> 3) & 1) + ((4 s + q) ^ (r & 7)); i is an immediate offset (2048 i)
+    const int r = lane & 15, q = lane >> 4;
+    const int lrow = (r & 7) * 256 + ((r >> 3) & 1) * 128;
+    const unsigned afrag0 = sbase + (unsigned)(wm * 4 * 2048 + lrow + (((0 + q) ^ (r & 7)) << 4));
+    const unsigned afrag1 = sbase + (unsigned)(wm * 4 * 2048 + lrow + (((4 + q) ^ (r & 7)) << 4));
+    const unsigned bfrag0 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((0 + q) ^ (r & 7)) << 4));
+    const unsigned bfrag1 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((4 + q) ^ (r & 7)) << 4));
+    const int nk = (Kc + KP - 1) / KP;
+    const bool late = wave >= 4;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!late && kt + 2 < nk) issue((kt + 2) % STAGES);
+        const unsigned so = (unsigned)((kt % STAGES) * SBYTES);
+        {
+            ig8_u32x4_t xf0[4], wf0[4], xf1[4], wf1[4];
+            ig8_load_sub(afrag0 + so, bfrag0 + so, xf0, wf0);
+            ig8_wait8(xf0, wf0);
+            ig8_load_sub(afrag1 + so, bfrag1 + so, xf1, wf1);       // in flight under the first 16 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma8<T>::run(wf0[i], xf0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            ig8_wait8(xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma8<T>::run(wf1[i], xf1[j], acc[i][j]);
+        }
+        if (late && kt + 2 < nk) issue((kt + 2) % STAGES);
+    }
+
+    // epilogue: lane holds, per (tn, tm), 4 consecutive output channels (rows of D) of pixel column r
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (wm * 4 + j) * 16 + r;
+        if (m >= a.M) continue;
+        size_t pix = (size_t)m;
+        int ow = 0, oh = 0, bb = 0;
+        if (a.upshuffle) { ow = m % a.OW; const int tq = m / a.OW; oh = tq % a.OH; bb = tq / a.OH; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nb = n0 + (wn * 4 + i) * 16 + q * 4;
+            if (nb >= a.Ng) continue;
+            int chan = g * a.Ng + nb;
+            int bidx = chan;
+            if (a.upshuffle) {
+                const int dd = nb / a.CoutT;
+                chan = nb - dd * a.CoutT;
+                bidx = chan;
+                pix = ((size_t)(bb * 2 * a.OH + 2 * oh + (dd >> 1)) * (2 * a.OW) + 2 * ow + (dd & 1));
+            }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f = acc[i][j][e];
+                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
+                v[e] = act_apply(f, a.act);
+            }
+            T* dst = yb + pix * a.ldy + chan;
+            if (a.vec_store && nb + 3 < a.Ng) {
+                *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+            }
+        }
+    }
+}
+
+// eligibility + launch; variant 0: 256(M) x 128(N), 1: 128(M) x 256(N).  Returns false when the legacy kernels must run.
+static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_t st) {
+    if (a.KH * a.KW > 32) return false;
+    if (a.mode == 1 && a.stride != 1) return false;
+    if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 30)) return false;
+    if (a.Cg % 64 != 0) return false;                     // whole 128-byte lines per tap: at most one tap wrap per K step
+    if (variant == 0) {
+        dim3 grid(cdiv(a.M, 256), cdiv(a.Ng, 128), groups);
+        if (a.mode == 0) conv_igemm8_kernel<bf16_t, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+        else conv_igemm8_kernel<bf16_t, 4, 2, 1><<<grid, 512, 0, st>>>(a);
+        note_kernel<bf16_t>("conv_igemm8_kernel", 256, 128);
+    } else {
+        dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 256), groups);
+        if (a.mode == 0) conv_igemm8_kernel<bf16_t, 2, 4, 0><<<grid, 512, 0, st>>>(a);
+        else conv_igemm8_kernel<bf16_t, 2, 4, 1><<<grid, 512, 0, st>>>(a);
+        note_kernel<bf16_t>("conv_igemm8_kernel", 128, 256);
+    }
+    return true;
+}

@@ -386,9 +386,23 @@ static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
             else wgrad8_kernel<2, 4, F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
         }
         OCTA_CHECK_LAUNCH("wgrad8");
+        octa_note_conv_kernel(variant == 0 ? (F16 ? "wgrad8_kernel<f16,256x128>" : "wgrad8_kernel<bf16,256x128>")
+                                           : (F16 ? "wgrad8_kernel<f16,128x256>" : "wgrad8_kernel<bf16,128x256>"));
         i0 = i1;
     }
     return OCTA_OK;
+}
+
+static int wg8_variant(const octa_wgrad_job& j) {
+    // slab orientation: the one that wastes less padded MFMA work; ties go to 256(N) x 128(K)
+    const int Ng = j.d.Cout / j.d.groups, Kpad = j.d.KH * j.d.KW * j.d.cin_g_pad;
+    const int64_t w0 = (int64_t)cdiv(Ng, 256) * 256 * cdiv(Kpad, 128) * 128, w1 = (int64_t)cdiv(Ng, 128) * 128 * cdiv(Kpad, 256) * 256;
+    return (w1 < w0) ? 1 : 0;
+}
+extern "C" size_t octa_wgrad_job_class(const octa_wgrad_job* job) {
+    static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
+    if (!job || off || !wg8_eligible(*job)) return 0;
+    return 1 + wg8_variant(*job);
 }
 
 extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_stream_t stream) {
@@ -415,9 +429,7 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
         p.s_o = (int)j.dw_strides[0]; p.s_i = (int)j.dw_strides[1]; p.s_h = (int)j.dw_strides[2]; p.s_w = (int)j.dw_strides[3];
         p.magicOW = wg_magic(d.OW); p.magicOH = wg_magic(d.OH);
         p.groups = d.groups;
-        // slab orientation: the one that wastes less padded MFMA work; ties go to 256(N) x 128(K)
-        const int64_t w0 = (int64_t)cdiv(p.Ng, 256) * 256 * cdiv(p.Kpad, 128) * 128, w1 = (int64_t)cdiv(p.Ng, 128) * 128 * cdiv(p.Kpad, 256) * 256;
-        pl.variant = (w1 < w0) ? 1 : 0;
+        pl.variant = wg8_variant(j);
         p.tilesN = cdiv(p.Ng, pl.variant ? 128 : 256);
         p.tilesK = cdiv(p.Kpad, pl.variant ? 256 : 128);
         pl.steps = (p.M + 63) / 64;

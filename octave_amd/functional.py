@@ -13,7 +13,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, OCTA_BF16, OCTA_F32, ConvDesc,
-                   OctaError, lib)
+                   OctaError, WgradJob, lib)
 
 Tensor = torch.Tensor
 _I64x4 = ctypes.c_int64 * 4
@@ -239,8 +239,10 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
         raise ValueError(kind)
     if cacheable:
         if len(_PACK_CACHE) > 8192:
-            _PACK_CACHE.clear()
-            _PACK_PLANS.clear()
+            # evict only entries whose parameter is gone: live entries may be baked into captured hipGraphs (their buffers
+            # and the device-side descriptor tables of _PACK_PLANS must stay where they are)
+            for k in [k for k, e_ in _PACK_CACHE.items() if e_.wref() is None]:
+                del _PACK_CACHE[k]
         e = _PackEntry()
         e.tag, e.out, e.wref, e.direct, e.kind, e.dtype, e.groups, e.pad_to = tag, out, weakref.ref(w), direct, kind, dtype, groups, pad_to
         e.aux = aux
@@ -308,10 +310,72 @@ def _record(kind, d, ptrs, keep):
     if _RECORD is not None:
         dd = ConvDesc()
         ctypes.memmove(ctypes.byref(dd), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+        dd.alg_groups = getattr(d, "alg_groups", d.groups)       # densified grouped layers keep their algorithmic group count
         _RECORD.append((kind, dd, ptrs, keep))
 
 
 # ----------------------------------------------------------------------------- raw conv ops
+_ALGO_OVERRIDE = 0      # octa_conv_desc.algo for every descriptor built below (0 = library heuristic; tools/conv8_micro.py sweeps it)
+
+
+# Per-shape kernel choice for fwd / dgrad (octa_conv_desc.algo), measured once per shape while a training step warms up:
+# small layers prefer the 4-wave kernels (occupancy), big ones the 8-wave LDS-DMA kernel; the crossover depends on M, N, K,
+# taps and groups in ways a formula only approximates, so it is measured (3 launches per candidate, HIP events).
+_AUTOTUNE = False
+_ALGO_CACHE = {}
+
+
+def set_conv_autotune(on: bool):
+    global _AUTOTUNE
+    _AUTOTUNE = bool(on)
+
+
+def _choose_algo(kind: str, d, launch) -> int:
+    if _ALGO_OVERRIDE:
+        return _ALGO_OVERRIDE
+    if d.dtype != OCTA_BF16:
+        return 0
+    key = (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.pad, d.groups, d.ldx, d.ldy, d.upshuffle, d.act)
+    a = _ALGO_CACHE.get(key)
+    if a is not None:
+        return a
+    if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0
+    cg = d.cin_g_pad if kind == "fwd" else d.cout_g_pad
+    cands = [1]
+    if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
+        cands += [2, 3]
+    best, best_t = 1, None
+    if len(cands) > 1:
+        for c in cands:
+            d.algo = c
+            launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(); launch(); launch()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t * 0.97:        # a challenger must win by 3 %
+                best, best_t = c, t
+    _ALGO_CACHE[key] = best
+    return best
+
+
+def _launch_fwd(d, x, wp, bias, y):
+    L, st = lib(), _st()
+    px, pw, pb, py = _p(x), _p(wp), _p(bias), _p(y)
+    d.algo = _choose_algo("fwd", d, lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
+    L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
+
+
+def _launch_dgrad(d, dy, wt, dx):
+    L, st = lib(), _st()
+    pdy, pw, pdx = _p(dy), _p(wt), _p(dx)
+    d.algo = _choose_algo("dgrad", d, lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
+    L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st)
+
+
 def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dtype, act=ACT_NONE, upshuffle=0) -> ConvDesc:
     d = ConvDesc()
     d.B, d.H, d.W, d.OH, d.OW = B, H, W, OH, OW
@@ -320,6 +384,7 @@ def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dty
     d.cout_g_pad = round8(Cout // groups)
     d.ldx, d.xoff, d.ldy, d.yoff = ldx, 0, ldy, 0
     d.dtype, d.act, d.upshuffle = _dt(dtype), act, upshuffle
+    d.algo = _ALGO_OVERRIDE
     return d
 
 
@@ -368,7 +433,7 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     else:
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
         wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
-    lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+    _launch_fwd(d, x, wp, bias, y)
     _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
     return y
 
@@ -388,7 +453,7 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, nhwc_ld(dx), ldy, dy.dtype)
         d.alg_groups = groups
         wt = _packed(w, "dgrad_dense", dy.dtype, groups, d.cout_g_pad)
-        lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
+        _launch_dgrad(d, dy, wt, dx)
         _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
         return dx
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
@@ -399,18 +464,110 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         N = Cin * KH * KW
         z = nhwc_empty(B, N, OH, OW, dy.dtype, dy.device)
         dz = _desc(B, OH, OW, OH, OW, d.cout_g_pad, N, 1, 1, 1, 0, 1, ldy, N, dy.dtype)
-        lib().octa_conv2d_fwd(ctypes.byref(dz), _p(dy), _p(wt), None, _p(z), _st())
+        _launch_fwd(dz, dy, wt, None, z)
         _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
         lib().octa_col2im(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, Cin, KH, KW, stride, pad, _dt(dy), _st())
         return dx
-    lib().octa_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _st())
+    _launch_dgrad(d, dy, wt, dx)
     _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
     return dx
 
 
+# ----------------------------------------------------------------------------- deferred weight gradients
+# Nothing downstream of a conv's backward reads its weight gradient before the optimiser does, so a training step
+# may queue the weight-gradient jobs and flush the queue as a few batched launches (octa_conv2d_wgrad_batch):
+# the M-split -- and with it the fp32 reduction traffic -- is then chosen over all queued layers at once, and
+# ~60 launches per step disappear.  Only jobs that accumulate into a pre-assigned gradient buffer (gradient sink)
+# are queued: autograd never sees their result, so nobody can read it before the flush.
+_WGRAD_Q = None
+_WGRAD_FLUSH_MIN = int(os.environ.get("OCTA_WGRAD_FLUSH_MIN", "8"))
+_MARK_HOOKS = []
+
+
+def defer_wgrads(on: bool):
+    """Turn the weight-gradient queue on/off (off flushes what is pending)."""
+    global _WGRAD_Q
+    if on:
+        if _WGRAD_Q is None:
+            _WGRAD_Q = []
+    else:
+        flush_wgrads()
+        _WGRAD_Q = None
+
+
+def pending_wgrads() -> int:
+    return len(_WGRAD_Q) if _WGRAD_Q else 0
+
+
+def flush_wgrads(min_jobs: int = 1) -> int:
+    """Launch every queued weight gradient (if at least `min_jobs` are pending).  Jobs are grouped by the kernel family
+    the library runs them on, so one call = one family (keeps bench.py's per-kernel attribution clean)."""
+    q = _WGRAD_Q
+    if not q or len(q) < min_jobs:
+        return 0
+    L = lib()
+    groups = {}
+    for job in q:
+        groups.setdefault(int(L.octa_wgrad_job_class(ctypes.byref(job[0]))), []).append(job)
+    st = _st()
+    for cls in sorted(groups):
+        jobs = groups[cls]
+        if cls == 0:
+            for j, keep in jobs:
+                L.octa_conv2d_wgrad(ctypes.byref(j.d), j.x, j.dy, j.dw, j.dw_strides, j.dbias, st)
+                _record("wgrad", j.d, (j.x, j.dy, keep[2], keep[3]), keep)
+            continue
+        arr = (WgradJob * len(jobs))()
+        for i, (j, keep) in enumerate(jobs):
+            ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(j), ctypes.sizeof(WgradJob))
+        L.octa_conv2d_wgrad_batch(arr, len(jobs), st)
+        if _RECORD is not None:
+            _RECORD.append(("wgrad_batch", arr, len(jobs), [k for _, k in jobs]))
+    n = len(q)
+    q.clear()
+    return n
+
+
+def add_mark_hook(fn):
+    """fn(tag) is called (after the weight-gradient flush) whenever the backward pass crosses a stage mark."""
+    _MARK_HOOKS.append(fn)
+
+
+def clear_mark_hooks():
+    _MARK_HOOKS.clear()
+
+
+class StageMarkFn(Function):
+    """Identity that marks a stage boundary of the network: when the BACKWARD pass crosses it, every layer executed after
+    the mark in forward has produced (or queued) its parameter gradients.  The queue of deferred weight gradients is
+    flushed there and the registered hooks run (bucketed gradient all-reduce, train.py)."""
+
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        flush_wgrads(1 if _MARK_HOOKS else _WGRAD_FLUSH_MIN)
+        for fn in _MARK_HOOKS:
+            fn(ctx.tag)
+        return g, None
+
+
+def stage_mark(x: Tensor, tag: str) -> Tensor:
+    if _WGRAD_Q is None and not _MARK_HOOKS:
+        return x
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return StageMarkFn.apply(x, tag)
+
+
 def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, groups: int, dw: Optional[Tensor] = None,
-                   dbias: Optional[Tensor] = None) -> Tensor:
-    """dw += wgrad; when `dbias` (fp32 [Cout]) is given the bias gradient is accumulated by the same kernel."""
+                   dbias: Optional[Tensor] = None, defer: bool = False) -> Tensor:
+    """dw += wgrad; when `dbias` (fp32 [Cout]) is given the bias gradient is accumulated by the same kernel.
+    defer=True (caller owns dw/dbias as gradient-sink buffers): the job may be queued instead of launched."""
     B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
     x, ldx = _conv_input(x, round8(Cin_g), groups)
     need = round8(Cout // groups) if groups == 1 else Cout
@@ -421,6 +578,14 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
         # rate of a strided OIHW target; MI355X_MICROARCH.md "Global float atomics")
         dw = torch.empty(tuple(w.shape), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
+    if defer and _WGRAD_Q is not None:
+        j = WgradJob()
+        ctypes.memmove(ctypes.byref(j.d), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+        j.x, j.dy, j.dw, j.dbias = _p(x), _p(dy), _p(dw), _p(dbias)
+        for a, sv in enumerate(dw.stride()):
+            j.dw_strides[a] = sv
+        _WGRAD_Q.append((j, (x, dy, tuple(dw.shape), tuple(dw.stride()), dw, dbias)))
+        return dw
     lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw
@@ -566,7 +731,9 @@ class Conv2dFn(Function):
             if db is None:
                 db = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
         if ctx.needs_input_grad[1]:
-            dw = _ret(w, raw_conv_wgrad(x, dy, w, stride, pad, groups, _sink(w), db if want_b else None))   # bias gradient fused
+            sw = _sink(w)
+            can_defer = sw is not None and (not want_b or _sink(b) is db)      # every target is a gradient-sink buffer
+            dw = _ret(w, raw_conv_wgrad(x, dy, w, stride, pad, groups, sw, db if want_b else None, defer=can_defer))   # bias gradient fused
         elif want_b:
             raw_colsum(dy, db)
         if want_b:
@@ -592,7 +759,7 @@ class ConvTranspose2x2Fn(Function):
         y = nhwc_empty(B, CoutT, 2 * H, 2 * W, x.dtype, x.device)
         d = _desc(B, H, W, H, W, Cin, 4 * CoutT, 1, 1, 1, 0, 1, ldx, nhwc_ld(y), x.dtype, ACT_NONE, upshuffle=1)
         wp = _packed(w, "convT", x.dtype, 1, d.cin_g_pad)
-        lib().octa_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _st())
+        _launch_fwd(d, x, wp, bias, y)
         _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
@@ -607,7 +774,8 @@ class ConvTranspose2x2Fn(Function):
         dx = raw_conv_fwd(dy, w, None, 2, 0, 1) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = _ret(w, raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1, _sink(w)))
+            sw = _sink(w)
+            dw = _ret(w, raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1, sw, defer=sw is not None))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             b = ctx.bias_ref
             db = _ret(b, raw_colsum(dy, _sink(b)))

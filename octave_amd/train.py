@@ -187,6 +187,7 @@ class TrainStep:
         self.seg_arena = FlatArena(seg_params)
         self.disc_arena = FlatArena(list(self.disc.parameters())) if self.adversarial else None
         F_.set_grad_sink(True)
+        F_.defer_wgrads(True)        # weight gradients are queued per stage and run as batched launches (functional.flush_wgrads)
         defer_bn_counters(True)
         self._graphs = None
         self._comm_stream = None
@@ -212,6 +213,7 @@ class TrainStep:
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
         try:
             loss.backward()
+            F_.flush_wgrads()
         finally:
             if self.adversarial:
                 for q in self.disc_arena.params:
@@ -229,6 +231,7 @@ class TrainStep:
             d_fake = self.disc(att)
             l_d = F_.lsgan_discriminator(d_real, d_fake)
             l_d.backward()
+            F_.flush_wgrads()
             out["loss_disc"] = l_d.detach()
 
     def _phase_seg_update(self, dyn=None):
@@ -285,8 +288,12 @@ class TrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):             # warm-up off the default stream, as graph capture requires
-            for _ in range(warmup):
-                self._eager_static()
+            F_.set_conv_autotune(True)            # the first warm-up step measures the fwd / dgrad kernel choice per layer shape
+            try:
+                for _ in range(warmup):
+                    self._eager_static()
+            finally:
+                F_.set_conv_autotune(False)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._out: Dict[str, Tensor] = {}
@@ -384,6 +391,8 @@ class TrainStep:
     def close(self):
         """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""
         F_.set_grad_sink(False)
+        F_.defer_wgrads(False)
+        F_.clear_mark_hooks()
         defer_bn_counters(False)
         if self.disc is not None:
             self.disc.rng_feed = None

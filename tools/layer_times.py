@@ -23,6 +23,21 @@ rows = []
 excess = []
 scratch = {}
 for kind, d, ptrs, keep in rec:
+    if kind == "wgrad_batch":
+        arr, n = d, ptrs
+        def launchb():
+            L.octa_conv2d_wgrad_batch(arr, n, st)
+        launchb()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launchb(); launchb(); launchb(); e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) / 3 * 1e3
+        fl = sum(bench.conv_flops(arr[i].d) for i in range(n))
+        dd = arr[0].d
+        desc = f"batch of {n}: first B{dd.B} {dd.H}x{dd.W} {dd.Cin}->{dd.Cout} k{dd.KH} g{dd.groups}"
+        rows.append((us, "wgradB", desc, fl))
+        excess.append((us - fl / 650e12 * 1e6, us, fl / 650e12 * 1e6, "wgradB", desc))
+        print(f"  wgrad batch {n:2d} jobs {us:8.1f} us {fl / us / 1e6:7.1f} TF/s  " + ", ".join(f"{arr[i].d.H}x{arr[i].d.W}:{arr[i].d.Cin}->{arr[i].d.Cout}k{arr[i].d.KH}g{arr[i].d.groups}" for i in range(n)))
+        continue
     def launch():
         if kind == "fwd": L.octa_conv2d_fwd(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[3], st)
         elif kind == "dgrad": L.octa_conv2d_dgrad(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], st)
@@ -47,7 +62,7 @@ print(f"total conv time {tot/1e3:.2f} ms over {len(rows)} launches")
 agg = {}
 for us, kind, desc, fl in rows:
     a = agg.setdefault((kind, desc), [0.0, 0, 0.0]); a[0] += us; a[1] += 1; a[2] += fl
-for (kind, desc), (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+for (kind, desc), (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:90]:
     print(f"{us:9.1f} us {n:3d}x  {kind:6s} {desc:44s} {fl / us / 1e6:7.1f} TF/s")
 
 print("\n== excess over max(flops/650T, bytes/5TB/s), aggregated per (kind, layer) ==")
