@@ -205,8 +205,10 @@ int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int O
 /* ------------------------------------------------------------------------------------------
  * Split attention (extra/resnest.py:106-138), radix 2.
  * ---------------------------------------------------------------------------------------- */
-/* gap[b][c] = mean_hw( x[b,hw,c] + x[b,hw,C+c] )   (fp32 out; resnest.py:108-116) */
-int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, octa_stream_t stream);
+/* gap[b][c] = mean_hw( x[b,hw,c] + x[b,hw,C+c] )   (fp32 out; resnest.py:108-116).
+ * prezeroed != 0 (here and below): the caller hands over an accumulator that is already zero (e.g. a slice of a scratch
+ * slab cleared once per training step), so the entry point skips its own zero-fill launch. */
+int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, int prezeroed, octa_stream_t stream);
 /* out[b,hw,c] = a0*x[b,hw,c] + a1*x[b,hw,C+c], (a0,a1) = softmax(logit[b][c], logit[b][C+c])
  * (resnest.py:125-138; the view(B, radix, C) has no cardinality transpose).  relu: fuse the
  * ReLU that follows SplAt in ResNestDecoder (resnest.py:29). */
@@ -216,7 +218,7 @@ int octa_splat_apply(const void* x, const float* logits, void* out, int B, int H
  * arriving at gap through fc1), produce dx [B,HW,2C] and dlogits [B,2C] (fp32). */
 int octa_splat_bwd(const void* dout, const void* x, const float* logits, const void* out,
                    const float* dgap, void* dx, float* dlogits, int B, int HW, int C, int dtype,
-                   int relu, int phase, octa_stream_t stream);
+                   int relu, int phase, int prezeroed /* dlogits, phase 0 */, octa_stream_t stream);
 
 /* The attention micro-net on (B, C) vectors (resnest.py:118-125), exact fp32, 2 <= B <= 32:
  * h1 = fc1(gap) [grouped 1x1, + bias]; h2 = relu(bn1(h1)) [batch statistics when training, running stats
@@ -230,7 +232,7 @@ int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, 
                        const float* h1, const float* h2, const float* mean, const float* invstd,
                        const float* gamma, float* dh1_workspace /* B*inter */, float* dgap, float* dw1,
                        float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C,
-                       int inter, int groups, octa_stream_t stream);
+                       int inter, int groups, int prezeroed /* dgap */, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention gate / head (segmentor/blocks.py:38-46; compose.py:79,181): per-pixel K-class linear

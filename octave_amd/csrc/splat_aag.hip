@@ -44,10 +44,10 @@ static void splat_map(int cpr, int& TX, int& gridx) {
     if (cpr >= 256) TX = 256; else if (256 % cpr == 0) TX = cpr; else TX = 64;
     gridx = cdiv(cpr, TX);
 }
-extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, octa_stream_t stream) {
+extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, int dtype, int prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(x && gap && B > 0 && HW > 0 && C % 8 == 0, "octa_splat_gap: bad arguments (C %% 8)");
     hipStream_t st = (hipStream_t)stream;
-    if (octa_zero_async(gap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_gap: memset failed");
+    if (!prezeroed && octa_zero_async(gap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_gap: memset failed");
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     int TX, gx;
     splat_map(C / epc, TX, gx);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void splat_bwd_apply_kernel(const T* __restric
     }
 }
 extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logits, const void* out, const float* dgap, void* dx,
-                              float* dlogits, int B, int HW, int C, int dtype, int relu, int phase, octa_stream_t stream) {
+                              float* dlogits, int B, int HW, int C, int dtype, int relu, int phase, int prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(dout && logits && C % 8 == 0 && C <= 4096, "octa_splat_bwd: bad arguments");
     OCTA_REQUIRE(!relu || out, "octa_splat_bwd: relu needs the forward output");
     OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_splat_bwd: bad dtype");
@@ -211,7 +211,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     if (phase == 0) {
         OCTA_REQUIRE(x && dlogits, "octa_splat_bwd(phase 0): null pointer");
-        if (octa_zero_async(dlogits, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bwd: memset failed");
+        if (!prezeroed && octa_zero_async(dlogits, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bwd: memset failed");
         int TX, gx;
         splat_map(C / epc, TX, gx);
         const int RY = 256 / TX;
@@ -336,14 +336,14 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
 }
 
 // backward A: block per j.  dh2[b][j] = sum_n dl[b][n] W2[n][j]  -> relu mask -> bn1 backward -> dh1[b][j]; dgamma/dbeta +=
-__global__ __launch_bounds__(256) void splat_mlp_bwdA_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+__device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
                                                             const float* __restrict__ h2, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dh1,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1, int B,
                                                             int inter, int N, int groups) {
     // 4 waves split the n range (the kernel is a chain of dependent memory round trips: 4x fewer of them), partials meet in LDS
     __shared__ float red[4][SPLAT_MAXB];
-    const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Ig = inter / groups, Ng = N / groups, grp = j / Ig, jl = j - grp * Ig;
     float acc[SPLAT_MAXB];
 #pragma unroll
@@ -388,9 +388,10 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdA_kernel(const float* __rest
     }
 }
 // backward B: block per n.  dW2[n][j] += sum_b dl[b][n] h2[b][j];  db2[n] += sum_b dl[b][n]
-__global__ __launch_bounds__(64) void splat_mlp_bwdB_kernel(const float* __restrict__ dl, const float* __restrict__ h2, float* __restrict__ dw2,
+__device__ __forceinline__ void splat_mlp_bwdB_body(int n, const float* __restrict__ dl, const float* __restrict__ h2, float* __restrict__ dw2,
                                                             float* __restrict__ db2, int B, int inter, int N, int groups) {
-    const int n = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;          // one wave does the work (the merged launch has 256-thread blocks)
+    if (lane >= 64) return;
     const int Ig = inter / groups, grp = n / (N / groups);
     float d[SPLAT_MAXB];
     float sb = 0.f;
@@ -408,19 +409,18 @@ __global__ __launch_bounds__(64) void splat_mlp_bwdB_kernel(const float* __restr
 // backward C: dgap[b][c] += sum_j dh1[b][j] W1[j][c].  Block = 64 channels c (lanes) x 4 waves; the j range of the
 // channel's group is split over gridDim.y blocks and the block's 4 waves (coalesced W1 rows), partial sums meet in
 // LDS and leave with one atomic per (b, c).  dgap is zeroed by the host wrapper.
-__global__ __launch_bounds__(256) void splat_mlp_bwdC_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, float* __restrict__ dgap, int B,
+__device__ __forceinline__ void splat_mlp_bwdC_body(int bx, int by, int ny, float (*red)[SPLAT_MAXB][64], const float* __restrict__ dh1, const float* __restrict__ w1, float* __restrict__ dgap, int B,
                                                              int C, int inter, int groups) {
-    __shared__ float red[4][SPLAT_MAXB][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = bx * 64 + lane;
     const int Cg = C / groups, Ig = inter / groups;
     const bool live = c < C;
     const int grp = live ? c / Cg : 0, cl = live ? c - grp * Cg : 0;
     float acc[SPLAT_MAXB];
 #pragma unroll
     for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    const int per = (Ig + gridDim.y - 1) / gridDim.y;
-    const int j0 = blockIdx.y * per, j1 = min(Ig, j0 + per);
+    const int per = (Ig + ny - 1) / ny;
+    const int j0 = by * per, j1 = min(Ig, j0 + per);
     if (live)
         for (int jj = j0 + wave; jj < j1; jj += 4) {
             const int j = grp * Ig + jj;
@@ -437,9 +437,9 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdC_kernel(const float* __rest
         if (live) atomicAdd(dgap + (size_t)b * C + c, red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]);
 }
 // backward D: block per j.  dW1[j][c] += sum_b dh1[b][j] gap[b][c]
-__global__ __launch_bounds__(256) void splat_mlp_bwdD_kernel(const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
+__device__ __forceinline__ void splat_mlp_bwdD_body(int j, const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
                                                             int C, int inter, int groups) {
-    const int j = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int Cg = C / groups, grp = j / (inter / groups);
     float d[SPLAT_MAXB];
 #pragma unroll
@@ -452,28 +452,44 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdD_kernel(const float* __rest
         dw1[(size_t)j * Cg + c] += a;
     }
 }
+__global__ __launch_bounds__(256) void splat_mlp_bwdAB_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+                                                             const float* __restrict__ h2, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, float* __restrict__ dh1, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ db1, float* __restrict__ dw2,
+                                                             float* __restrict__ db2, int B, int inter, int N, int groups) {
+    if ((int)blockIdx.x < inter) splat_mlp_bwdA_body(blockIdx.x, dl, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups);
+    else splat_mlp_bwdB_body(blockIdx.x - inter, dl, h2, dw2, db2, B, inter, N, groups);
+}
+__global__ __launch_bounds__(256) void splat_mlp_bwdCD_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, const float* __restrict__ gap,
+                                                             float* __restrict__ dgap, float* __restrict__ dw1, int B, int C, int inter, int groups,
+                                                             int nx, int ny) {
+    __shared__ float red[4][SPLAT_MAXB][64];
+    const int nC = nx * ny;
+    if ((int)blockIdx.x < nC) splat_mlp_bwdC_body(blockIdx.x % nx, blockIdx.x / nx, ny, red, dh1, w1, dgap, B, C, inter, groups);
+    else splat_mlp_bwdD_body(blockIdx.x - nC, dh1, gap, dw1, B, C, inter, groups);
+}
 extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
                                   const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1, float* db1,
-                                  float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, octa_stream_t stream) {
+                                  float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, int prezeroed,
+                                  octa_stream_t stream) {
     OCTA_REQUIRE(dlogits && gap && w1 && w2 && h1 && h2 && mean && invstd && gamma && dh1_ws && dgap && dw1 && dgamma && dbeta && dw2,
                  "octa_splat_mlp_bwd: null pointer");
     OCTA_REQUIRE(B > 1 && B <= SPLAT_MAXB && groups >= 1, "octa_splat_mlp_bwd: needs 2 <= B <= 32");
     hipStream_t st = (hipStream_t)stream;
-    splat_mlp_bwdA_kernel<<<inter, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, B, inter, 2 * C, groups);
-    OCTA_CHECK_LAUNCH("splat_mlp_bwdA");
-    splat_mlp_bwdB_kernel<<<2 * C, 64, 0, st>>>(dlogits, h2, dw2, db2, B, inter, 2 * C, groups);
-    OCTA_CHECK_LAUNCH("splat_mlp_bwdB");
-    if (octa_zero_async(dgap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
+    // two launches instead of four (+ a zero fill): A and B only read dlogits, C and D only read dh1 -- each pair shares a grid,
+    // the block index selects the role
+    splat_mlp_bwdAB_kernel<<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdAB");
+    if (!prezeroed && octa_zero_async(dgap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
     {
         const int Ig = inter / groups;
         int js = Ig / 32;                 // >= 32 rows of W1 per block
         if (js < 1) js = 1;
         if (js > 8) js = 8;
-        splat_mlp_bwdC_kernel<<<dim3(cdiv(C, 64), js), 256, 0, st>>>(dh1_ws, w1, dgap, B, C, inter, groups);
+        const int nC = cdiv(C, 64) * js;
+        splat_mlp_bwdCD_kernel<<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
     }
-    OCTA_CHECK_LAUNCH("splat_mlp_bwdC");
-    splat_mlp_bwdD_kernel<<<inter, 256, 0, st>>>(dh1_ws, gap, dw1, B, C, inter, groups);
-    OCTA_CHECK_LAUNCH("splat_mlp_bwdD");
+    OCTA_CHECK_LAUNCH("splat_mlp_bwdCD");
     return OCTA_OK;
 }
 

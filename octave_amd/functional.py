@@ -57,10 +57,11 @@ def round8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
-def nhwc_empty(B: int, C: int, H: int, W: int, dtype, device, zero: bool = False) -> Tensor:
-    """(B,C,H,W)-shaped tensor with NHWC memory, ld = round8(C); padded channels are zeroed."""
+def nhwc_empty(B: int, C: int, H: int, W: int, dtype, device, zero: bool = False, pad_written: bool = False) -> Tensor:
+    """(B,C,H,W)-shaped tensor with NHWC memory, ld = round8(C); padded channels are zeroed unless the caller's kernel
+    writes them itself (pad_written)."""
     ld = round8(C)
-    mk = torch.zeros if (zero or ld != C) else torch.empty
+    mk = torch.zeros if (zero or (ld != C and not pad_written)) else torch.empty
     buf = mk((B, H, W, ld), dtype=dtype, device=device)
     t = buf.permute(0, 3, 1, 2)
     return t if ld == C else t[:, :C]
@@ -104,11 +105,11 @@ def to_nhwc(x: Tensor, dtype=None, cpad: Optional[int] = None) -> Tensor:
     if ld is not None and x.dtype == dtype and ld >= cpad:
         return x
     src = x if x.dtype == torch.float32 else x.float()
-    out = nhwc_empty(B, max(cpad, C), H, W, dtype, x.device, zero=True)
+    out = nhwc_empty(B, max(cpad, C), H, W, dtype, x.device, pad_written=True)      # the kernel zero-fills channels C .. ld-1
     base = out if out.shape[1] == C else out[:, :C]
     ldo = round8(max(cpad, C))
     lib().octa_nchw_to_nhwc(_p(src), src.stride(0), src.stride(1), src.stride(2), src.stride(3), _p(base), B, C, H, W,
-                            ldo, 0, C, _dt(dtype), _st())
+                            ldo, 0, ldo, _dt(dtype), _st())
     return base
 
 
@@ -135,6 +136,52 @@ def dense_nhwc(x: Tensor) -> Tensor:
     out = nhwc_empty(B, C, H, W, x.dtype, x.device)
     lib().octa_copy_channels(_p(x), H, W, ld, 0, _p(out), H, W, C, 0, B, C, _dt(x), 0, _st())
     return out
+
+
+# ----------------------------------------------------------------------------- zero slab
+class _ZeroSlab:
+    """fp32 scratch slab cleared by ONE launch at the start of a training step.  Ops that need a zero-initialised fp32
+    accumulator (split-attention GAP / logit gradients, ...) take a slice instead of launching a zero fill each
+    (63 launches per step).  Bump allocation, never reused inside a step; inactive outside a TrainStep."""
+
+    def __init__(self, nfloats: int = 4 << 20):
+        self.cap, self.buf, self.off, self.high, self.active = nfloats, None, 0, 0, False
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device)
+            self.high = 0
+        else:
+            n = self.cap if self.high == 0 else min(self.cap, self.high)
+            self.buf[:n].zero_()
+        self.off, self.active = 0, True
+
+    def end(self):
+        self.high = max(self.high, self.off)
+        self.active = False
+
+    def take(self, shape) -> Optional[Tensor]:
+        if not self.active:
+            return None
+        n = 1
+        for v in shape:
+            n *= v
+        a = (self.off + 15) // 16 * 16
+        if a + n > self.cap:
+            return None
+        self.off = a + n
+        return self.buf[a:a + n].view(shape)
+
+
+ZERO_SLAB = _ZeroSlab()
+
+
+def _zeroed_f32(shape, device):
+    """(tensor, prezeroed flag): a slab slice that is already zero, or an uninitialised tensor the kernel must clear."""
+    t = ZERO_SLAB.take(shape)
+    if t is not None and t.device == device:
+        return t, 1
+    return torch.empty(shape, dtype=torch.float32, device=device), 0
 
 
 # ----------------------------------------------------------------------------- packed weights
@@ -621,9 +668,9 @@ def dense_or_same(t: Tensor) -> Tensor:
 def _match_ld(t: Tensor, ld: int) -> Tensor:
     """Copy an NHWC tensor into a fresh buffer with per-pixel stride `ld` (pad zeroed)."""
     B, C, H, W = t.shape
-    out = torch.zeros((B, H, W, ld), dtype=t.dtype, device=t.device).permute(0, 3, 1, 2)[:, :C]
+    out = torch.empty((B, H, W, ld), dtype=t.dtype, device=t.device).permute(0, 3, 1, 2)[:, :C]
     src = to_nchw_f32(t)
-    lib().octa_nchw_to_nhwc(_p(src), src.stride(0), src.stride(1), src.stride(2), src.stride(3), _p(out), B, C, H, W, ld, 0, C,
+    lib().octa_nchw_to_nhwc(_p(src), src.stride(0), src.stride(1), src.stride(2), src.stride(3), _p(out), B, C, H, W, ld, 0, ld,
                             _dt(t), _st())
     return out
 
@@ -980,8 +1027,8 @@ class SplatTailFn(Function):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, inter, 1, 1)}")
         L = lib()
         dev = xr.device
-        gap = torch.empty((B, C), dtype=torch.float32, device=dev)
-        L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), _st())
+        gap, pz = _zeroed_f32((B, C), dev)
+        L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), pz, _st())
         w1, w2 = _dense2d(fc1_w.detach()), _dense2d(fc2_w.detach())
         if w1 is None:
             w1 = fc1_w.detach().float().contiguous()
@@ -1013,8 +1060,8 @@ class SplatTailFn(Function):
         L = lib()
         dev = xr.device
         dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
-        dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
-        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, _st())
+        dlogits, pz = _zeroed_f32((B, 2 * C), dev)
+        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, pz, _st())
         dw1, r_w1 = _grad_buf(fc1_w, True)
         db1f, r_b1f = _grad_buf(fc1_b)
         dg1, r_g1 = _grad_buf(g1)
@@ -1022,11 +1069,11 @@ class SplatTailFn(Function):
         dw2, r_w2 = _grad_buf(fc2_w, True)
         db2, r_b2 = _grad_buf(fc2_b)
         dh1 = torch.empty((B, inter), dtype=torch.float32, device=dev)
-        dgap = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dgap, pzg = _zeroed_f32((B, C), dev)
         L.octa_splat_mlp_bwd(_p(dlogits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap), _p(dw1),
-                             _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, _st())
+                             _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, pzg, _st())
         dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, dev)
-        L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, _st())
+        L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, 0, _st())
         return dx, r_w1, r_b1f, r_g1, r_be1, None, None, r_w2, r_b2, None, None, None, None, None
 
 
@@ -1251,7 +1298,7 @@ class NoiseClipFn(Function):
         _require_gpu(y)
         y = y.float()
         B, C, H, W = y.shape
-        out = nhwc_empty(B, C, H, W, dtype, y.device, zero=True)
+        out = nhwc_empty(B, C, H, W, dtype, y.device, pad_written=True)       # the kernel writes all round8(C) channels
         mask = torch.empty((B, C, H, W), dtype=torch.uint8, device=y.device)
         lib().octa_noise_clip_fwd(_p(y), _strides4(y), _p(noise), _p(out), _p(mask), B, C, H, W, round8(C), round8(C), _dt(dtype), _st())
         ctx.save_for_backward(mask)
@@ -1295,13 +1342,19 @@ class DiscCatFn(Function):
         B, Cs, H, W = s.shape
         Cy = y.shape[1]
         C = Cs + Cy
-        out = nhwc_empty(B, C, H, W, s.dtype, s.device, zero=True)
+        out = nhwc_empty(B, C, H, W, s.dtype, s.device, pad_written=True)
         ld = round8(C)
         L = lib()
-        s32 = to_nchw_f32(s)
-        L.octa_nchw_to_nhwc(_p(s32), s32.stride(0), s32.stride(1), s32.stride(2), s32.stride(3), _p(out), B, Cs, H, W, ld, 0, Cs, _dt(s), _st())
+        lds = nhwc_ld(s)
+        if lds == ld and s.storage_offset() % 8 == 0:
+            # s lives in a buffer of the same padded width (its pad channels are zero): ONE 16-byte-chunk copy of all ld channels,
+            # then the map overwrites channels Cs .. Cs+Cy-1 and zero-fills the rest
+            L.octa_copy_channels(_p(s), H, W, lds, 0, _p(out), H, W, ld, 0, B, ld, _dt(s), 0, _st())
+        else:
+            s32 = to_nchw_f32(s)
+            L.octa_nchw_to_nhwc(_p(s32), s32.stride(0), s32.stride(1), s32.stride(2), s32.stride(3), _p(out), B, Cs, H, W, ld, 0, Cs, _dt(s), _st())
         yf = y.float()
-        L.octa_nchw_to_nhwc(_p(yf), yf.stride(0), yf.stride(1), yf.stride(2), yf.stride(3), _p(out), B, Cy, H, W, ld, Cs, Cy, _dt(s), _st())
+        L.octa_nchw_to_nhwc(_p(yf), yf.stride(0), yf.stride(1), yf.stride(2), yf.stride(3), _p(out), B, Cy, H, W, ld, Cs, ld - Cs, _dt(s), _st())
         ctx.cfg = (Cs, Cy)
         return out
 

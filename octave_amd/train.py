@@ -197,6 +197,7 @@ class TrainStep:
     # (split at the two gradient all-reduces so that the collectives stay OUTSIDE any captured graph)
     def _phase_segmentor(self, x, ys, out):
         self.seg_arena.zero_grad()
+        F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         att, agg, _ = self.seg(x)
         l = F_.wpce_dice(agg, ys, from_logits=True)
         loss = l[0] + l[1] if self.use_dice else l[0]
@@ -219,6 +220,7 @@ class TrainStep:
                 for q in self.disc_arena.params:
                     q.requires_grad_(True)
         out["loss_seg"] = loss.detach()
+        F_.ZERO_SLAB.end()
         flush_bn_counters()
         return [a.detach() for a in att]
 
