@@ -57,15 +57,13 @@ class InstanceNoise(nn.Module):
     def forward(self, x: Tensor, noise_dev: Tensor = None, fed: bool = False):
         """`fed=True`: the (H, W) plane was drawn by the caller (same CPU-generator order) and already lives on
         the device (hipGraph replay); otherwise it is drawn here exactly like the reference."""
-        if not self.clipping:
-            raise NotImplementedError("InstanceNoise without clipping is off the hot path")
         if fed:
             nz = noise_dev if self.is_training else None
         else:
             noise = self.draw()                  # drawn even when not added (ref :150-151)
             nz = noise.to(x.device, non_blocking=True) if self.is_training else None
         dtype = self.compute_dtype or torch.float32
-        return F_.NoiseClipFn.apply(x, nz, dtype)
+        return F_.NoiseClipFn.apply(x, nz, dtype, self.clipping)
 
 
 class LabelNoise(nn.Module):
@@ -77,12 +75,14 @@ class LabelNoise(nn.Module):
         self.mode = mode
 
     def draw_sign(self) -> float:
-        if self.mode != 'sign':
-            raise NotImplementedError("LabelNoise mode 'label' is off the hot path")
         return -1.0 if bool(rand_uniform() < self.prob) else 1.0
 
     def forward(self, x: Tensor):
-        return x * self.draw_sign()
+        if self.mode == 'sign':                      # ref :165-170
+            return x * self.draw_sign()
+        if self.mode == 'label':                     # ref :172-177: |1 - x| with probability prob (one CPU uniform per call)
+            return F_.Abs1mFn.apply(x) if bool(rand_uniform() < self.prob) else x
+        raise NotImplementedError
 
 
 class DiscriminatorBlock(nn.Module):

@@ -13,7 +13,7 @@ from torch import nn
 from torch.nn.modules.utils import _pair
 
 from octave_amd import functional as F_
-from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_counter
+from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_counter, conv_bn
 
 BN_MOMENTUM = 0.1
 
@@ -47,7 +47,7 @@ class SplAtConv2d(nn.Module):
         self.fc2 = Conv2d(inter_channels, channels * radix, 1, groups=self.cardinality)
 
     def forward(self, x, relu_after: bool = False):
-        x = self.bn0(self.conv(x), relu=True)
+        x = conv_bn(self.conv, self.bn0, x, relu=True)
         bn1 = self.bn1
         training = bn1.training
         if training and bn1.num_batches_tracked is not None:
@@ -89,13 +89,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         out = self.conv2(out)
         if self.avd:
             out = F_.avg_pool(out, 3, self.avd_stride, 1)
-        out = self.conv3(out)
         residual = self.downsample(x) if self.downsample is not None else x
-        return self.bn3(out, relu=True, residual=residual)
+        return conv_bn(self.conv3, self.bn3, out, relu=True, residual=residual)
 
 
 class _AvgDown(nn.Module):
@@ -116,9 +115,7 @@ class _ConvBN(nn.Sequential):
     """Sequential whose forward threads the fused-ReLU flag into its trailing BatchNorm."""
 
     def forward(self, x):
-        for m in self:
-            x = m(x)
-        return x
+        return conv_bn(self[1], self[2], self[0](x))
 
 
 class ResNet(nn.Module):
@@ -178,9 +175,9 @@ class ResNet(nn.Module):
 
     def stem(self, x):
         c = self.conv1
-        x = c[1](c[0](x), relu=True)
-        x = c[4](c[3](x), relu=True)
-        return self.bn1(c[6](x), relu=True)
+        x = conv_bn(c[0], c[1], x, relu=True)
+        x = conv_bn(c[3], c[4], x, relu=True)
+        return conv_bn(c[6], self.bn1, x, relu=True)
 
     def forward(self, x):
         raise NotImplementedError("the classification forward of ResNet is off the hot path; the U-Net consumes its stages")
@@ -214,10 +211,10 @@ class ResNestDecoder(nn.Module):
 
     def forward(self, x):
         c = self.conv
-        out = c[1](c[0](x), relu=True)
+        out = conv_bn(c[0], c[1], x, relu=True)
         out = c[3](out, relu_after=True)
-        # residual branch: BN(1x1(x)) + out, then ReLU -- one fused BatchNorm-apply
-        return self.downsample[1](self.downsample[0](x), relu=True, residual=out)
+        # residual branch: BN(1x1(x)) + out, then ReLU -- one fused BatchNorm-apply (training) / folded conv + add (inference)
+        return conv_bn(self.downsample[0], self.downsample[1], x, relu=True, residual=out)
 
 
 class Upsampling(nn.Module):

@@ -26,11 +26,12 @@ class AdversarialAttentionGate(nn.Module):
 
 
 class GlobalAveragePooling2D(nn.Module):
-    """Spatial mean -> (B, C).  Only used by the classification heads (off the hot path); kept so
-    ``ResnestUNet`` registers the same sub-modules as the reference."""
+    """Spatial mean -> (B, C) (ref :349-354), used by the classification heads."""
 
     def __init__(self):
         super().__init__()
 
     def forward(self, x: Tensor):
-        return x.float().mean(dim=(2, 3))
+        if F_.nhwc_ld(x) is not None and x.shape[1] > 1 and x.stride(1) == 1:
+            x = F_.to_nchw_f32(x)                     # NHWC activation -> dense fp32 NCHW
+        return F_.adaptive_avg_pool(x, 1).flatten(1)  # one launch: the (1, 1) adaptive pool is the spatial mean

@@ -1,7 +1,8 @@
 """Mirror of reference architectures/segmentor/losses.py for the hot path: ``WeightedPartialCE``
 (ref :11-61), ``DiceLoss`` (:64-74), ``InterlayerDivergence`` (:90-172).  Each forward is one fused
 reduction on the GPU (ref: 10-30 ATen launches each).  ``ImageMseLoss``/``CELoss`` (thin wrappers over
-torch losses, off the hot path) are not provided.
+torch losses, off the hot path) are not provided.  All branches of the three classes run on HIP kernels: the manual
+WPCE, its nn.CrossEntropyLoss / nn.BCEWithLogitsLoss forms, KLD and JSD.
 """
 import logging
 from typing import Literal, Optional, Sequence
@@ -26,13 +27,25 @@ class WeightedPartialCE(nn.Module):
 
     def forward(self, y_hat: Tensor, ys: Tensor, ignore_bg: bool = False, reduction: Literal['mean', 'sum'] = 'mean', **kwargs) -> Tensor:
         assert y_hat.shape[1] == ys.shape[1], 'Number of class mismatch.'
-        if not self.manual or self.num_classes == 1:
-            raise NotImplementedError("WeightedPartialCE: only manual=True with num_classes >= 2 is on the hot path")
         if reduction not in ('mean', 'sum'):
             raise ValueError(reduction)
         if ignore_bg:
             ys[:, 0] = 0        # in place on the caller's tensor, like ref :29-30
-        return F_.wpce_dice(y_hat, ys, from_logits=False, full=bool(kwargs.get('full', False)), reduction_sum=(reduction == 'sum'))[0]
+        full = bool(kwargs.get('full', False))
+        if self.num_classes == 1:
+            # ref :48-49: nn.BCEWithLogitsLoss()(y_hat * ys, ys); with manual=False the reference first drops every channel of a
+            # one-channel ys (ys[:, 1:]) and fails on the shape -- the same ValueError is raised here
+            if not self.manual:
+                raise ValueError(f"Target size (torch.Size([0])) must be the same as input size ({tuple(y_hat.permute(0, 2, 3, 1).reshape(-1, 1).shape)})")
+            return F_.pixel_ce(y_hat, ys, full=full, mode=1)
+        if not self.manual:
+            # ref :58: nn.CrossEntropyLoss()(masked scores, long(ys[:, 1:])) -- defined for exactly two classes (for more the
+            # flattened target has (C-1) entries per pixel and the reference raises on the batch-size mismatch)
+            if y_hat.shape[1] != 2:
+                n = y_hat.shape[0] * y_hat.shape[2] * y_hat.shape[3]
+                raise ValueError(f"Expected input batch_size ({n}) to match target batch_size ({n * (y_hat.shape[1] - 1)}).")
+            return F_.pixel_ce(y_hat, ys, full=full, mode=0)
+        return F_.wpce_dice(y_hat, ys, from_logits=False, full=full, reduction_sum=(reduction == 'sum'))[0]
 
     def forward_logits(self, logits: Tensor, ys: Tensor, **kwargs) -> Tensor:
         """Same loss on raw logits with the caller's nn.Softmax(dim=1) fused into the kernel."""
@@ -79,5 +92,6 @@ class InterlayerDivergence(nn.Module):
                 raise Exception('Divergence is NaN')
             return out[0]
         elif self.divergence == 'JSD':
-            raise NotImplementedError("JSD branch is off the hot path (SURVEY.md 8f rank 4)")
+            # ref :154-169 (no NaN check and no `mode` there either)
+            return F_.interlayer_jsd(attentions, weights, self.stop_gradient, self.eps)[0]
         raise NotImplementedError(f'Invalid divergence type / Not implemented: {self.divergence}')

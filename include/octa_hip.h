@@ -203,6 +203,50 @@ int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int O
                      int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The rest of the reference's public surface around the hot path, extras.hip.
+ * ---------------------------------------------------------------------------------------- */
+/* InterlayerDivergence, JSD branch (segmentor/losses.py:154-169): mean_q = mean_j w_j resize(Q_j), M = (P + mean_q)/2,
+ * loss = mean_pix sum_k [P/2 (log(P+1e-12) - log(M+eps)) + mean_q/2 (log(mean_q+1e-12) - log(M+eps))].  out[0] = loss,
+ * out[1] = NaN flag; ws: 1024 floats.  bwd: gq_ws is a B*K*H*W fp32 scratch, dbasis may be NULL (stop_gradient). */
+int octa_interlayer_jsd_fwd(const float* basis, const float* const* maps_host, const int* shifts_host,
+                            const float* weights_host, int n_maps, float eps, int B, int K, int H, int W,
+                            float* out, float* ws, octa_stream_t stream);
+int octa_interlayer_jsd_bwd(const float* basis, const float* const* maps_host, const int* shifts_host,
+                            const float* weights_host, int n_maps, float eps, int B, int K, int H, int W,
+                            const float* g, float* dbasis, float* gq_ws, float* const* dmaps_host,
+                            octa_stream_t stream);
+/* WeightedPartialCE's non-manual branches (segmentor/losses.py:40-60) on z = y_hat * ys (or y_hat when full):
+ * mode 0 (2 classes): nn.CrossEntropyLoss()(z, long(ys[:, 1])); mode 1 (1 class): nn.BCEWithLogitsLoss()(z, ys).
+ * out[0] = loss; ws: 1024 floats; din is dense NCHW. */
+int octa_pixel_ce_fwd(const float* in, const int64_t* in_strides, const float* ys, const int64_t* ys_strides, int B,
+                      int K, int H, int W, int full, int mode, float* out, float* ws, octa_stream_t stream);
+int octa_pixel_ce_bwd(const float* in, const int64_t* in_strides, const float* ys, const int64_t* ys_strides, int B,
+                      int K, int H, int W, int full, int mode, const float* g, float* din, octa_stream_t stream);
+/* LabelNoise mode 'label' (discriminator/blocks.py:172-177): out = |1 - x|; with dy: out = d|1-x|/dx * dy. */
+int octa_abs1m(const float* x, const float* dy, float* out, int64_t n, octa_stream_t stream);
+/* ResnestUNet.predict post-processing (segmentor/compose.py:189-199) on (B,K,H,W) logits (any strides):
+ * mode 0: fp32 sigmoid map; mode 1: int64 one-hot of the argmax (first maximum wins, like torch.argmax), and
+ * maxclass[0] (int, zeroed by the caller) = largest argmax seen (F.one_hot sizes its output by it). */
+int octa_predict_map(const float* logits, const int64_t* strides, int B, int K, int H, int W, int mode, void* out,
+                     int* maxclass_zeroed, octa_stream_t stream);
+/* Dice coefficient terms per (sample, class): out[b][k][0] = sum pred*target, out[b][k][1] = sum (pred + target). */
+int octa_dice_terms(const float* pred, const int64_t* pred_strides, const float* target, const int64_t* target_strides,
+                    int B, int K, int H, int W, float* out, octa_stream_t stream);
+/* nn.AdaptiveAvgPool2d on dense NCHW fp32 (classification head, segmentor/compose.py:89): forward (dy == NULL,
+ * out = [BC][OH][OW]) or backward (x may be NULL, out = dx [BC][H][W]). */
+int octa_adaptive_avgpool(const float* x, const float* dy, float* out, int64_t BC, int H, int W, int OH, int OW,
+                          octa_stream_t stream);
+/* Device-side synthetic batch: x (B,3,H,W) grayscale plane replicated to 3 channels, ys (B,2,H,W)
+ * scribbles (~5 % per class, rest unlabelled), real (B,2,H,W) dense one-hot mask; counter-based generator keyed on
+ * (seed, element index).  vessel != 0: curvilinear vessel field instead of white noise. */
+int octa_synth_octa(int64_t seed, int B, int H, int W, int vessel, float* x, float* ys, float* real,
+                    octa_stream_t stream);
+/* Levels 1 .. n-1 of the discriminator's real-mask pyramid (nearest down-sampling by 2^l; the contract of
+ * discriminator/blocks.py:114-125) in one launch; levels_host[0] is ignored (level 0 is `src` itself). */
+int octa_mask_pyramid(const float* src, float* const* levels_host, int n_levels, int64_t BC, int H, int W,
+                      octa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Split attention (extra/resnest.py:106-138), radix 2.
  * ---------------------------------------------------------------------------------------- */
 /* gap[b][c] = mean_hw( x[b,hw,c] + x[b,hw,C+c] )   (fp32 out; resnest.py:108-116).
@@ -312,7 +356,7 @@ int octa_lsgan_bwd(const float* real, const float* fake, int n_real, int n_fake,
  * the clip passed the gradient.  noise may be NULL (is_training False). */
 int octa_noise_clip_fwd(const float* src, const int64_t* src_strides, const float* noise, void* dst,
                         uint8_t* mask, int B, int C, int H, int W, int ld, int cpad, int dtype,
-                        octa_stream_t stream);
+                        int clip /* 0: InstanceNoise(clipping=False), mask all ones */, octa_stream_t stream);
 /* dsrc[b,c,h,w] (dense NCHW fp32) = mask ? ddst[b,h,w,c] : 0 */
 int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask, float* dsrc, int B, int C,
                         int H, int W, int dtype, octa_stream_t stream);

@@ -30,14 +30,14 @@ __global__ __launch_bounds__(256) void noise_clip_fwd_kernel(const float* __rest
     }
 }
 extern "C" int octa_noise_clip_fwd(const float* src, const int64_t* ss, const float* noise, void* dst, uint8_t* mask, int B, int C, int H, int W,
-                                   int ld, int cpad, int dtype, octa_stream_t stream) {
+                                   int ld, int cpad, int dtype, int clip, octa_stream_t stream) {
     OCTA_REQUIRE(src && ss && dst && cpad >= C && cpad <= ld, "octa_noise_clip_fwd: bad arguments");
     Strides4 s{ss[0], ss[1], ss[2], ss[3]};
     const int64_t total = (int64_t)B * H * W;
     const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == OCTA_F32) noise_clip_fwd_kernel<float><<<blocks, 256, 0, st>>>(src, s, noise, (float*)dst, mask, B, C, H, W, ld, cpad, 1);
-    else if (dtype == OCTA_BF16) noise_clip_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>(src, s, noise, (bf16_t*)dst, mask, B, C, H, W, ld, cpad, 1);
+    if (dtype == OCTA_F32) noise_clip_fwd_kernel<float><<<blocks, 256, 0, st>>>(src, s, noise, (float*)dst, mask, B, C, H, W, ld, cpad, clip);
+    else if (dtype == OCTA_BF16) noise_clip_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>(src, s, noise, (bf16_t*)dst, mask, B, C, H, W, ld, cpad, clip);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_noise_clip_fwd: bad dtype");
     OCTA_CHECK_LAUNCH("noise_clip_fwd");
     return OCTA_OK;

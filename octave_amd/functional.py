@@ -708,6 +708,17 @@ def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv:
     return y, mean, invstd, x, mask
 
 
+def raw_bn_apply_only(x: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, relu: bool, residual: Optional[Tensor]) -> Tensor:
+    """y = (x - mean) * invstd * gamma + beta [+ residual] [-> relu] with GIVEN per-channel vectors (inference)."""
+    x = to_nhwc(x)
+    B, C, H, W = x.shape
+    y = nhwc_empty(B, C, H, W, x.dtype, x.device)
+    res = to_nhwc(residual, dtype=x.dtype) if residual is not None else None
+    lib().octa_bn_apply(_p(x), nhwc_ld(x), 0, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
+                        _p(y), nhwc_ld(y), 0, B * H * W, C, _dt(x), int(relu), None, _st())
+    return y
+
+
 def raw_bn_bwd(dy: Tensor, x: Tensor, y: Optional[Tensor], mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool,
                want_dres: bool, dgamma: Tensor, dbeta: Tensor, mask: Optional[Tensor] = None):
     B, C, H, W = x.shape
@@ -1294,13 +1305,13 @@ class NoiseClipFn(Function):
     """InstanceNoise (+clip) on an NCHW fp32 map, emitting the NHWC activation (blocks.py:149-154)."""
 
     @staticmethod
-    def forward(ctx, y, noise, dtype):
+    def forward(ctx, y, noise, dtype, clip=True):
         _require_gpu(y)
         y = y.float()
         B, C, H, W = y.shape
         out = nhwc_empty(B, C, H, W, dtype, y.device, pad_written=True)       # the kernel writes all round8(C) channels
         mask = torch.empty((B, C, H, W), dtype=torch.uint8, device=y.device)
-        lib().octa_noise_clip_fwd(_p(y), _strides4(y), _p(noise), _p(out), _p(mask), B, C, H, W, round8(C), round8(C), _dt(dtype), _st())
+        lib().octa_noise_clip_fwd(_p(y), _strides4(y), _p(noise), _p(out), _p(mask), B, C, H, W, round8(C), round8(C), _dt(dtype), int(bool(clip)), _st())
         ctx.save_for_backward(mask)
         return out
 
@@ -1312,7 +1323,7 @@ class NoiseClipFn(Function):
         d = to_nhwc(d)
         g = torch.empty((B, C, H, W), dtype=torch.float32, device=d.device)
         lib().octa_noise_clip_bwd(_p(d), nhwc_ld(d), _p(mask), _p(g), B, C, H, W, _dt(d), _st())
-        return g, None, None
+        return g, None, None, None
 
 
 class ToNhwcFn(Function):
@@ -1434,6 +1445,191 @@ class FullConvFn(Function):
         return dx, dw, db, None, None
 
 
-def fill_(t: Tensor, value: float):
-    t.fill_(value)
-    return t
+# ----------------------------------------------------------------------------- the rest of the public surface
+class InterlayerJSDFn(Function):
+    """InterlayerDivergence, JSD branch (segmentor/losses.py:154-169) with the nearest up-sampling fused."""
+
+    @staticmethod
+    def forward(ctx, weights, stop_gradient, eps, basis, *maps):
+        _require_gpu(basis)
+        basis = basis.float().contiguous()
+        B, K, H, W = basis.shape
+        use = [(m.float().contiguous(), float(w)) for m, w in zip(maps, weights) if w != 0]
+        shifts = []
+        for m, _ in use:
+            f = H // m.shape[2]
+            if f < 1 or f & (f - 1) or m.shape[2] * f != H or m.shape[3] * f != W:
+                raise OctaError(f"interlayer JSD: map {tuple(m.shape)} is not a power-of-two reduction of {tuple(basis.shape)}")
+            shifts.append(f.bit_length() - 1)
+        n = len(use)
+        ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m, _ in use])
+        sh = (ctypes.c_int * n)(*shifts)
+        wt = (ctypes.c_float * n)(*[w for _, w in use])
+        out = torch.empty((2,), dtype=torch.float32, device=basis.device)
+        ws = torch.empty((1024,), dtype=torch.float32, device=basis.device)
+        lib().octa_interlayer_jsd_fwd(_p(basis), ptrs, sh, wt, n, float(eps), B, K, H, W, _p(out), _p(ws), _st())
+        ctx.cfg = (shifts, [w for _, w in use], float(eps), stop_gradient, [i for i, w in enumerate(weights[:len(maps)]) if w != 0], len(maps))
+        ctx.save_for_backward(basis, *[m for m, _ in use])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        basis, *use = ctx.saved_tensors
+        shifts, wts, eps, stop_gradient, idx, nmaps = ctx.cfg
+        B, K, H, W = basis.shape
+        g0 = g.float().contiguous()
+        n = len(use)
+        dmaps = [torch.empty_like(m) for m in use]
+        ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in use])
+        dptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in dmaps])
+        sh = (ctypes.c_int * n)(*shifts)
+        wt = (ctypes.c_float * n)(*wts)
+        dbasis = None if stop_gradient else torch.empty_like(basis)
+        gq = torch.empty_like(basis)
+        lib().octa_interlayer_jsd_bwd(_p(basis), ptrs, sh, wt, n, eps, B, K, H, W, _p(g0), _p(dbasis), _p(gq), dptrs, _st())
+        grads: List[Optional[Tensor]] = [None] * nmaps
+        for i, d in zip(idx, dmaps):
+            grads[i] = d
+        return (None, None, None, dbasis, *grads)
+
+
+def interlayer_jsd(attentions: Sequence[Tensor], weights, stop_gradient=False, eps=1e-12) -> Tensor:
+    """returns a (2,) tensor: [loss, nan_flag]."""
+    return InterlayerJSDFn.apply(list(weights), stop_gradient, eps, attentions[0], *attentions[1:])
+
+
+class PixelCEFn(Function):
+    """WeightedPartialCE's nn.CrossEntropyLoss (mode 0, 2 classes) / nn.BCEWithLogitsLoss (mode 1, 1 class) branches
+    (segmentor/losses.py:40-60) on the masked scores y_hat * ys."""
+
+    @staticmethod
+    def forward(ctx, y_hat, ys, full, mode):
+        _require_gpu(y_hat)
+        y_hat, ys = y_hat.float(), ys.float()
+        B, K, H, W = y_hat.shape
+        out = torch.empty((2,), dtype=torch.float32, device=y_hat.device)
+        ws = torch.empty((1024,), dtype=torch.float32, device=y_hat.device)
+        lib().octa_pixel_ce_fwd(_p(y_hat), _strides4(y_hat), _p(ys), _strides4(ys), B, K, H, W, int(full), mode, _p(out), _p(ws), _st())
+        ctx.cfg = (int(full), mode)
+        ctx.save_for_backward(y_hat, ys)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y_hat, ys = ctx.saved_tensors
+        B, K, H, W = y_hat.shape
+        g = g.float().contiguous().view(1)
+        din = torch.empty((B, K, H, W), dtype=torch.float32, device=y_hat.device)
+        lib().octa_pixel_ce_bwd(_p(y_hat), _strides4(y_hat), _p(ys), _strides4(ys), B, K, H, W, ctx.cfg[0], ctx.cfg[1], _p(g), _p(din), _st())
+        return din, None, None, None
+
+
+def pixel_ce(y_hat, ys, full=False, mode=0):
+    return PixelCEFn.apply(y_hat, ys, full, mode)
+
+
+class Abs1mFn(Function):
+    """|1 - x| (LabelNoise mode 'label', discriminator/blocks.py:172-177)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xf = x.float().contiguous()
+        out = torch.empty_like(xf)
+        lib().octa_abs1m(_p(xf), None, _p(out), xf.numel(), _st())
+        ctx.save_for_backward(xf)
+        ctx.dtype = x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (xf,) = ctx.saved_tensors
+        gf = g.float().contiguous()
+        out = torch.empty_like(xf)
+        lib().octa_abs1m(_p(xf), _p(gf), _p(out), xf.numel(), _st())
+        return out.to(ctx.dtype)
+
+
+def predict_sigmoid(logits: Tensor) -> Tensor:
+    """nn.Sigmoid()(agg_map) (segmentor/compose.py:193) -> dense fp32 NCHW."""
+    _require_gpu(logits)
+    logits = logits.float()
+    B, K, H, W = logits.shape
+    out = torch.empty((B, K, H, W), dtype=torch.float32, device=logits.device)
+    lib().octa_predict_map(_p(logits), _strides4(logits), B, K, H, W, 0, _p(out), None, _st())
+    return out
+
+
+def predict_one_hot(logits: Tensor) -> Tensor:
+    """rearrange(F.one_hot(torch.argmax(agg_map, dim=1)), 'b h w c -> b c h w') (segmentor/compose.py:195): int64, first maximum
+    wins, and -- like F.one_hot without num_classes -- the channel count is 1 + the largest class that occurs."""
+    _require_gpu(logits)
+    logits = logits.float()
+    B, K, H, W = logits.shape
+    out = torch.empty((B, K, H, W), dtype=torch.int64, device=logits.device)
+    mx = torch.zeros((1,), dtype=torch.int32, device=logits.device)
+    lib().octa_predict_map(_p(logits), _strides4(logits), B, K, H, W, 1, _p(out), _p(mx), _st())
+    return out[:, :int(mx.item()) + 1]      # F.one_hot itself synchronises on the maximum
+
+
+def dice_coefficient(pred: Tensor, target: Tensor, eps: float = 1e-12) -> Tensor:
+    """Dice coefficient 2 |A.B| / (|A| + |B|) per (sample, class) -> (B, K) fp32 (the metric the paper reports; one launch)."""
+    _require_gpu(pred)
+    pred, target = pred.float(), target.float()
+    B, K, H, W = pred.shape
+    terms = torch.empty((B, K, 2), dtype=torch.float32, device=pred.device)
+    lib().octa_dice_terms(_p(pred), _strides4(pred), _p(target), _strides4(target), B, K, H, W, _p(terms), _st())
+    return 2.0 * terms[..., 0] / (terms[..., 1] + eps)
+
+
+class AdaptiveAvgPoolFn(Function):
+    """nn.AdaptiveAvgPool2d on a dense NCHW fp32 map (classification head, segmentor/compose.py:89)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        _require_gpu(x)
+        x = x.float().contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        lib().octa_adaptive_avgpool(_p(x), None, _p(y), B * C, H, W, OH, OW, _st())
+        ctx.cfg = (B, C, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, C, H, W, OH, OW = ctx.cfg
+        dy = dy.float().contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        lib().octa_adaptive_avgpool(None, _p(dy), _p(dx), B * C, H, W, OH, OW, _st())
+        return dx, None, None
+
+
+def adaptive_avg_pool(x, output_size):
+    OH, OW = (output_size, output_size) if isinstance(output_size, int) else output_size
+    return AdaptiveAvgPoolFn.apply(x, OH, OW)
+
+
+def synth_octa_batch(B: int, H: int, W: int, seed: int, device, vessel: bool = False):
+    """Device-side synthetic batch: x (B,3,H,W), scribbles ys (B,2,H,W), dense real mask (B,2,H,W), fp32 NCHW."""
+    x = torch.empty((B, 3, H, W), dtype=torch.float32, device=device)
+    ys = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+    real = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+    _require_gpu(x)
+    lib().octa_synth_octa(int(seed), B, H, W, int(vessel), _p(x), _p(ys), _p(real), _st())
+    return x, ys, real
+
+
+def mask_pyramid_dense(mask: Tensor, levels: int = 5) -> List[Tensor]:
+    """The discriminator's real pyramid (nearest down-sampling by 2**i; contract of discriminator/blocks.py:114-125) as DENSE
+    tensors written by one launch (the strided-view form costs a gather per level and per use)."""
+    _require_gpu(mask)
+    mask = mask.float().contiguous()
+    B, C, H, W = mask.shape
+    outs = [mask] + [torch.empty((B, C, H >> l, W >> l), dtype=torch.float32, device=mask.device) for l in range(1, levels)]
+    ptrs = (ctypes.c_void_p * levels)(*[o.data_ptr() for o in outs])
+    lib().octa_mask_pyramid(_p(mask), ptrs, levels, B * C, H, W, _st())
+    return outs

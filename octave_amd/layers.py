@@ -1,11 +1,13 @@
 """nn.Module leaves whose forward runs on libocta_hip.so.  They subclass the torch modules only to
 inherit parameter registration, initialisation and state_dict layout (identical keys/shapes to the
 reference); no ATen compute kernel is called in their forward."""
+import weakref
+
 import torch
 from torch import nn
 
 from . import functional as F_
-from ._lib import ACT_NONE
+from ._lib import ACT_NONE, ACT_RELU
 
 
 # num_batches_tracked bookkeeping: per-call `add_(1)` is one tiny ATen launch per BatchNorm (93 per step).
@@ -101,3 +103,80 @@ def use_channels_last_weights(module: nn.Module) -> nn.Module:
             if isinstance(m, (Conv2d, ConvTranspose2d)):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
     return module
+
+
+# ----------------------------------------------------------------------------- inference: BatchNorm folded into the conv
+# Eval-mode conv -> BatchNorm (-> ReLU) is ONE conv launch: the running statistics are folded into the weights
+# (w' = w * gamma / sqrt(var + eps) per output channel) and into a bias (b' = (b - mean) * gamma / sqrt(var + eps) + beta)
+# when the operand is packed; the folded parameters are rebuilt only when a weight, an affine parameter or a running
+# statistic changes (version counters).  Training mode and grad-enabled eval go through the unfused layers.
+_FOLD_CACHE = {}
+_IDENT = {}
+
+
+def _fold_entry(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    key = (id(conv.weight), id(bn.running_mean))
+    w, cb = conv.weight, conv.bias
+    tag = (w._version, F_._WEIGHT_EPOCH, w.data_ptr(), bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version,
+           None if cb is None else cb._version, bn.eps)
+    e = _FOLD_CACHE.get(key)
+    if e is not None and e[0] == tag and e[3]() is w and e[4]() is bn:
+        return e[1], e[2]
+    with torch.no_grad():
+        scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        wf = (w.detach().float() * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+        base = -bn.running_mean.float() if cb is None else (cb.detach().float() - bn.running_mean.float())
+        bf = (base * scale + bn.bias.float()).contiguous()
+    # a Parameter object so that the pack cache of functional.py keys on its identity (packed once per fold)
+    wp = nn.Parameter(wf, requires_grad=False)
+    _FOLD_CACHE[key] = (tag, wp, bf, weakref.ref(w), weakref.ref(bn))
+    return wp, bf
+
+
+def _identity_stats(C: int, device):
+    k = (C, str(device))
+    t = _IDENT.get(k)
+    if t is None:
+        t = (torch.zeros(C, device=device), torch.ones(C, device=device))
+        _IDENT[k] = t
+    return t
+
+
+def conv_bn(conv: "Conv2d", bn: "BatchNorm2d", x, relu: bool = False, residual=None):
+    """bn(conv(x)) [+ residual] [-> relu].  Training: the two fused-statistics layers.  Inference (eval mode, no grad): one conv
+    launch with the BatchNorm folded into its packed weights and bias (+ one add/ReLU pass when there is a residual)."""
+    if bn.training or bn.running_mean is None or torch.is_grad_enabled():
+        return bn(conv(x), relu=relu, residual=residual)
+    wf, bf = _fold_entry(conv, bn)
+    act = ACT_RELU if (relu and residual is None) else ACT_NONE
+    if conv.act != ACT_NONE:
+        raise NotImplementedError("conv_bn: the conv already has a fused activation")
+    y = F_.conv2d(x, wf, bf, conv.stride[0], conv.padding[0], conv.groups, act)
+    if residual is None:
+        return y
+    zero, one = _identity_stats(y.shape[1], y.device)
+    # (y - 0) * 1 * 1 + 0 + residual -> relu: the BatchNorm-apply kernel with identity statistics is the add(+ReLU) pass
+    return F_.raw_bn_apply_only(y, zero, one, one, zero, relu, residual)
+
+
+class Linear(nn.Linear):
+    """nn.Linear as a 1x1 conv on the MFMA engine (classification heads, segmentor/compose.py:85,97): same parameters/keys."""
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise NotImplementedError("octave_amd.Linear: (B, features) input")
+        y = F_.conv2d(x.view(x.shape[0], x.shape[1], 1, 1), self.weight.view(self.out_features, self.in_features, 1, 1), self.bias)
+        return F_.to_nchw_f32(y).view(x.shape[0], self.out_features)
+
+
+class AdaptiveAvgPool2d(nn.Module):
+    """nn.AdaptiveAvgPool2d on dense fp32 NCHW maps (classification head)."""
+
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        if F_.nhwc_ld(x) is not None and x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 1:
+            x = F_.to_nchw_f32(x)
+        return F_.adaptive_avg_pool(x, self.output_size)

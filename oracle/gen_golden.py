@@ -371,6 +371,122 @@ def gen_trainstep():
     _save("trainstep_48.npz", d)
 
 
+def gen_extras():
+    """Fixtures for the rest of the public surface and for parity at a BASELINE size:
+    reference state_dict layouts, eval-mode inference (logits / softmax / sigmoid / one-hot), classification heads,
+    the dual-head U-Nets, the non-manual WPCE branches, LabelNoise 'label', InstanceNoise without clipping."""
+    from architectures.discriminator.blocks import InstanceNoise, LabelNoise
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.compose import ResnestUnetParallelHead, ResnestUnetParallelHeadAttentionGate
+    from architectures.segmentor.losses import WeightedPartialCE
+    d = {}
+    # (1) state_dict layouts dumped from the reference itself
+    net = OctaScribbleNet(torch.Size((2, 3, 48, 48)), torch.Size((2, 2, 48, 48)), True, False)
+    sd = net.state_dict()
+    d["layout/octa/keys"] = np.array(list(sd.keys()))
+    d["layout/octa/shapes"] = np.array([",".join(str(v) for v in t.shape) for t in sd.values()])
+    for tag, cls in (("ph", ResnestUnetParallelHead), ("phag", ResnestUnetParallelHeadAttentionGate)):
+        m = cls(2, False)
+        sdm = m.state_dict()
+        d[f"layout/{tag}/keys"] = np.array(list(sdm.keys()))
+        d[f"layout/{tag}/shapes"] = np.array([",".join(str(v) for v in t.shape) for t in sdm.values()])
+    # (2) eval-mode inference, 48 (odd H/16) and 64 (even)
+    for H in (48, 64):
+        B = 2
+        x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), False, False)
+        fill_state_dict(net.state_dict())
+        net.eval()
+        with torch.no_grad():
+            att, agg, x4 = net.segmentor(x)
+            d[f"eval{H}/agg"] = _np(agg)
+            for i, a in enumerate(att):
+                d[f"eval{H}/att{i}"] = _np(a)
+            d[f"eval{H}/softmax"] = _np(net.segmentor.predict(x, "softmax")[1])
+            d[f"eval{H}/sigmoid"] = _np(net.segmentor.predict(x, "sigmoid")[1])
+            d[f"eval{H}/onehot"] = _np(net.segmentor.predict(x, "one-hot")[1]).astype(np.uint8)
+            net64 = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), False, False)
+            fill_state_dict(net64.state_dict())
+            net64 = net64.double().eval()
+            d[f"eval{H}/agg_f64"] = _np(net64.segmentor(x.double())[1])
+            if H == 48:
+                # (3) classification heads (compose.py:201-230)
+                for mode in ("classic", "ae-squash", "ae-extract"):
+                    for method in ("softmax", "sigmoid"):
+                        cp, _, pred = net.segmentor.classification_predict(x, method, mode)
+                        d[f"cls/{mode}/{method}"] = _np(cp)
+                d["cls/predicate"] = _np(pred)
+    # (4) dual-head U-Nets, train mode, B = 3, 48x48, fp32 + float64 twin
+    B, H = 3, 48
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    for tag, cls, kw in (("ph", ResnestUnetParallelHead, {}), ("phag", ResnestUnetParallelHeadAttentionGate, {"gating_leveL": 3})):
+        for suffix, dt in (("", torch.float32), ("_f64", torch.float64)):
+            m = cls(2, False, **kw)
+            fill_state_dict(m.state_dict())
+            m = m.to(dt).train()
+            with torch.no_grad():
+                out = m(x.to(dt))
+            if tag == "ph":
+                d[f"{tag}/agg{suffix}"] = _np(out)
+            else:
+                (att, att_c), agg = out
+                d[f"{tag}/agg{suffix}"] = _np(agg)
+                d[f"{tag}/n_att"] = np.array([len(att), len(att_c)])
+                for i, a in enumerate(att):
+                    d[f"{tag}/att{i}{suffix}"] = _np(a)
+                for i, a in enumerate(att_c):
+                    d[f"{tag}/att_c{i}{suffix}"] = _np(a)
+    # (5) WPCE non-manual branches
+    Bq, C, Hq, Wq = 3, 2, 16, 16
+    p = F.softmax(3.0 * hash_input((Bq, C, Hq, Wq), 21, -1, 1), dim=1).requires_grad_(True)
+    u = hash_input((Bq, 1, Hq, Wq), 22)
+    ys = torch.zeros(Bq, C, Hq, Wq)
+    ys[:, 1:2] = (u < 0.08).float()
+    ys[:, 0:1] = ((u > 0.3) & (u < 0.4)).float()
+    for tag, kw in (("ce", {}), ("ce_full", {"full": True})):
+        pp = p.detach().clone().requires_grad_(True)
+        l = WeightedPartialCE(num_classes=2, manual=False)(pp, ys.clone(), **kw)
+        l.backward()
+        d[f"wpce_{tag}/loss"], d[f"wpce_{tag}/grad"] = _np(l), _np(pp.grad)
+    z1 = (2.0 * hash_input((Bq, 1, Hq, Wq), 27, -1, 1)).requires_grad_(True)
+    t1 = (hash_input((Bq, 1, Hq, Wq), 28) < 0.3).float()
+    l = WeightedPartialCE(num_classes=1, manual=True)(z1, t1)
+    l.backward()
+    d["wpce_bce/loss"], d["wpce_bce/grad"] = _np(l), _np(z1.grad)
+    # (6) LabelNoise 'label' (flip forced / never) and InstanceNoise without clipping
+    xl = hash_input((4, 1), 44, -0.5, 1.5).requires_grad_(True)
+    yl = LabelNoise(prob=2.0, mode="label")(xl)
+    (yl * hash_input((4, 1), 45, -1, 1)).sum().backward()
+    d["labelflip/out"], d["labelflip/grad"] = _np(yl), _np(xl.grad)
+    d["labelkeep/out"] = _np(LabelNoise(prob=-1.0, mode="label")(xl))
+    torch.manual_seed(11)
+    xin = hash_input((2, 2, 8, 8), 46, -0.2, 1.2)
+    d["noise_noclip/out"] = _np(InstanceNoise(torch.Size((2, 2, 8, 8)), 0.0, 0.2, False, True)(xin))
+    torch.manual_seed(11)
+    d["noise_noclip/noise"] = _np(torch.normal(mean=0.0, std=0.2, size=(8, 8)))
+    _save("extras.npz", d)
+
+
+def gen_unet304():
+    """BASELINE config-1 size: B = 2, 304 x 304, fp32, train mode -- logits and their float64 twin (stored as float32: its
+    rounding, 2e-6 absolute, is three orders below the reference's own fp32-vs-fp64 band)."""
+    from architectures.models.octa import OctaScribbleNet
+    B, H = 2, 304
+    d = {}
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net.train()
+    with torch.no_grad():
+        d["agg"] = _np(net.segmentor(x)[1])
+    net64 = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+    fill_state_dict(net64.state_dict())
+    net64 = net64.double().train()
+    with torch.no_grad():
+        d["agg_f64_as_f32"] = _np(net64.segmentor(x.double())[1]).astype(np.float32)
+    _save("unet_304.npz", d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}")
@@ -378,7 +494,7 @@ if __name__ == "__main__":
     _install_standins()
     torch.set_num_threads(8)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep"]
+    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304"]
     if "blocks" in which:
         gen_blocks()
     if "losses" in which:
@@ -389,3 +505,7 @@ if __name__ == "__main__":
         gen_unet()
     if "trainstep" in which:
         gen_trainstep()
+    if "extras" in which:
+        gen_extras()
+    if "unet304" in which:
+        gen_unet304()

@@ -346,3 +346,90 @@ def discriminator_loss(P: State, real_pyr: Sequence[Tensor], att: Sequence[Tenso
     d_real = discriminator_forward(real_pyr, P, noise=noise_r, flip=flip_r)
     d_fake = discriminator_forward([a.detach() for a in att], P, noise=noise_f, flip=flip_f)
     return ls_discriminator_loss(d_real, d_fake)
+
+
+# --------------------------------------------------------------------------- #
+# the rest of the public surface
+# --------------------------------------------------------------------------- #
+def weighted_partial_ce_ce(y_hat: Tensor, ys: Tensor, full: bool = False) -> Tensor:
+    """WeightedPartialCE.forward with manual=False and two classes, segmentor/losses.py:40-45,56-58:
+    nn.CrossEntropyLoss on the masked scores with target long(ys[:, 1])."""
+    z = y_hat if full else y_hat * ys                                      # :31-32
+    z = z.permute(0, 2, 3, 1).reshape(-1, z.shape[1])                      # :43
+    t = ys[:, 1:].permute(0, 2, 3, 1).reshape(-1).long()                   # :41,45
+    return F.cross_entropy(z, t)                                           # :58
+
+
+def weighted_partial_ce_bce(y_hat: Tensor, ys: Tensor, full: bool = False) -> Tensor:
+    """WeightedPartialCE.forward with num_classes == 1 (manual=True), segmentor/losses.py:48-49."""
+    z = y_hat if full else y_hat * ys
+    return F.binary_cross_entropy_with_logits(z.permute(0, 2, 3, 1).reshape(-1, 1), ys.permute(0, 2, 3, 1).reshape(-1, 1))
+
+
+def label_noise_label(x: Tensor, flip: bool) -> Tensor:
+    """LabelNoise.flip_label, discriminator/blocks.py:172-177."""
+    return torch.abs(1.0 - x) if flip else x
+
+
+def instance_noise(x: Tensor, noise: Tensor, clipping: bool, is_training: bool = True) -> Tensor:
+    """InstanceNoise.forward, discriminator/blocks.py:149-154."""
+    out = x + noise.to(x.dtype) if is_training else x
+    return torch.clip(out, 0, 1) if clipping else out
+
+
+def classification_predict(x: Tensor, P: State, method: str, mode: str, prefix: str = "segmentor", training: bool = False):
+    """ResnestUNet.classification_predict, segmentor/compose.py:201-230 (encoder_gating=False)."""
+    p = prefix + "." if prefix else ""
+    att, agg, latent = resnest_unet_forward(x, P, prefix, training=training)
+    pred = F.softmax(agg, dim=1)                                           # :210
+    if mode == "classic":
+        emb = F.linear(latent.mean(dim=(2, 3)), P[p + "linear_head_emb.1.weight"], P[p + "linear_head_emb.1.bias"])  # :82-85
+    elif mode == "ae-squash":
+        emb = pred.mean(dim=(2, 3))                                        # :215
+    elif mode == "ae-extract":                                             # :88-98
+        e = F.adaptive_avg_pool2d(pred, (32, 32))
+        e = F.relu(F.conv2d(e, P[p + "linear_head_dec.1.weight"], P[p + "linear_head_dec.1.bias"]))
+        e = batch_norm(e, P, p + "linear_head_dec.3", training)
+        e = F.relu(F.conv2d(e, P[p + "linear_head_dec.4.weight"], P[p + "linear_head_dec.4.bias"]))
+        e = batch_norm(e, P, p + "linear_head_dec.6", training)
+        emb = F.linear(e.mean(dim=(2, 3)), P[p + "linear_head_dec.8.weight"], P[p + "linear_head_dec.8.bias"])
+    else:
+        raise NotImplementedError
+    cls = F.softmax(emb, dim=1) if method == "softmax" else torch.sigmoid(emb)   # :222-225
+    return cls, att, pred
+
+
+def parallel_head_forward(x: Tensor, P: State, gates: bool, gating_level: int = 3, training: bool = True):
+    """ResnestUnetParallelHead.forward (segmentor/compose.py:292-346) / ResnestUnetParallelHeadAttentionGate.forward
+    (:440-513): returns (attentions, attentions_c, stacked logits)."""
+    x_0_0 = stem(x, P, "encoder_0_1_2", training)
+    x_0_1 = F.max_pool2d(x_0_0, 3, 2, 1)
+    x_1 = encoder_stage(x_0_1, P, "encoder_1", 0, training)
+    x_2 = encoder_stage(x_1, P, "encoder_2", 1, training)
+    x_3 = encoder_stage(x_2, P, "encoder_3", 2, training)
+    pad_h, pad_w = x_3.shape[2] % 2 == 1, x_3.shape[3] % 2 == 1
+    if pad_h or pad_w:
+        x_3 = F.pad(x_3, (0, int(pad_w), 0, int(pad_h)))
+    x_4 = encoder_stage(x_3, P, "encoder_4", 3, training)
+    att, att_c = [], []
+
+    def gate(d, name, on, lst):
+        if gates and on:
+            d, y = attention_gate(d, P, name)
+            lst.append(y)
+        return d
+    d = torch.cat((x_3, upsampling(x_4, P, "upsampling_4")), dim=1)
+    d = d[:, :, :d.shape[2] - int(pad_h), :d.shape[3] - int(pad_w)]
+    d = gate(resnest_decoder(d, P, "decoder_4", training), "aag_4", gating_level > 3, att)      # :473
+    for lvl, skip in ((3, x_2), (2, x_1), (1, x_0_0)):
+        d = resnest_decoder(torch.cat((skip, upsampling(d, P, f"upsampling_{lvl}")), dim=1), P, f"decoder_{lvl}", training)
+        d = gate(d, f"aag_{lvl}", gating_level >= lvl, att)
+    d = gate(resnest_decoder(upsampling(d, P, "upsampling_0"), P, "decoder_0", training), "aag_0", gating_level >= 0, att)
+    dc = resnest_decoder(torch.cat((x_0_0, upsampling(x_1, P, "upsampling_1_c")), dim=1), P, "decoder_1_c", training)   # :332-334
+    dc = gate(dc, "aag_1_c", gating_level >= 1, att_c)
+    dc = gate(resnest_decoder(upsampling(dc, P, "upsampling_0_c"), P, "decoder_0_c", training), "aag_0_c", gating_level >= 0, att_c)
+    att.reverse()
+    att_c.reverse()
+    agg = F.conv2d(d, P["fc.weight"], P["fc.bias"])
+    agg_c = F.conv2d(dc, P["fc_c.weight"], P["fc_c.bias"])
+    return tuple(att), tuple(att_c), torch.stack((agg, agg_c), 0)

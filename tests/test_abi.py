@@ -72,6 +72,11 @@ def test_module_state_dict_matches_reference_layout():
     mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     want = octa_state_shapes(48)
     assert mine == dict(want)
+    # ... and equal to the key / shape list dumped from the reference itself (tests/golden/extras.npz, oracle/gen_golden.py extras)
+    import numpy as np, os
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "extras.npz"), allow_pickle=False) as z:
+        assert list(mine.keys()) == z["layout/octa/keys"].tolist()
+        assert [",".join(str(v) for v in s) for s in mine.values()] == z["layout/octa/shapes"].tolist()
     assert sum(p.numel() for p in net.segmentor.parameters()) == 73056784
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1))

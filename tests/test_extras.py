@@ -1,0 +1,287 @@
+"""The rest of the reference's public surface and parity at a BASELINE size.
+
+CPU part: the oracle (oracle/ref_ops.py) against fixtures generated from the reference (tests/golden/extras.npz,
+unet_304.npz; generator: oracle/gen_golden.py extras unet304).  GPU part (-m gpu): the HIP path against the same fixtures."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_ops as R
+from oracle.fill import fill_state_dict, hash_input
+
+
+def _close(name, got, want, tol):
+    got = np.asarray(got.detach().cpu() if isinstance(got, torch.Tensor) else got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    err = np.abs(got - want).max() if got.size else 0.0
+    assert np.isfinite(got).all() and err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (scale {np.abs(want).max():.3e})"
+
+
+def _loss_inputs():
+    Bq, C, Hq, Wq = 3, 2, 16, 16
+    p = F.softmax(3.0 * hash_input((Bq, C, Hq, Wq), 21, -1, 1), dim=1)
+    u = hash_input((Bq, 1, Hq, Wq), 22)
+    ys = torch.zeros(Bq, C, Hq, Wq)
+    ys[:, 1:2] = (u < 0.08).float()
+    ys[:, 0:1] = ((u > 0.3) & (u < 0.4)).float()
+    z1 = 2.0 * hash_input((Bq, 1, Hq, Wq), 27, -1, 1)
+    t1 = (hash_input((Bq, 1, Hq, Wq), 28) < 0.3).float()
+    return p, ys, z1, t1
+
+
+# ----------------------------------------------------------------------------------------- CPU: layouts + oracle
+def test_state_dict_layouts_match_reference_dump(golden):
+    """Keys, shapes AND order of every network's state_dict equal the lists dumped from the reference itself."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.compose import ResnestUnetParallelHead, ResnestUnetParallelHeadAttentionGate
+    G = golden("extras.npz")
+    nets = {"octa": OctaScribbleNet(torch.Size((2, 3, 48, 48)), torch.Size((2, 2, 48, 48)), True, False),
+            "ph": ResnestUnetParallelHead(2, False), "phag": ResnestUnetParallelHeadAttentionGate(2, False)}
+    for tag, net in nets.items():
+        sd = net.state_dict()
+        assert list(sd.keys()) == G[f"layout/{tag}/keys"].tolist(), tag
+        assert [",".join(str(v) for v in t.shape) for t in sd.values()] == G[f"layout/{tag}/shapes"].tolist(), tag
+
+
+def test_oracle_extra_losses_and_noise(golden):
+    G = golden("extras.npz")
+    p, ys, z1, t1 = _loss_inputs()
+    for tag, full in (("ce", False), ("ce_full", True)):
+        pp = p.clone().requires_grad_(True)
+        l = R.weighted_partial_ce_ce(pp, ys, full)
+        l.backward()
+        _close(f"oracle wpce_{tag}", l, G[f"wpce_{tag}/loss"], 1e-6)
+        _close(f"oracle wpce_{tag} grad", pp.grad, G[f"wpce_{tag}/grad"], 1e-7)
+    z = z1.clone().requires_grad_(True)
+    l = R.weighted_partial_ce_bce(z, t1)
+    l.backward()
+    _close("oracle bce", l, G["wpce_bce/loss"], 1e-6)
+    _close("oracle bce grad", z.grad, G["wpce_bce/grad"], 1e-7)
+    xl = hash_input((4, 1), 44, -0.5, 1.5)
+    _close("oracle label flip", R.label_noise_label(xl, True), G["labelflip/out"], 1e-7)
+    _close("oracle label keep", R.label_noise_label(xl, False), G["labelkeep/out"], 0)
+    xin = hash_input((2, 2, 8, 8), 46, -0.2, 1.2)
+    _close("oracle noise no clip", R.instance_noise(xin, torch.from_numpy(G["noise_noclip/noise"]), False), G["noise_noclip/out"], 1e-7)
+
+
+def _eval_state(H, B=2, training_ctor=False):
+    from architectures.models.octa import OctaScribbleNet
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), training_ctor, False)
+    fill_state_dict(net.state_dict())
+    return net
+
+
+def test_oracle_eval_inference_and_heads(golden):
+    G = golden("extras.npz")
+    H, B = 48, 2
+    net = _eval_state(H)
+    P = {k: v.clone() for k, v in net.state_dict().items()}
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        att, agg, _ = R.resnest_unet_forward(x, P, training=False)
+        _close("oracle eval agg", agg, G["eval48/agg"], 2e-4 * float(np.abs(G["eval48/agg"]).max()))
+        _close("oracle eval sigmoid", R.predict(agg, "sigmoid"), G["eval48/sigmoid"], 1e-4)
+        for mode in ("classic", "ae-squash", "ae-extract"):
+            for method in ("softmax", "sigmoid"):
+                cp, _, _ = R.classification_predict(x, P, method, mode)
+                _close(f"oracle cls {mode}/{method}", cp, G[f"cls/{mode}/{method}"], 2e-4)
+
+
+def test_oracle_parallel_heads(golden):
+    from architectures.segmentor.compose import ResnestUnetParallelHeadAttentionGate
+    G = golden("extras.npz")
+    B, H = 3, 48
+    m = ResnestUnetParallelHeadAttentionGate(2, False)
+    fill_state_dict(m.state_dict())
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        att, att_c, agg = R.parallel_head_forward(x, P, gates=True, gating_level=3)
+    assert [len(att), len(att_c)] == G["phag/n_att"].tolist()
+    noise = float(np.abs(G["phag/agg"] - G["phag/agg_f64"]).max())
+    e64 = float(np.abs(agg.numpy().astype(np.float64) - G["phag/agg_f64"]).max())
+    assert e64 <= 4 * noise + 1e-4 * float(np.abs(G["phag/agg"]).max()), (e64, noise)
+
+
+# ----------------------------------------------------------------------------------------- GPU: HIP path
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the MI355X (run with -m gpu on the GPU box)")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_hip_jsd_vs_reference(dev, golden):
+    from architectures.segmentor.losses import InterlayerDivergence
+    G = golden("losses.npz")
+    B, C = 3, 2
+
+    def probs(seed, shape):
+        return F.softmax(3.0 * hash_input(shape, seed, -1, 1), dim=1)
+    att = [probs(30 + i, (B, C, 32 >> max(i - 1, 0), 32 >> max(i - 1, 0))).to(dev).requires_grad_(True) for i in range(6)]
+    l = InterlayerDivergence(divergence="JSD")(att)
+    l.backward()
+    _close("jsd loss", l, G["jsd/loss"], 1e-6 + 1e-5 * abs(float(G["jsd/loss"])))
+    for i, a in enumerate(att):
+        _close(f"jsd grad{i}", a.grad, G[f"jsd/grad{i}"], 1e-8 + 1e-4 * float(np.abs(G[f"jsd/grad{i}"]).max()))
+
+
+@pytest.mark.gpu
+def test_hip_wpce_branches_and_noise_modes(dev, golden):
+    from architectures.discriminator.blocks import InstanceNoise, LabelNoise
+    from architectures.segmentor.losses import WeightedPartialCE
+    G = golden("extras.npz")
+    p, ys, z1, t1 = _loss_inputs()
+    for tag, kw in (("ce", {}), ("ce_full", {"full": True})):
+        pp = p.to(dev).requires_grad_(True)
+        l = WeightedPartialCE(num_classes=2, manual=False)(pp, ys.to(dev), **kw)
+        l.backward()
+        _close(f"wpce_{tag}", l, G[f"wpce_{tag}/loss"], 1e-5)
+        _close(f"wpce_{tag} grad", pp.grad, G[f"wpce_{tag}/grad"], 1e-7)
+    z = z1.to(dev).requires_grad_(True)
+    l = WeightedPartialCE(num_classes=1, manual=True)(z, t1.to(dev))
+    l.backward()
+    _close("wpce bce", l, G["wpce_bce/loss"], 1e-5)
+    _close("wpce bce grad", z.grad, G["wpce_bce/grad"], 1e-7)
+    with pytest.raises(ValueError):
+        WeightedPartialCE(num_classes=3, manual=False)(torch.rand(1, 3, 4, 4, device=dev), torch.zeros(1, 3, 4, 4, device=dev))
+    xl = hash_input((4, 1), 44, -0.5, 1.5).to(dev).requires_grad_(True)
+    yl = LabelNoise(prob=2.0, mode="label")(xl)
+    (yl * hash_input((4, 1), 45, -1, 1).to(dev)).sum().backward()
+    _close("label flip", yl, G["labelflip/out"], 1e-7)
+    _close("label flip grad", xl.grad, G["labelflip/grad"], 1e-7)
+    _close("label keep", LabelNoise(prob=-1.0, mode="label")(xl), G["labelkeep/out"], 0)
+    torch.manual_seed(11)
+    xin = hash_input((2, 2, 8, 8), 46, -0.2, 1.2).to(dev)
+    out = InstanceNoise(torch.Size((2, 2, 8, 8)), 0.0, 0.2, False, True)(xin)
+    _close("instance noise without clipping", out, G["noise_noclip/out"], 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [48, 64])
+def test_hip_eval_inference_folded_bn(dev, golden, H):
+    """Eval-mode forward (BatchNorm folded into the conv operands), predict() post-processing and the Dice metric against
+    the reference in .eval().  No train-mode BatchNorm -> no chaotic amplification: 1e-4 of the logit scale holds end to end,
+    and the one-hot mask is bit-exact outside the float64-anchored rounding band."""
+    from octave_amd import functional as F_
+    G = golden("extras.npz")
+    B = 2
+    net = _eval_state(H).to(dev).eval()
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        att, agg, _ = net.segmentor(x)
+        scale = float(np.abs(G[f"eval{H}/agg"]).max())
+        noise = float(np.abs(G[f"eval{H}/agg"] - G[f"eval{H}/agg_f64"]).max())
+        e64 = float(np.abs(agg.cpu().numpy().astype(np.float64) - G[f"eval{H}/agg_f64"]).max())
+        print(f"[eval {H}] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} scale {scale:.2f}")
+        assert e64 <= 4 * noise + 1e-4 * scale
+        _close("eval logits", agg, G[f"eval{H}/agg"], 1e-4 * scale + 5 * noise)
+        for i, a in enumerate(att):
+            _close(f"eval att{i}", a, G[f"eval{H}/att{i}"], 2e-4)
+        _close("predict softmax", net.segmentor.predict(x, "softmax")[1], G[f"eval{H}/softmax"], 2e-4)
+        _close("predict sigmoid", net.segmentor.predict(x, "sigmoid")[1], G[f"eval{H}/sigmoid"], 2e-4)
+        oh = net.segmentor.predict(x, "one-hot")[1]
+        assert oh.dtype == torch.int64 and tuple(oh.shape) == tuple(G[f"eval{H}/onehot"].shape)
+        margin = np.abs(G[f"eval{H}/agg_f64"][:, 0] - G[f"eval{H}/agg_f64"][:, 1])
+        safe = margin > 10 * noise + 1e-4 * scale
+        got = oh.cpu().numpy().astype(np.uint8)
+        assert safe.mean() > 0.95 and np.array_equal(got[:, 1][safe], G[f"eval{H}/onehot"][:, 1][safe])
+        # Dice coefficient of the HIP mask against the reference's mask: 1 up to the band pixels
+        dice = F_.dice_coefficient(oh.float(), torch.from_numpy(G[f"eval{H}/onehot"].astype(np.float32)).to(dev))
+        assert float(dice.min()) > 1 - 1e-3, dice
+        # folded conv+BN was really used: the fold cache holds one entry per conv/BN pair that ran
+        from octave_amd import layers
+        assert len(layers._FOLD_CACHE) >= 60
+
+
+@pytest.mark.gpu
+def test_hip_classification_heads(dev, golden):
+    G = golden("extras.npz")
+    H, B = 48, 2
+    net = _eval_state(H).to(dev).eval()
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        for mode in ("classic", "ae-squash", "ae-extract"):
+            for method in ("softmax", "sigmoid"):
+                cp, att, pred = net.segmentor.classification_predict(x, method, mode)
+                _close(f"cls {mode}/{method}", cp, G[f"cls/{mode}/{method}"], 5e-4)
+        _close("cls predicate", pred, G["cls/predicate"], 2e-4)
+        with pytest.raises(ValueError):
+            net.segmentor.classification_predict(x, "softmax", "classic-gating")
+
+
+@pytest.mark.gpu
+def test_hip_parallel_head_unets(dev, golden):
+    from architectures.segmentor.compose import ResnestUnetParallelHead, ResnestUnetParallelHeadAttentionGate
+    G = golden("extras.npz")
+    B, H = 3, 48
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+    for tag, cls, kw in (("ph", ResnestUnetParallelHead, {}), ("phag", ResnestUnetParallelHeadAttentionGate, {"gating_leveL": 3})):
+        m = cls(2, False, **kw)
+        fill_state_dict(m.state_dict())
+        m = m.to(dev).train()
+        with torch.no_grad():
+            out = m(x)
+        agg = out if tag == "ph" else out[1]
+        noise = float(np.abs(G[f"{tag}/agg"] - G[f"{tag}/agg_f64"]).max())
+        scale = float(np.abs(G[f"{tag}/agg"]).max())
+        e64 = float(np.abs(agg.cpu().numpy().astype(np.float64) - G[f"{tag}/agg_f64"]).max())
+        print(f"[{tag}] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} scale {scale:.2f}")
+        assert tuple(agg.shape) == tuple(G[f"{tag}/agg"].shape) and e64 <= 4 * noise + 1e-4 * scale
+        if tag == "phag":
+            (att, att_c) = out[0]
+            assert [len(att), len(att_c)] == G["phag/n_att"].tolist()
+            for i, a in enumerate(att):
+                n_i = float(np.abs(G[f"phag/att{i}"] - G[f"phag/att{i}_f64"]).max())
+                _close(f"phag att{i}", a, G[f"phag/att{i}_f64"], 4 * n_i + 1e-4)
+            for i, a in enumerate(att_c):
+                n_i = float(np.abs(G[f"phag/att_c{i}"] - G[f"phag/att_c{i}_f64"]).max())
+                _close(f"phag att_c{i}", a, G[f"phag/att_c{i}_f64"], 4 * n_i + 1e-4)
+            pred = m.predict(x, "one-hot")[1]
+            assert pred.shape[0] == 2 and pred.shape[1] == B and pred.dtype == torch.int64
+
+
+@pytest.mark.gpu
+def test_hip_unet_304_vs_reference(dev, golden):
+    """BASELINE config-1 size (B = 2, 304 x 304, fp32, train mode): logits against the reference under the float64-anchored
+    noise-band rule of the 48 / 64 tests."""
+    from architectures.models.octa import OctaScribbleNet
+    G = golden("unet_304.npz")
+    B, H = 2, 304
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        agg = net.segmentor(x)[1].cpu().numpy()
+    ref32, ref64 = G["agg"], G["agg_f64_as_f32"].astype(np.float64)
+    noise = float(np.abs(ref32 - ref64).max())
+    scale = float(np.abs(ref32).max())
+    e64 = float(np.abs(agg.astype(np.float64) - ref64).max())
+    print(f"[unet 304] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} scale {scale:.1f}")
+    assert e64 <= 4 * noise + 1e-4 * scale, (e64, noise)
+    margin = np.abs(ref64[:, 0] - ref64[:, 1])
+    safe = margin > 10 * noise
+    assert np.array_equal(np.argmax(agg, 1)[safe], np.argmax(ref32, 1)[safe])
+
+
+@pytest.mark.gpu
+def test_device_side_synthetic_batch_and_pyramid(dev):
+    from octave_amd import functional as F_
+    B, H = 4, 64
+    x, ys, real = F_.synth_octa_batch(B, H, H, seed=1234, device=dev)
+    x2, _, _ = F_.synth_octa_batch(B, H, H, seed=1234, device=dev)
+    assert torch.equal(x, x2), "the generator is a pure function of (seed, index)"
+    assert x.shape == (B, 3, H, H) and torch.equal(x[:, 0], x[:, 1]) and torch.equal(x[:, 0], x[:, 2])
+    assert 0.0 <= float(x.min()) and float(x.max()) < 1.0 and 0.45 < float(x.mean()) < 0.55
+    assert set(torch.unique(ys).tolist()) <= {0.0, 1.0} and float((ys[:, 0] * ys[:, 1]).sum()) == 0.0
+    assert 0.03 < float(ys[:, 1].mean()) < 0.07 and 0.03 < float(ys[:, 0].mean()) < 0.07
+    assert torch.equal(real.sum(1), torch.ones(B, H, H, device=dev)) and 0.15 < float(real[:, 1].mean()) < 0.25
+    pyr = F_.mask_pyramid_dense(real, 5)
+    for i, p in enumerate(pyr):
+        assert torch.equal(p, real[:, :, ::2 ** i, ::2 ** i]), i       # == the contract of discriminator/blocks.py:114-125
+    xv, ysv, realv = F_.synth_octa_batch(B, H, H, seed=7, device=dev, vessel=True)
+    assert 0.05 < float(realv[:, 1].mean()) < 0.6 and float((ysv[:, 1] * realv[:, 0]).sum()) == 0.0
