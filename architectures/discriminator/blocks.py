@@ -97,6 +97,7 @@ class DiscriminatorBlock(nn.Module):
         self.depth = depth
         self.compute_dtype = None
         self.rng_feed = None       # optional: object with next_noise()/next_sign() returning DEVICE tensors (octave_amd.train)
+        self.input_hw = (int(input_shape[2]), int(input_shape[3]))
         in_channels = input_shape[1]
         modules = []
         if instance_noise:
@@ -125,6 +126,19 @@ class DiscriminatorBlock(nn.Module):
             modules.append(LabelNoise(0.1, 'sign'))
         self.out = nn.Sequential(*modules)
         self._has_label_noise = label_noise
+
+    def share_body_with(self, other: "DiscriminatorBlock") -> "DiscriminatorBlock":
+        """Mixed-resolution training (BASELINE config 5): the reference's block is tied to ONE resolution -- its full-extent
+        head conv (ref :68-72) and the InstanceNoise plane (ref :42) are sized by `input_shape` -- so a second resolution
+        needs a second block.  This makes `self` use `other`'s conv stack (first conv, squeeze and spectral-norm convs incl.
+        their u / v buffers) so that only the head `out.0` is resolution-specific.  Returns self."""
+        if (self.depth, self.num_filters, self._has_noise) != (other.depth, other.num_filters, other._has_noise):
+            raise ValueError("share_body_with: the two discriminators must have the same depth / width / noise configuration")
+        i = 1 if self._has_noise else 0
+        self.stack_0[i] = other.stack_0[i]
+        self.squeeze_dict = other.squeeze_dict
+        self.spectral_dict = other.spectral_dict
+        return self
 
     def _discriminator(self, in_channels, num_squeeze_filters: int, num_fake_channels: int, num_sn_filters: int, sn_kernel_size: int,
                        num_sn_stride: int, sn_padding: int):

@@ -29,6 +29,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, Na
     return (bf16_t)(u >> 16);
 }
 
+struct f16_t { unsigned short v; };   // raw IEEE half bits; a distinct type (bf16_t is a plain unsigned short) so that templates can specialise
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // round-to-nearest-even, saturates to inf
+
 template <typename T> struct DT;
 template <> struct DT<float> {
     static constexpr int EPC = 4;  // elements per 16-byte chunk
@@ -41,6 +45,20 @@ template <> struct DT<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct DT<f16_t> {
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->v); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f2h(v); }
+};
+// two fp32 values -> one dword of two 16-bit elements of T
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) { return (unsigned)f2h(a) | ((unsigned)f2h(b) << 16); }
+template <typename T> struct DTName;
+template <> struct DTName<float> { static constexpr const char* v = "f32"; };
+template <> struct DTName<bf16_t> { static constexpr const char* v = "bf16"; };
+template <> struct DTName<f16_t> { static constexpr const char* v = "f16"; };
+
 // unpack a 16-byte chunk into EPC floats / pack back
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& c, float* f);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& c, float* f) {
@@ -51,6 +69,12 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& c, flo
     f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
     f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
     f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& c, float* f) {
+    f[0] = h2f((unsigned short)(c.x & 0xffffu)); f[1] = h2f((unsigned short)(c.x >> 16));
+    f[2] = h2f((unsigned short)(c.y & 0xffffu)); f[3] = h2f((unsigned short)(c.y >> 16));
+    f[4] = h2f((unsigned short)(c.z & 0xffffu)); f[5] = h2f((unsigned short)(c.z >> 16));
+    f[6] = h2f((unsigned short)(c.w & 0xffffu)); f[7] = h2f((unsigned short)(c.w >> 16));
 }
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
@@ -64,6 +88,17 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
     c.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
     return c;
 }
+
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
+    return make_uint4(pack2<f16_t>(f[0], f[1]), pack2<f16_t>(f[2], f[3]), pack2<f16_t>(f[4], f[5]), pack2<f16_t>(f[6], f[7]));
+}
+// three-way dtype dispatch: `using T` inside the braces
+#define OCTA_DISPATCH3(dtype, NAME, ...)                                                     \
+    if ((dtype) == OCTA_F32) { using T = float; __VA_ARGS__ }                                \
+    else if ((dtype) == OCTA_BF16) { using T = bf16_t; __VA_ARGS__ }                         \
+    else if ((dtype) == OCTA_F16) { using T = f16_t; __VA_ARGS__ }                           \
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, NAME ": bad dtype %d", (int)(dtype));
+#define OCTA_DTYPE_OK(dtype) ((dtype) == OCTA_F32 || (dtype) == OCTA_BF16 || (dtype) == OCTA_F16)
 
 // ---------------------------------------------------------------- reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {

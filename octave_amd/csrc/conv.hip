@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -48,6 +49,11 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
@@ -597,8 +603,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
 // tools/pmc_traffic.py (bench.py attributes its per-launch timings with it instead of re-implementing the dispatcher).
 static thread_local char g_last_kernel[96] = "";
 template <typename T> static void note_kernel(const char* family, int bm, int bn) {
-    if (bn > 0) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%dx%d>", family, sizeof(T) == 2 ? "bf16" : "f32", bm, bn);
-    else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%d>", family, sizeof(T) == 2 ? "bf16" : "f32", bm);
+    if (bn > 0) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%dx%d>", family, DTName<T>::v, bm, bn);
+    else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,%d>", family, DTName<T>::v, bm);
 }
 extern "C" const char* octa_last_conv_kernel(void) { return g_last_kernel; }
 void octa_note_conv_kernel(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
@@ -671,7 +677,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             const double gf = 2.0 * (double)a.M * a.Ng * a.Kc * 8.0 * groups * 1e-9;
             if (gf >= thr && a.Cg % 64 == 0) want = (a.Ng >= 256) ? 3 : 2;
         }
-        if ((want == 2 || want == 3) && launch_igemm8(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
+        if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
     }
     if (conv_variant() >= 1) {
         const bool done = a.mode == 0 ? launch_halo<T, 0>(a, groups, st) : launch_halo<T, 1>(a, groups, st);
@@ -716,7 +722,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
 
 static int check_desc(const octa_conv_desc* d, const char* who) {
     OCTA_REQUIRE(d != nullptr, "%s: null descriptor", who);
-    OCTA_REQUIRE(d->dtype == OCTA_F32 || d->dtype == OCTA_BF16, "%s: bad dtype %d", who, d->dtype);
+    OCTA_REQUIRE(OCTA_DTYPE_OK(d->dtype), "%s: bad dtype %d", who, d->dtype);
     OCTA_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0, "%s: bad image dims", who);
     OCTA_REQUIRE(d->groups > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0, "%s: channels not divisible by groups", who);
     OCTA_REQUIRE(d->cin_g_pad % 8 == 0 && d->cin_g_pad >= d->Cin / d->groups, "%s: cin_g_pad %d invalid", who, d->cin_g_pad);
@@ -752,7 +758,8 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     if (d->upshuffle) OCTA_REQUIRE(d->ldy >= a.CoutT + d->yoff, "octa_conv2d_fwd: ldy too small for upshuffle");
     else OCTA_REQUIRE(d->ldy >= d->Cout + d->yoff, "octa_conv2d_fwd: ldy %d < yoff+Cout", d->ldy);
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
-                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo);
+         : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
+                                 : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
 }
 
 extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
@@ -776,7 +783,8 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
-                                : launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo);
+         : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
+                                 : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -812,6 +820,7 @@ static int pack_common(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, in
     const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
     if (dtype == OCTA_F32) pack_weight_kernel<float><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (float*)packed, Cout_g, Cin_g, KH, KW, groups, pad_to, transposed);
     else if (dtype == OCTA_BF16) pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (bf16_t*)packed, Cout_g, Cin_g, KH, KW, groups, pad_to, transposed);
+    else if (dtype == OCTA_F16) pack_weight_kernel<f16_t><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (f16_t*)packed, Cout_g, Cin_g, KH, KW, groups, pad_to, transposed);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_pack_weight: bad dtype %d", dtype);
     OCTA_CHECK_LAUNCH("pack_weight");
     return OCTA_OK;
@@ -846,6 +855,9 @@ template <typename T> __device__ __forceinline__ void pack_store8(T* dst, const 
 template <> __device__ __forceinline__ void pack_store8<float>(float* dst, const float (&v)[8]) {
     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
     *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void pack_store8<f16_t>(f16_t* dst, const float (&v)[8]) {
+    *(uint4*)dst = make_uint4(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]), pack2<f16_t>(v[4], v[5]), pack2<f16_t>(v[6], v[7]));
 }
 template <> __device__ __forceinline__ void pack_store8<bf16_t>(bf16_t* dst, const float (&v)[8]) {
     uint4 o;
@@ -937,7 +949,7 @@ __device__ __forceinline__ void pack_tile_transpose(const octa_pack_desc& d, uns
             T* dst = (T*)d.dst + drow * d.pad_to + c;
             const float a = tile[c4][rl], b = tile[c4 + 1][rl], cc = tile[c4 + 2][rl], dd = tile[c4 + 3][rl];
             if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(a, b, cc, dd);
-            else *(uint2*)dst = make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(cc) | ((unsigned)f2bf(dd) << 16));
+            else *(uint2*)dst = make_uint2(pack2<T>(a, b), pack2<T>(cc, dd));
         }
     }
     __syncthreads();
@@ -951,9 +963,9 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const octa_pack_desc* __
         const octa_pack_desc d = desc[lo];
         const unsigned tl = (unsigned)(tb - prefix[lo]);
         if (d.kind == 1 || d.kind == 2) {
-            if (d.dtype == OCTA_F32) pack_tile_transpose<float>(d, tl, tile); else pack_tile_transpose<bf16_t>(d, tl, tile);
+            if (d.dtype == OCTA_F32) pack_tile_transpose<float>(d, tl, tile); else if (d.dtype == OCTA_BF16) pack_tile_transpose<bf16_t>(d, tl, tile); else pack_tile_transpose<f16_t>(d, tl, tile);
         } else {
-            if (d.dtype == OCTA_F32) pack_tile_linear<float>(d, tl); else pack_tile_linear<bf16_t>(d, tl);
+            if (d.dtype == OCTA_F32) pack_tile_linear<float>(d, tl); else if (d.dtype == OCTA_BF16) pack_tile_linear<bf16_t>(d, tl); else pack_tile_linear<f16_t>(d, tl);
         }
     }
 }
@@ -987,6 +999,7 @@ extern "C" int octa_pack_weight_convT(const float* w, int64_t s_ci, int64_t s_co
     const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
     if (dtype == OCTA_F32) pack_convT_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_ci, s_co, s_h, s_w, (float*)packed, CinT, CoutT, cin_pad);
     else if (dtype == OCTA_BF16) pack_convT_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_ci, s_co, s_h, s_w, (bf16_t*)packed, CinT, CoutT, cin_pad);
+    else if (dtype == OCTA_F16) pack_convT_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_ci, s_co, s_h, s_w, (f16_t*)packed, CinT, CoutT, cin_pad);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_pack_weight_convT: bad dtype");
     OCTA_CHECK_LAUNCH("pack_convT");
     return OCTA_OK;
@@ -1018,6 +1031,7 @@ template <> struct WgLds<bf16_t> {   // [32 m][128 cols] bf16, 256-B rows, 32-B 
         return m * ROWB + ((((c >> 1) ^ f)) << 5) + ((c & 1) << 4);
     }
 };
+template <> struct WgLds<f16_t> : WgLds<bf16_t> {};
 template <> struct WgLds<float> {    // [16 m][128 cols] fp32, rows padded to 144 floats
     static constexpr int MT = 16, ROWB = 576;
     __device__ static __forceinline__ int chunk_off(int m, int c) { return m * ROWB + c * 16; }
@@ -1158,7 +1172,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TK; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf[i]), __builtin_bit_cast(bf16x8_t, qf[j]), acc[i][j], 0, 0, 0);
+                    Mma<T>::run(pf[i], qf[j], acc[i][j]);
         } else {
 #pragma unroll
             for (int s = 0; s < MT / 4; ++s) {
@@ -1451,7 +1465,8 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
         return OCTA_OK;
     }
     return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
-                                : launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream);
+         : d->dtype == OCTA_BF16 ? launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream)
+                                 : launch_wgrad<f16_t>(a, d->groups, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1493,6 +1508,7 @@ extern "C" int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, in
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) col2im_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
     else if (dtype == OCTA_BF16) col2im_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
+    else if (dtype == OCTA_F16) col2im_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)z, ldz, (f16_t*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_col2im: bad dtype");
     OCTA_CHECK_LAUNCH("col2im");
     return OCTA_OK;
@@ -1570,7 +1586,7 @@ __global__ __launch_bounds__(1024) void colsum_fold_kernel(const float* __restri
 extern "C" size_t octa_colsum_workspace_floats(int C) { return (size_t)2048 * (size_t)((C + 7) / 8 * 8); }
 extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off, int dtype, float* out, float* part, octa_stream_t stream) {
     OCTA_REQUIRE(src && out && rows > 0 && C > 0, "octa_colsum: bad arguments");
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_colsum: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_colsum: bad dtype");
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     if (C % epc == 0 && ld % epc == 0 && off % epc == 0 && ((size_t)src & 15) == 0) {
         const int cpr = C / epc;
@@ -1582,7 +1598,8 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
         dim3 grid(cdiv(cpr, TX), (unsigned)cdiv64(rows, rpb));
         if (grid.y < 64) part = nullptr;                  // few blocks: plain atomics are cheaper than a second launch
         if (dtype == OCTA_F32) colsum_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
-        else colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
+        else if (dtype == OCTA_BF16) colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
+        else colsum_vec_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
         if (part) colsum_fold_kernel<<<cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>(part, (int)grid.y, C, out);
         OCTA_CHECK_LAUNCH("colsum_vec");
         return OCTA_OK;
@@ -1592,6 +1609,7 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
     dim3 grid(cdiv(C, 64), (unsigned)cdiv64(rows, rpb)), block(64, 4);
     if (dtype == OCTA_F32) colsum_kernel<float><<<grid, block, 0, (hipStream_t)stream>>>((const float*)src, rows, C, ld, off, out, rpb);
     else if (dtype == OCTA_BF16) colsum_kernel<bf16_t><<<grid, block, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, C, ld, off, out, rpb);
+    else if (dtype == OCTA_F16) colsum_kernel<f16_t><<<grid, block, 0, (hipStream_t)stream>>>((const f16_t*)src, rows, C, ld, off, out, rpb);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_colsum: bad dtype");
     OCTA_CHECK_LAUNCH("colsum");
     return OCTA_OK;

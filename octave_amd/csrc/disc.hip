@@ -38,6 +38,7 @@ extern "C" int octa_noise_clip_fwd(const float* src, const int64_t* ss, const fl
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) noise_clip_fwd_kernel<float><<<blocks, 256, 0, st>>>(src, s, noise, (float*)dst, mask, B, C, H, W, ld, cpad, clip);
     else if (dtype == OCTA_BF16) noise_clip_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>(src, s, noise, (bf16_t*)dst, mask, B, C, H, W, ld, cpad, clip);
+    else if (dtype == OCTA_F16) noise_clip_fwd_kernel<f16_t><<<blocks, 256, 0, st>>>(src, s, noise, (f16_t*)dst, mask, B, C, H, W, ld, cpad, clip);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_noise_clip_fwd: bad dtype");
     OCTA_CHECK_LAUNCH("noise_clip_fwd");
     return OCTA_OK;
@@ -64,6 +65,7 @@ extern "C" int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) noise_clip_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)ddst, ld, mask, dsrc, B, C, H, W);
     else if (dtype == OCTA_BF16) noise_clip_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)ddst, ld, mask, dsrc, B, C, H, W);
+    else if (dtype == OCTA_F16) noise_clip_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)ddst, ld, mask, dsrc, B, C, H, W);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_noise_clip_bwd: bad dtype");
     OCTA_CHECK_LAUNCH("noise_clip_bwd");
     return OCTA_OK;
@@ -223,6 +225,7 @@ extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bia
     dim3 grid(nblk, B);
     if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, sign_dev, nblk);
     else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, sign_dev, nblk);
+    else if (dtype == OCTA_F16) fullconv_fwd_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, w, out, n, sign, sign_dev, nblk);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_fwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_fwd");
     return OCTA_OK;
@@ -256,6 +259,7 @@ extern "C" int octa_fullconv_bwd(const void* x, const float* w, const float* dou
     const int blocks = (int)(cdiv64(n, 256) > 2048 ? 2048 : cdiv64(n, 256));
     if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev);
     else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev);
+    else if (dtype == OCTA_F16) fullconv_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, w, dout, (f16_t*)dx, dw, dbias, B, n, sign, sign_dev);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_bwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_bwd");
     return OCTA_OK;

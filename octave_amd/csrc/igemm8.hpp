@@ -29,6 +29,11 @@ __device__ __forceinline__ void ig8_load_sub(unsigned abase, unsigned bbase, ig8
 }
 
 template <typename T> struct Mma8;
+template <> struct Mma8<f16_t> {
+    __device__ static __forceinline__ void run(const ig8_u32x4_t& a, const ig8_u32x4_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
 template <> struct Mma8<bf16_t> {
     __device__ static __forceinline__ void run(const ig8_u32x4_t& a, const ig8_u32x4_t& b, f32x4_t& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
             }
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
-                *(uint2*)dst = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
 }
 
 // eligibility + launch; variant 0: 256(M) x 128(N), 1: 128(M) x 256(N).  Returns false when the legacy kernels must run.
+template <typename T>
 static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_t st) {
     if (a.KH * a.KW > 32) return false;
     if (a.mode == 1 && a.stride != 1) return false;
@@ -228,14 +234,14 @@ static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_
     if (a.Cg % 64 != 0) return false;                     // whole 128-byte lines per tap: at most one tap wrap per K step
     if (variant == 0) {
         dim3 grid(cdiv(a.M, 256), cdiv(a.Ng, 128), groups);
-        if (a.mode == 0) conv_igemm8_kernel<bf16_t, 4, 2, 0><<<grid, 512, 0, st>>>(a);
-        else conv_igemm8_kernel<bf16_t, 4, 2, 1><<<grid, 512, 0, st>>>(a);
-        note_kernel<bf16_t>("conv_igemm8_kernel", 256, 128);
+        if (a.mode == 0) conv_igemm8_kernel<T, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+        else conv_igemm8_kernel<T, 4, 2, 1><<<grid, 512, 0, st>>>(a);
+        note_kernel<T>("conv_igemm8_kernel", 256, 128);
     } else {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 256), groups);
-        if (a.mode == 0) conv_igemm8_kernel<bf16_t, 2, 4, 0><<<grid, 512, 0, st>>>(a);
-        else conv_igemm8_kernel<bf16_t, 2, 4, 1><<<grid, 512, 0, st>>>(a);
-        note_kernel<bf16_t>("conv_igemm8_kernel", 128, 256);
+        if (a.mode == 0) conv_igemm8_kernel<T, 2, 4, 0><<<grid, 512, 0, st>>>(a);
+        else conv_igemm8_kernel<T, 2, 4, 1><<<grid, 512, 0, st>>>(a);
+        note_kernel<T>("conv_igemm8_kernel", 128, 256);
     }
     return true;
 }

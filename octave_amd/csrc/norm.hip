@@ -179,7 +179,7 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
                              float* invstd, float* running_mean, float* running_var, float* ws, octa_stream_t stream) {
     OCTA_REQUIRE(x && mean && invstd && ws, "octa_bn_stats: null pointer");
     OCTA_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && off % 8 == 0, "octa_bn_stats: C/ld/off must be multiples of 8 (C=%d ld=%d off=%d)", C, ld, off);
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_bn_stats: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_bn_stats: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     const ColMap cm = col_map(C / epc);
@@ -189,8 +189,10 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     const size_t sh = (size_t)256 * epc * 3 * sizeof(float);
     if (dtype == OCTA_F32)
         bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
-    else
+    else if (dtype == OCTA_BF16)
         bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
+    else
+        bn_reduce_kernel<f16_t, 0><<<grid, 256, sh, st>>>((const f16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(stats)");
     bn_stats_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
     OCTA_CHECK_LAUNCH("bn_stats_finalize");
@@ -256,6 +258,8 @@ extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean
         bn_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu, relu_mask);
     else if (dtype == OCTA_BF16)
         bn_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
+    else if (dtype == OCTA_F16)
+        bn_apply_kernel<f16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const f16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const f16_t*)residual, ldr, roff, (f16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_bn_apply: bad dtype");
     OCTA_CHECK_LAUNCH("bn_apply");
     return OCTA_OK;
@@ -332,7 +336,7 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     OCTA_REQUIRE(!relu || y || relu_mask, "octa_bn_bwd: relu needs the forward output or the mask octa_bn_apply wrote");
     OCTA_REQUIRE(C % 8 == 0 && lddy % 8 == 0 && dyoff % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddx % 8 == 0 && dxoff % 8 == 0,
                  "octa_bn_bwd: C/ld/off must be multiples of 8");
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_bn_bwd: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_bn_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     const ColMap cm = col_map(C / epc);
@@ -343,15 +347,19 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     float* fin = ws + (size_t)1026 * 2 * C;
     if (dtype == OCTA_F32)
         bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
-    else
+    else if (dtype == OCTA_BF16)
         bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
+    else
+        bn_reduce_kernel<f16_t, 1><<<grid, 256, sh, st>>>((const f16_t*)x, ldx, xoff, (const f16_t*)dy, lddy, dyoff, (const f16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
     OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");
     if (dtype == OCTA_F32)
         bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
-    else
+    else if (dtype == OCTA_BF16)
         bn_bwd_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
+    else
+        bn_bwd_apply_kernel<f16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const f16_t*)dy, lddy, dyoff, (const f16_t*)x, ldx, xoff, (const f16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (f16_t*)dx, lddx, dxoff, (f16_t*)dres, lddr, droff, rows, C, relu);
     OCTA_CHECK_LAUNCH("bn_bwd_apply");
     return OCTA_OK;
 }

@@ -5,6 +5,7 @@ static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int
 #define DISPATCH_T(dtype, NAME, ...)                                                         \
     if ((dtype) == OCTA_F32) { using T = float; __VA_ARGS__ }                                \
     else if ((dtype) == OCTA_BF16) { using T = bf16_t; __VA_ARGS__ }                         \
+    else if ((dtype) == OCTA_F16) { using T = f16_t; __VA_ARGS__ }                           \
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, NAME ": bad dtype %d", (int)(dtype));
 
 // ------------------------------------------------------------------------------------------ maxpool 3x3 s2 p1
@@ -332,6 +333,9 @@ extern "C" int octa_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
     else if (sd == OCTA_BF16 && dd == OCTA_F32) cast_kernel<bf16_t, float><<<ew_blocks(n), 256, 0, st>>>((const bf16_t*)src, (float*)dst, n);
     else if (sd == OCTA_F32 && dd == OCTA_F32) cast_kernel<float, float><<<ew_blocks(n), 256, 0, st>>>((const float*)src, (float*)dst, n);
     else if (sd == OCTA_BF16 && dd == OCTA_BF16) cast_kernel<bf16_t, bf16_t><<<ew_blocks(n), 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n);
+    else if (sd == OCTA_F32 && dd == OCTA_F16) cast_kernel<float, f16_t><<<ew_blocks(n), 256, 0, st>>>((const float*)src, (f16_t*)dst, n);
+    else if (sd == OCTA_F16 && dd == OCTA_F32) cast_kernel<f16_t, float><<<ew_blocks(n), 256, 0, st>>>((const f16_t*)src, (float*)dst, n);
+    else if (sd == OCTA_F16 && dd == OCTA_F16) cast_kernel<f16_t, f16_t><<<ew_blocks(n), 256, 0, st>>>((const f16_t*)src, (f16_t*)dst, n);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_cast: bad dtypes");
     OCTA_CHECK_LAUNCH("cast");
     return OCTA_OK;

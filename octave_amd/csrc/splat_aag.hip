@@ -58,6 +58,7 @@ extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, i
     const size_t sh = (size_t)256 * epc * sizeof(float);
     if (dtype == OCTA_F32) splat_gap_kernel<float><<<grid, 256, sh, st>>>((const float*)x, gap, HW, C, TX, rpb);
     else if (dtype == OCTA_BF16) splat_gap_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, gap, HW, C, TX, rpb);
+    else if (dtype == OCTA_F16) splat_gap_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)x, gap, HW, C, TX, rpb);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_splat_gap: bad dtype");
     OCTA_CHECK_LAUNCH("splat_gap");
     return OCTA_OK;
@@ -105,6 +106,7 @@ extern "C" int octa_splat_apply(const void* x, const float* logits, void* out, i
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) splat_apply_kernel<float><<<grid, 256, sh, st>>>((const float*)x, logits, (float*)out, HW, C, relu, rpb);
     else if (dtype == OCTA_BF16) splat_apply_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, logits, (bf16_t*)out, HW, C, relu, rpb);
+    else if (dtype == OCTA_F16) splat_apply_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)x, logits, (f16_t*)out, HW, C, relu, rpb);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_splat_apply: bad dtype");
     OCTA_CHECK_LAUNCH("splat_apply");
     return OCTA_OK;
@@ -206,7 +208,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
                               float* dlogits, int B, int HW, int C, int dtype, int relu, int phase, int prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(dout && logits && C % 8 == 0 && C <= 4096, "octa_splat_bwd: bad arguments");
     OCTA_REQUIRE(!relu || out, "octa_splat_bwd: relu needs the forward output");
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_splat_bwd: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_splat_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     if (phase == 0) {
@@ -220,7 +222,8 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
         dim3 grid(gx, cdiv(HW, rpb), B);
         const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
         if (dtype == OCTA_F32) splat_bwd_reduce_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, (const float*)out, dlogits, HW, C, TX, rpb, relu);
-        else splat_bwd_reduce_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)out, dlogits, HW, C, TX, rpb, relu);
+        else if (dtype == OCTA_BF16) splat_bwd_reduce_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)out, dlogits, HW, C, TX, rpb, relu);
+        else splat_bwd_reduce_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, (const f16_t*)out, dlogits, HW, C, TX, rpb, relu);
         OCTA_CHECK_LAUNCH("splat_bwd_reduce");
         splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
         OCTA_CHECK_LAUNCH("splat_softmax_bwd");
@@ -231,7 +234,8 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
         dim3 grid(cdiv(HW, rpb), B);
         const size_t sh = (size_t)2 * C * sizeof(float);
         if (dtype == OCTA_F32) splat_bwd_apply_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)out, logits, dgap, (float*)dx, HW, C, relu, rpb);
-        else splat_bwd_apply_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, logits, dgap, (bf16_t*)dx, HW, C, relu, rpb);
+        else if (dtype == OCTA_BF16) splat_bwd_apply_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, logits, dgap, (bf16_t*)dx, HW, C, relu, rpb);
+        else splat_bwd_apply_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)out, logits, dgap, (f16_t*)dx, HW, C, relu, rpb);
         OCTA_CHECK_LAUNCH("splat_bwd_apply");
     }
     return OCTA_OK;
@@ -773,11 +777,12 @@ extern "C" int octa_aag_fwd(const void* x, const float* w, const float* bias, vo
                             int mode, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && bias && y && (mode == 1 || masked), "octa_aag_fwd: null pointer");
     OCTA_REQUIRE(C % 8 == 0 && K >= 2 && K <= 4, "octa_aag_fwd: needs C %% 8 == 0 and 2 <= num_classes <= 4 (got C=%d K=%d)", C, K);
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_aag_fwd: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_aag_fwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int64_t npix = B * HW;
 #define AAG_K(KV) (dtype == OCTA_F32 ? aag_fwd_launch<float, KV>(x, w, bias, masked, y, npix, HW, C, mode, st) \
-                                     : aag_fwd_launch<bf16_t, KV>(x, w, bias, masked, y, npix, HW, C, mode, st))
+                   : dtype == OCTA_BF16 ? aag_fwd_launch<bf16_t, KV>(x, w, bias, masked, y, npix, HW, C, mode, st) \
+                                        : aag_fwd_launch<f16_t, KV>(x, w, bias, masked, y, npix, HW, C, mode, st))
     if (K == 2) return AAG_K(2);
     if (K == 3) return AAG_K(3);
     return AAG_K(4);
@@ -788,11 +793,12 @@ extern "C" int octa_aag_bwd(const void* x, const float* w, const float* y, const
                             float* dbias, int64_t B, int HW, int C, int K, int dtype, int mode, float* part, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && dx && dw && dbias && (mode == 1 || (y && dmasked)), "octa_aag_bwd: null pointer");
     OCTA_REQUIRE(C % 8 == 0 && K >= 2 && K <= 4, "octa_aag_bwd: needs C %% 8 == 0 and 2 <= num_classes <= 4");
-    OCTA_REQUIRE(dtype == OCTA_F32 || dtype == OCTA_BF16, "octa_aag_bwd: bad dtype");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_aag_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     const int64_t npix = B * HW;
 #define AAG_K(KV) (dtype == OCTA_F32 ? aag_bwd_launch<float, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st) \
-                                     : aag_bwd_launch<bf16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st))
+                   : dtype == OCTA_BF16 ? aag_bwd_launch<bf16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st) \
+                                        : aag_bwd_launch<f16_t, KV>(x, w, y, dmasked, dy, dx, dw, dbias, npix, HW, C, mode, part, st))
     if (K == 2) return AAG_K(2);
     if (K == 3) return AAG_K(3);
     return AAG_K(4);

@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, OCTA_BF16, OCTA_F32, ConvDesc,
+from ._lib import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, OCTA_BF16, OCTA_F16, OCTA_F32, ConvDesc,
                    OctaError, WgradJob, lib)
 
 Tensor = torch.Tensor
@@ -26,7 +26,9 @@ def _dt(t_or_dtype) -> int:
         return OCTA_F32
     if d == torch.bfloat16:
         return OCTA_BF16
-    raise OctaError(f"unsupported activation dtype {d} (float32 or bfloat16)")
+    if d == torch.float16:
+        return OCTA_F16
+    raise OctaError(f"unsupported activation dtype {d} (float32, bfloat16 or float16)")
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -145,15 +147,16 @@ class _ZeroSlab:
     (63 launches per step).  Bump allocation, never reused inside a step; inactive outside a TrainStep."""
 
     def __init__(self, nfloats: int = 4 << 20):
-        self.cap, self.buf, self.off, self.high, self.active = nfloats, None, 0, 0, False
+        self.cap, self.buf, self.off, self.high, self.active, self.zeroed = nfloats, None, 0, 0, False, 0
 
     def begin(self, device):
         if self.buf is None or self.buf.device != device:
             self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device)
-            self.high = 0
+            self.high, self.zeroed = 0, self.cap
         else:
             n = self.cap if self.high == 0 else min(self.cap, self.high)
             self.buf[:n].zero_()
+            self.zeroed = n          # slices beyond this are NOT clean (an earlier, larger user): take() refuses them
         self.off, self.active = 0, True
 
     def end(self):
@@ -167,8 +170,9 @@ class _ZeroSlab:
         for v in shape:
             n *= v
         a = (self.off + 15) // 16 * 16
-        if a + n > self.cap:
-            return None
+        self.high = max(self.high, min(self.cap, a + n))     # the next begin() clears this far
+        if a + n > self.zeroed:
+            return None              # the caller's entry point zero-fills its own buffer this once
         self.off = a + n
         return self.buf[a:a + n].view(shape)
 
@@ -380,9 +384,9 @@ def set_conv_autotune(on: bool):
 def _choose_algo(kind: str, d, launch) -> int:
     if _ALGO_OVERRIDE:
         return _ALGO_OVERRIDE
-    if d.dtype != OCTA_BF16:
+    if d.dtype == OCTA_F32:
         return 0
-    key = (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.pad, d.groups, d.ldx, d.ldy, d.upshuffle, d.act)
+    key = (kind, d.dtype, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.pad, d.groups, d.ldx, d.ldy, d.upshuffle, d.act)
     a = _ALGO_CACHE.get(key)
     if a is not None:
         return a
@@ -461,7 +465,7 @@ def _densify(groups: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pa
     once, 4x the MFMA work, which is free here) - 2-3x faster.  Algorithmic FLOPs are still counted with the groups."""
     if groups == 1 or (KH, KW, stride, pad) != (3, 3, 1, 1) or os.environ.get("OCTA_NO_DENSIFY") == "1":
         return False
-    ck = 32 if dtype == torch.bfloat16 else 16
+    ck = 16 if dtype == torch.float32 else 32
     return Cin // groups <= 8 and Cout // groups <= 16 and Cin % ck == 0 and Cout % ck == 0 and H * W >= 128 * 128
 
 
@@ -702,7 +706,7 @@ def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv:
     if residual is not None:
         res = to_nhwc(residual, dtype=x.dtype)
     # 1 bit per element ReLU mask for the backward pass (read instead of y: 1/16 of the bytes in both backward kernels)
-    mask = torch.empty(((rows * (C // (8 if x.dtype == torch.bfloat16 else 4)) + 3) // 4 * 4,), dtype=torch.uint8, device=x.device) if (relu and training) else None
+    mask = torch.empty(((rows * (C // (4 if x.dtype == torch.float32 else 8)) + 3) // 4 * 4,), dtype=torch.uint8, device=x.device) if (relu and training) else None
     L.octa_bn_apply(_p(x), nhwc_ld(x), 0, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
                     _p(y), nhwc_ld(y), 0, rows, C, _dt(x), int(relu), _p(mask), _st())
     return y, mean, invstd, x, mask

@@ -7,12 +7,13 @@ raises -- models/octa.py:59-60; defined in SURVEY.md 3.5):
     L_d = LSDisc(D(real_pyramid), D([a.detach() for a in att])); L_d.backward(); Adam(discriminator)
 
 Data parallel: one process per GPU, gradients live in two flat fp32 arenas (segmentor,
-discriminator) that are all-reduced over RCCL (torch.distributed backend "nccl" on ROCm) and then
-consumed by ONE fused Adam launch each.  BatchNorm statistics and the WPCE class weights are
-per-replica, like DistributedDataParallel on the reference would be.
+discriminator) that are all-reduced over RCCL (torch.distributed backend "nccl" on ROCm) in BUCKETS
+laid out in reverse execution order, and then consumed by ONE fused Adam launch each.  BatchNorm
+statistics and the WPCE class weights are per-replica, like DistributedDataParallel on the reference
+would be; parameters and buffers are broadcast from rank 0 at construction.
 """
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -25,13 +26,39 @@ from .layers import defer_bn_counters, flush_bn_counters
 
 FORCE_ALLREDUCE = os.environ.get("OCTA_DIST_ALWAYS") == "1"     # exercise the RCCL path with a single rank (tests)
 
+# top-level modules of ResnestUNet in the order their parameter gradients COMPLETE in the backward pass; each entry is
+# (stage mark that fires when the group is complete, module names).  The flat arena is laid out in this order, so a gradient
+# bucket is one contiguous slice and can be all-reduced as soon as its mark has fired (or, graph mode, in this order afterwards).
+SEG_GRAD_ORDER: List[Tuple[str, Tuple[str, ...]]] = [
+    ("decoder_0", ("fc", "aag_0", "decoder_0")),
+    ("decoder_1", ("upsampling_0", "aag_1", "decoder_1")),
+    ("decoder_2", ("upsampling_1", "aag_2", "decoder_2")),
+    ("decoder_3", ("upsampling_2", "aag_3", "decoder_3")),
+    ("decoder_4", ("upsampling_3", "aag_4", "decoder_4")),
+    ("encoder_4", ("upsampling_4", "encoder_4")),
+    ("encoder_3", ("encoder_3",)),
+    ("encoder_2", ("encoder_2",)),
+    ("encoder_1", ("encoder_1",)),
+    ("end", ("encoder_0_1_2",)),
+]
+
+
+def _dist_on(world: int) -> bool:
+    return world > 1 or (FORCE_ALLREDUCE and dist.is_available() and dist.is_initialized())
+
 
 class FlatArena:
     """Flat fp32 storage for the grad-bearing parameters of a module, their gradients and the Adam
-    moments.  Parameters keep their logical shapes AND strides (channels-last conv weights stay so)."""
+    moments.  Parameters keep their logical shapes AND strides (channels-last conv weights stay so).
+    `named_params`: (name, parameter) pairs in arena order; `groups`: optional list of (tag, [names]) -- consecutive
+    parameters of one group form one gradient bucket."""
 
-    def __init__(self, params: Sequence[nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]], groups: Optional[List[Tuple[str, List[str]]]] = None,
+                 min_bucket: int = 4 << 20):
+        named_params = [np_ if isinstance(np_, tuple) else (f"p{i}", np_) for i, np_ in enumerate(named_params)]   # plain parameters are fine too
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
         dev = self.params[0].device
         offs, n = [], 0
         for p in self.params:
@@ -39,6 +66,7 @@ class FlatArena:
             offs.append(n)
             n += p.numel()
         self.numel = (n + 3) // 4 * 4
+        self.offsets = dict(zip(self.names, offs))
         self.p = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.g = torch.zeros_like(self.p)
         self.m = torch.zeros_like(self.p)
@@ -53,39 +81,128 @@ class FlatArena:
                 p.data = view
                 p.grad = self.g.as_strided(p.shape, p.stride(), o)
         self.step_count = 0
+        # gradient buckets: (tag, lo, hi) contiguous element ranges in arena order; small groups are merged into the NEXT one
+        # (a bucket may only be reduced once every group in it is complete, i.e. when its LAST group's mark has fired)
+        self.buckets: List[Tuple[str, int, int]] = []
+        if groups:
+            end_of = {}
+            for name, p, o in zip(self.names, self.params, offs):
+                end_of[name] = (o + p.numel() + 3) // 4 * 4
+            lo = 0
+            for tag, names in groups:
+                present = [nm for nm in names if nm in end_of]
+                if not present:
+                    continue
+                hi = max(end_of[nm] for nm in present)
+                if hi - lo >= min_bucket or tag == groups[-1][0]:
+                    self.buckets.append((tag, lo, hi))
+                    lo = hi
+            if not self.buckets or self.buckets[-1][2] != self.numel:
+                last_lo = self.buckets[-1][2] if self.buckets else 0
+                if self.buckets and self.buckets[-1][0] == groups[-1][0]:
+                    t, l, _ = self.buckets[-1]
+                    self.buckets[-1] = (t, l, self.numel)
+                else:
+                    self.buckets.append((groups[-1][0], last_lo, self.numel))
+        else:
+            self.buckets = [("end", 0, self.numel)]
+        self._comm_bufs: Dict[int, Tensor] = {}
+
+    # ------------------------------------------------------------------ optimiser state (checkpoint / resume)
+    def state_dict(self) -> Dict:
+        """Adam moments keyed by parameter name (+ the step counter): round-trips with net.state_dict()."""
+        out = {"step": self.step_count, "exp_avg": {}, "exp_avg_sq": {}}
+        for n, p in zip(self.names, self.params):
+            o = self.offsets[n]
+            out["exp_avg"][n] = self.m.as_strided(p.shape, p.stride(), o).detach().clone().contiguous()
+            out["exp_avg_sq"][n] = self.v.as_strided(p.shape, p.stride(), o).detach().clone().contiguous()
+        return out
+
+    def load_state_dict(self, sd: Dict):
+        with torch.no_grad():
+            for n, p in zip(self.names, self.params):
+                o = self.offsets[n]
+                self.m.as_strided(p.shape, p.stride(), o).copy_(sd["exp_avg"][n])
+                self.v.as_strided(p.shape, p.stride(), o).copy_(sd["exp_avg_sq"][n])
+        self.step_count = int(sd["step"])
 
     def zero_grad(self):
         self.g.zero_()
 
-    def needs_comm(self, world: int) -> bool:
-        return world > 1 or (FORCE_ALLREDUCE and dist.is_available() and dist.is_initialized())
+    def param_range(self, params: Sequence[nn.Parameter]) -> List[Tuple[int, int]]:
+        """Merged element ranges covering `params` (Adam on a subset: the discriminator head of the current resolution)."""
+        ids = {id(p) for p in params}
+        rs = sorted((self.offsets[n], (self.offsets[n] + p.numel() + 3) // 4 * 4) for n, p in zip(self.names, self.params) if id(p) in ids)
+        out: List[Tuple[int, int]] = []
+        for lo, hi in rs:
+            if out and lo <= out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], hi))
+            else:
+                out.append((lo, hi))
+        return out
 
-    def all_reduce(self, world: int):
-        if self.needs_comm(world):
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
-
-    def all_reduce_begin(self, world: int, comm_stream):
-        """Start the all-reduce on `comm_stream` once the gradients written on the current stream are complete;
-        the caller overlaps independent work and calls all_reduce_end() before consuming the gradients."""
-        if not self.needs_comm(world):
+    # ------------------------------------------------------------------ gradient exchange
+    def _reduce_range(self, lo: int, hi: int, comm_dtype):
+        sl = self.g[lo:hi]
+        if comm_dtype is None or comm_dtype == torch.float32:
+            dist.all_reduce(sl, op=dist.ReduceOp.SUM)
             return
-        cur = torch.cuda.current_stream()
-        comm_stream.wait_stream(cur)
+        # reduced-precision exchange: half the xGMI bytes (143 MB instead of 286 MB for the segmentor), one rounding per gradient
+        buf = self._comm_bufs.get(lo)
+        if buf is None or buf.numel() != hi - lo or buf.dtype != comm_dtype:
+            buf = torch.empty(hi - lo, dtype=comm_dtype, device=sl.device)
+            self._comm_bufs[lo] = buf
+        st = torch.cuda.current_stream().cuda_stream
+        L = lib()
+        L.octa_cast(sl.data_ptr(), 0, buf.data_ptr(), F_._dt(comm_dtype), hi - lo, st)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        L.octa_cast(buf.data_ptr(), F_._dt(comm_dtype), sl.data_ptr(), 0, hi - lo, st)
+
+    def all_reduce(self, world: int, comm_dtype=None):
+        if _dist_on(world):
+            for _, lo, hi in self.buckets:
+                self._reduce_range(lo, hi, comm_dtype)
+
+    def all_reduce_bucket_async(self, world: int, comm_stream, idx: int, comm_dtype=None):
+        """Start the all-reduce of bucket `idx` on `comm_stream` once the gradients written so far on the current stream are
+        complete; all_reduce_end() joins."""
+        if not _dist_on(world):
+            return
+        _, lo, hi = self.buckets[idx]
+        comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(comm_stream):
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
+            self._reduce_range(lo, hi, comm_dtype)
+
+    def all_reduce_begin(self, world: int, comm_stream, comm_dtype=None, skip: Sequence[int] = ()):
+        """Start every bucket not yet started (in arena = completion order) on `comm_stream`; the caller overlaps independent
+        work and calls all_reduce_end() before consuming the gradients."""
+        if not _dist_on(world):
+            return
+        comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm_stream):
+            for i, (_, lo, hi) in enumerate(self.buckets):
+                if i not in skip:
+                    self._reduce_range(lo, hi, comm_dtype)
 
     def all_reduce_end(self, world: int, comm_stream):
-        if self.needs_comm(world):
+        if _dist_on(world):
             torch.cuda.current_stream().wait_stream(comm_stream)
 
-    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None):
-        """One fused Adam launch over the arena.  `dyn` (device, 2 floats) carries the bias corrections when the
-        launch is captured in a hipGraph; the caller then advances step_count / dyn itself (set_dyn)."""
+    def broadcast(self, src: int = 0):
+        dist.broadcast(self.p, src)
+        F_.bump_weight_epoch()
+
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None,
+             ranges: Optional[List[Tuple[int, int]]] = None):
+        """One fused Adam launch over the arena (or one per element range in `ranges`).  `dyn` (device, 2 floats) carries the
+        bias corrections when the launch is captured in a hipGraph; the caller then advances step_count / dyn itself."""
         if dyn is None:
             self.step_count += 1
-        lib().octa_adam_step(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.numel, lr, betas[0], betas[1],
-                             eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
-                             torch.cuda.current_stream().cuda_stream)
+        st = torch.cuda.current_stream().cuda_stream
+        for lo, hi in (ranges or [(0, self.numel)]):
+            o = lo * 4
+            lib().octa_adam_step(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, hi - lo, lr, betas[0],
+                                 betas[1], eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(), st)
         # one launch refreshes every cached packed conv operand of THIS network; nothing else went stale, so the global
         # weight epoch is left alone (bumping it here made the other network's operands look stale: ~170 redundant
         # per-weight pack launches were captured into every replayed step)
@@ -101,7 +218,9 @@ class FlatArena:
 
 def mask_pyramid(mask: Tensor, levels: int = 5) -> List[Tensor]:
     """Real multi-scale pyramid for the discriminator: nearest down-sampling by 2**i (contract of
-    discriminator/blocks.py:114-125; views, no copy)."""
+    discriminator/blocks.py:114-125).  On the GPU the levels are written densely by one launch; CPU tensors give views."""
+    if mask.is_cuda:
+        return F_.mask_pyramid_dense(mask, levels)
     return [mask[:, :, ::2 ** i, ::2 ** i] for i in range(levels)]
 
 
@@ -170,34 +289,128 @@ class _RngFeed:
         return t
 
 
+class _Capture:
+    """Static buffers and the four hipGraphs of one input resolution."""
+    __slots__ = ("sx", "sys", "sreal", "feed", "out", "att", "graphs", "disc")
+
+
 class TrainStep:
+    """One optimiser step of the adversarial (or segmentor-only) loop on fused kernels.
+
+    compute_dtype: torch.bfloat16 (default), torch.float16 (BASELINE config 5: pass loss_scale, e.g. 1024 -- the losses
+    themselves are always accumulated in fp32) or torch.float32 (parity runs).
+    extra_discriminators: {image size: DiscriminatorBlock} for mixed-resolution training (config 5).  The reference's
+    discriminator is tied to ONE resolution (its full-extent head conv and its InstanceNoise plane, blocks.py:42,68-72), so a
+    second resolution needs a second block; build it with `DiscriminatorBlock.share_body_with(net.discriminator)` so that
+    only the head differs.  A step picks the block matching its input size and updates only that block's head."""
+
     def __init__(self, net: nn.Module, lr: float = 1e-4, lr_disc: Optional[float] = None, betas=(0.9, 0.999), compute_dtype=torch.bfloat16,
-                 adversarial: bool = True, use_dice: bool = True, kl_weight: float = 0.1, adv_weight: float = 0.1):
+                 adversarial: bool = True, use_dice: bool = True, kl_weight: float = 0.1, adv_weight: float = 0.1,
+                 loss_scale: float = 1.0, grad_comm_dtype=None, extra_discriminators: Optional[Dict[int, nn.Module]] = None,
+                 overlap_backward: Optional[bool] = None):
         self.net = net
         self.seg, self.disc = net.segmentor, getattr(net, "discriminator", None)
         self.adversarial = adversarial and self.disc is not None
         self.use_dice, self.kl_weight, self.adv_weight = use_dice, kl_weight, adv_weight
         self.lr, self.lr_disc, self.betas = lr, lr_disc or lr, betas
+        self.loss_scale = float(loss_scale)
+        self.grad_comm_dtype = grad_comm_dtype
         self.seg.compute_dtype = compute_dtype
+        self.discs: Dict[Optional[int], nn.Module] = {}
         if self.disc is not None:
             self.disc.compute_dtype = compute_dtype
+            self.discs[getattr(self.disc, "input_hw", (None, None))[0]] = self.disc
+            for hw, d in (extra_discriminators or {}).items():
+                d.compute_dtype = compute_dtype
+                self.discs[int(hw)] = d
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # linear_head_* never receive a gradient on this path (SURVEY.md 2c): keep them out of the arena
-        seg_params = [p for n, p in self.seg.named_parameters() if not n.startswith("linear_head_")]
-        self.seg_arena = FlatArena(seg_params)
-        self.disc_arena = FlatArena(list(self.disc.parameters())) if self.adversarial else None
+        named = [(n, p) for n, p in self.seg.named_parameters() if not n.startswith("linear_head_")]
+        rank = {m: i for i, (_, mods) in enumerate(SEG_GRAD_ORDER) for m in mods}
+        named.sort(key=lambda np_: rank.get(np_[0].split(".", 1)[0], len(rank)))       # stable: registration order inside a module
+        groups = [(tag, [n for n, _ in named if n.split(".", 1)[0] in mods]) for tag, mods in SEG_GRAD_ORDER]
+        self.seg_arena = FlatArena(named, groups)
+        self.disc_arena = None
+        if self.adversarial:
+            seen, dn = set(), []
+            for hw, d in self.discs.items():
+                for n, p in d.named_parameters():
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        dn.append((n if d is self.disc else f"hw{hw}.{n}", p))
+            self.disc_arena = FlatArena(dn)
+            self._disc_ranges = {id(d): (self.disc_arena.param_range(list(d.parameters())) if len(self.discs) > 1 else None) for d in self.discs.values()}
+        if _dist_on(self.world):
+            self._broadcast_state()
         F_.set_grad_sink(True)
         F_.defer_wgrads(True)        # weight gradients are queued per stage and run as batched launches (functional.flush_wgrads)
         defer_bn_counters(True)
-        self._graphs = None
+        self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
+        self._dyn = None
+        # eager launches with more than one rank: start each gradient bucket's all-reduce from the stage mark that completes it,
+        # i.e. overlapped with the REST of the backward pass (BASELINE config 4).  Captured graphs hold no collective: there the
+        # buckets are issued, in the same order, right after the segmentor graph and overlap the discriminator step instead.
+        self.overlap_backward = _dist_on(self.world) if overlap_backward is None else bool(overlap_backward)
+        self._started: List[int] = []
+        self._tag_to_bucket = {tag: i for i, (tag, _, _) in enumerate(self.seg_arena.buckets)}
         self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
+        self.launch_timing = None
 
-    # ------------------------------------------------------------------ the three phases of a step
+    # ------------------------------------------------------------------ replicas
+    def _broadcast_state(self):
+        """Every rank starts from rank 0's parameters AND buffers (BatchNorm running statistics, spectral-norm u / v, counters):
+        what DistributedDataParallel does at construction.  Without it replicas silently diverge unless every rank seeded
+        the same generator before building the network."""
+        self.seg_arena.broadcast(0)
+        if self.disc_arena is not None:
+            self.disc_arena.broadcast(0)
+        mods = [self.seg] + list(self.discs.values())
+        seen = set()
+        for m in mods:
+            for b in m.buffers():
+                if id(b) in seen or not b.is_cuda:
+                    continue
+                seen.add(id(b))
+                dist.broadcast(b, 0)
+        for p in self.seg.parameters():          # the heads that are not in the arena
+            if id(p) not in {id(q) for q in self.seg_arena.params}:
+                dist.broadcast(p.data, 0)
+
+    def state_dict(self) -> Dict:
+        """Optimiser state for checkpoint / resume (the network itself: net.state_dict())."""
+        sd = {"segmentor": self.seg_arena.state_dict()}
+        if self.disc_arena is not None:
+            sd["discriminator"] = self.disc_arena.state_dict()
+        return sd
+
+    def load_state_dict(self, sd: Dict):
+        self.seg_arena.load_state_dict(sd["segmentor"])
+        if self.disc_arena is not None and "discriminator" in sd:
+            self.disc_arena.load_state_dict(sd["discriminator"])
+
+    def _pick_disc(self, x: Tensor):
+        if not self.adversarial:
+            return None
+        if len(self.discs) == 1:
+            return self.disc
+        d = self.discs.get(int(x.shape[-1]))
+        if d is None:
+            raise ValueError(f"no discriminator was registered for {x.shape[-1]} x {x.shape[-1]} inputs (have {sorted(k for k in self.discs if k)})")
+        return d
+
+    # ------------------------------------------------------------------ the phases of a step
     # (split at the two gradient all-reduces so that the collectives stay OUTSIDE any captured graph)
-    def _phase_segmentor(self, x, ys, out):
+    def _on_mark(self, tag: str):
+        i = self._tag_to_bucket.get(tag)
+        if i is not None and i not in self._started:
+            self.seg_arena.all_reduce_bucket_async(self.world, self._comm(), i, self.grad_comm_dtype)
+            self._started.append(i)
+
+    def _phase_segmentor(self, x, ys, out, disc, hooks: bool = False):
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
+        self._started = []
         att, agg, _ = self.seg(x)
         l = F_.wpce_dice(agg, ys, from_logits=True)
         loss = l[0] + l[1] if self.use_dice else l[0]
@@ -209,39 +422,46 @@ class TrainStep:
             # (zeroed before D's step, here and in the reference), so they are not computed at all
             for q in self.disc_arena.params:
                 q.requires_grad_(False)
-            g_adv = F_.lsgan_generator(self.disc(att))
+            g_adv = F_.lsgan_generator(disc(att))
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
+        if hooks:
+            F_.add_mark_hook(self._on_mark)
         try:
-            loss.backward()
+            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             F_.flush_wgrads()
         finally:
+            if hooks:
+                F_.clear_mark_hooks()
             if self.adversarial:
                 for q in self.disc_arena.params:
                     q.requires_grad_(True)
+            F_.ZERO_SLAB.end()
         out["loss_seg"] = loss.detach()
-        F_.ZERO_SLAB.end()
         flush_bn_counters()
         return [a.detach() for a in att]
 
-    def _phase_discriminator(self, att, real_pyramid, out):
+    def _phase_discriminator(self, att, real_pyramid, out, disc):
         """The discriminator's forward/backward.  It depends on the segmentor step only through the (detached)
         attention maps, not on the reduced segmentor gradients, so it runs WHILE those are being all-reduced."""
         if self.adversarial:
             self.disc_arena.zero_grad()
-            d_real = self.disc(real_pyramid)
-            d_fake = self.disc(att)
+            d_real = disc(real_pyramid)
+            d_fake = disc(att)
             l_d = F_.lsgan_discriminator(d_real, d_fake)
-            l_d.backward()
+            (l_d * self.loss_scale if self.loss_scale != 1.0 else l_d).backward()
             F_.flush_wgrads()
             out["loss_disc"] = l_d.detach()
 
-    def _phase_seg_update(self, dyn=None):
-        self.seg_arena.adam(self.lr, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+    def _grad_scale(self) -> float:
+        return 1.0 / (self.world * self.loss_scale)
 
-    def _phase_finish(self, dyn=None):
+    def _phase_seg_update(self, dyn=None):
+        self.seg_arena.adam(self.lr, self.betas, grad_scale=self._grad_scale(), dyn=dyn)
+
+    def _phase_finish(self, disc, dyn=None):
         if self.adversarial:
-            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=1.0 / self.world, dyn=dyn)
+            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ranges=self._disc_ranges[id(disc)])
 
     def _comm(self):
         if self._comm_stream is None:
@@ -251,41 +471,49 @@ class TrainStep:
     def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
         if self.adversarial and real_pyramid is None:
             raise ValueError("the adversarial step needs the real mask pyramid")
-        if self._graphs is not None and self.launch == "graph":
-            return self._replay(x, ys, real_pyramid)
-        # launch == "eager" (or nothing captured): the step launched kernel by kernel from Python.  Same arenas, step counters
-        # and global CPU generator as the replayed path, so the two can be mixed freely.
+        cap = self._caps.get(int(x.shape[-1]))
+        if cap is not None and self.launch == "graph":
+            return self._replay(cap, x, ys, real_pyramid)
+        # launch == "eager" (or nothing captured for this size): the step launched kernel by kernel from Python.  Same arenas,
+        # step counters and global CPU generator as the replayed path, so the two can be mixed freely.
         out: Dict[str, Tensor] = {}
-        feed = getattr(self.disc, "rng_feed", None) if self.disc is not None else None
+        disc = self._pick_disc(x)
+        feed = getattr(disc, "rng_feed", None) if disc is not None else None
         if feed is not None:
-            self.disc.rng_feed = None          # captured earlier: this path draws the discriminator's noise inline, like the reference
+            disc.rng_feed = None          # captured earlier: this path draws the discriminator's noise inline, like the reference
         try:
-            att = self._phase_segmentor(x, ys, out)
-            self.seg_arena.all_reduce_begin(self.world, self._comm())      # 286 MB over xGMI, hidden behind the D step
-            self._phase_discriminator(att, real_pyramid, out)
+            att = self._phase_segmentor(x, ys, out, disc, hooks=self.overlap_backward)
+            # buckets not started from a stage mark (all of them without overlap): 286 MB over xGMI, hidden behind the D step
+            self.seg_arena.all_reduce_begin(self.world, self._comm(), self.grad_comm_dtype, skip=self._started)
+            self._phase_discriminator(att, real_pyramid, out, disc)
             self.seg_arena.all_reduce_end(self.world, self._comm())
             self._phase_seg_update()
             if self.adversarial:
                 self.disc_arena.all_reduce(self.world)
-            self._phase_finish()
+            self._phase_finish(disc)
         finally:
             if feed is not None:
-                self.disc.rng_feed = feed
+                disc.rng_feed = feed
         return out
 
     # ------------------------------------------------------------------ hipGraph capture / replay
     def capture(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None, warmup: int = 2):
-        """Capture the step into three hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm) around the two
-        all-reduces.  Inputs are copied into static buffers on every call; the CPU random draws of the
-        discriminator are staged through _RngFeed; Adam's bias corrections come from device memory."""
+        """Capture the step for inputs of x's size into four hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm: segmentor
+        fwd/bwd | discriminator step | segmentor Adam + operand repack | discriminator Adam) around the two all-reduces.
+        Inputs are copied into static buffers on every call; the CPU random draws of the discriminator are staged through
+        _RngFeed; Adam's bias corrections come from device memory.  Call once per input resolution."""
         dev = x.device
-        self._sx, self._sys = x.clone(), ys.clone()
-        self._sreal = [r.contiguous().clone() for r in real_pyramid] if real_pyramid is not None else None
+        cap = _Capture()
+        cap.sx, cap.sys = x.clone(), ys.clone()
+        cap.sreal = [r.contiguous().clone() for r in real_pyramid] if real_pyramid is not None else None
+        cap.disc = self._pick_disc(x)
+        cap.feed = None
         if self.adversarial:
-            self._feed = _RngFeed(self.disc, dev)
-            self.disc.rng_feed = self._feed
-        self._dyn = [_PinnedRing((2,), dev) for _ in range(2)]
-        self._dyn_dev = [r.dev for r in self._dyn]
+            cap.feed = _RngFeed(cap.disc, dev)
+            cap.disc.rng_feed = cap.feed
+        if self._dyn is None:
+            self._dyn = [_PinnedRing((2,), dev) for _ in range(2)]
+            self._dyn_dev = [r.dev for r in self._dyn]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -293,69 +521,105 @@ class TrainStep:
             F_.set_conv_autotune(True)            # the first warm-up step measures the fwd / dgrad kernel choice per layer shape
             try:
                 for _ in range(warmup):
-                    self._eager_static()
+                    self._eager_static(cap)
             finally:
                 F_.set_conv_autotune(False)
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self._out: Dict[str, Tensor] = {}
+        cap.out = {}
         # the warm-up steps ended with Adam + repack_all: every cached operand is current, so no per-weight pack launch
         # is captured (a stale cache here would put ~180 redundant pack kernels into every replay)
         if self.adversarial:
-            self._feed.rewind()
+            cap.feed.rewind()
         # "thread_local": RCCL's watchdog thread keeps polling the events of the warm-up all-reduces with hipEventQuery while this
         # thread captures; under the default global mode that query is an error and the watchdog aborts the process
         mode = "thread_local"
+        pool = next(iter(self._caps.values())).graphs[0].pool() if self._caps else None
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, capture_error_mode=mode):
-            self._att = self._phase_segmentor(self._sx, self._sys, self._out)
+        with torch.cuda.graph(g1, pool=pool, capture_error_mode=mode):
+            cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
-            self._phase_discriminator(self._att, self._sreal, self._out)
+            self._phase_discriminator(cap.att, cap.sreal, cap.out, cap.disc)
         g2b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=mode):
             self._phase_seg_update(dyn=self._dyn_dev[0])
         g3 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
-            self._phase_finish(dyn=self._dyn_dev[1])
-        self._graphs = (g1, g2, g2b, g3)
+            self._phase_finish(cap.disc, dyn=self._dyn_dev[1])
+        cap.graphs = (g1, g2, g2b, g3)
+        self._caps[int(x.shape[-1])] = cap
         return self
 
-    def _eager_static(self):
+    @property
+    def _graphs(self):          # bench.py's roofline leg swaps this to record an eager step
+        return self._caps or None
+
+    @_graphs.setter
+    def _graphs(self, v):
+        self._caps = v or {}
+
+    def _eager_static(self, cap: _Capture):
         out: Dict[str, Tensor] = {}
         if self.adversarial:
-            self._feed.refill()
+            cap.feed.refill()
         self.seg_arena.advance_dyn(self._dyn[0], self.betas)
-        att = self._phase_segmentor(self._sx, self._sys, out)
-        self.seg_arena.all_reduce_begin(self.world, self._comm())
-        self._phase_discriminator(att, self._sreal, out)
+        att = self._phase_segmentor(cap.sx, cap.sys, out, cap.disc)
+        self.seg_arena.all_reduce_begin(self.world, self._comm(), self.grad_comm_dtype)
+        self._phase_discriminator(att, cap.sreal, out, cap.disc)
         self.seg_arena.all_reduce_end(self.world, self._comm())
         self._phase_seg_update(dyn=self._dyn_dev[0])
         if self.adversarial:
             self.disc_arena.advance_dyn(self._dyn[1], self.betas)
             self.disc_arena.all_reduce(self.world)
-        self._phase_finish(dyn=self._dyn_dev[1])
+        self._phase_finish(cap.disc, dyn=self._dyn_dev[1])
         return out
 
-    def _load_static(self, x, ys, real_pyramid):
-        if x is not self._sx:
-            self._sx.copy_(x, non_blocking=True)
-        if ys is not self._sys:
-            self._sys.copy_(ys, non_blocking=True)
-        if self._sreal is not None and real_pyramid is not None:
-            for dst, src in zip(self._sreal, real_pyramid):
+    def _load_static(self, cap: _Capture, x, ys, real_pyramid):
+        if x is not cap.sx:
+            cap.sx.copy_(x, non_blocking=True)
+        if ys is not cap.sys:
+            cap.sys.copy_(ys, non_blocking=True)
+        if cap.sreal is not None and real_pyramid is not None:
+            for dst, src in zip(cap.sreal, real_pyramid):
                 if dst is not src:
                     dst.copy_(src, non_blocking=True)
 
+    # ------------------------------------------------------------------ launch-path choice
+    def _snapshot(self):
+        arenas = [a for a in (self.seg_arena, self.disc_arena) if a is not None]
+        mods = [self.seg] + list(self.discs.values())
+        bufs, seen = [], set()
+        for m in mods:
+            for b in m.buffers():
+                if id(b) not in seen:
+                    seen.add(id(b))
+                    bufs.append((b, b.detach().clone()))
+        return ([(a, a.p.clone(), a.m.clone(), a.v.clone(), a.step_count) for a in arenas], bufs, torch.get_rng_state())
+
+    def _restore(self, snap):
+        arenas, bufs, rng = snap
+        with torch.no_grad():
+            for a, p, m, v, sc in arenas:
+                a.p.copy_(p); a.m.copy_(m); a.v.copy_(v)
+                a.step_count = sc
+                F_.repack_all(a.params)
+            for b, c in bufs:
+                b.copy_(c)
+        torch.set_rng_state(rng)
+
     def autotune_launch(self, x, ys, real_pyramid=None, rounds: int = 3, steps: int = 4) -> str:
         """Pick the faster launch path for THIS process on THIS host: hipGraph replay needs almost no host time but pays a few
-        microseconds of dependency handling per node and stalls when the box is busy; launching the ~1100 kernels from Python
-        costs the host ~35 ms/step, which is enough to keep an otherwise quiet GPU fed (measured a steady 39.7 ms/step eager
-        against 39.6-66 ms/step replayed across boxes; with a slower or shared host core the order flips).  Both paths run the
-        identical step on the same arenas; `rounds` alternating timings of `steps` real training steps each, the medians decide."""
+        microseconds of dependency handling per node and stalls when the box is busy; launching the ~1400 kernels from Python
+        costs the host ~33 ms/step.  Both paths run the identical step on the same arenas; `rounds` alternating timings of
+        `steps` real steps each, the medians decide.  The parameters, Adam moments and step counters, every module buffer and
+        the CPU generator are snapshotted before and restored after, so the call has no training side effect."""
         import time
-        if self._graphs is None:
+        cap = self._caps.get(int(x.shape[-1]))
+        if cap is None:
+            self.launch_timing = None
             return self.launch
+        snap = self._snapshot()
         t = {"graph": [], "eager": []}
         for _ in range(rounds):
             for mode in ("graph", "eager"):
@@ -369,26 +633,29 @@ class TrainStep:
         med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
         self.launch = "eager" if med["eager"] < med["graph"] else "graph"
         self.launch_timing = med
+        self._restore(snap)
+        torch.cuda.synchronize()
         return self.launch
 
-    def _replay(self, x, ys, real_pyramid):
-        self._load_static(x, ys, real_pyramid)
+    def _replay(self, cap: _Capture, x, ys, real_pyramid):
+        self._load_static(cap, x, ys, real_pyramid)
         if self.adversarial:
-            self._feed.refill()
-        g1, g2, g2b, g3 = self._graphs
+            cap.feed.refill()
+        g1, g2, g2b, g3 = cap.graphs
         self.seg_arena.advance_dyn(self._dyn[0], self.betas)
         if self.adversarial:
             self.disc_arena.advance_dyn(self._dyn[1], self.betas)
         g1.replay()
-        self.seg_arena.all_reduce_begin(self.world, self._comm())
-        g2.replay()                                  # D step overlaps the segmentor gradient all-reduce
+        # bucketed, in completion order, on the comm stream: the D step overlaps the segmentor gradient exchange
+        self.seg_arena.all_reduce_begin(self.world, self._comm(), self.grad_comm_dtype)
+        g2.replay()
         self.seg_arena.all_reduce_end(self.world, self._comm())
         g2b.replay()
         if self.adversarial:
             self.disc_arena.all_reduce(self.world)
         g3.replay()
         F_.bump_weight_epoch()      # the weights moved behind the pack cache's back
-        return self._out
+        return cap.out
 
     def close(self):
         """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""
@@ -396,6 +663,6 @@ class TrainStep:
         F_.defer_wgrads(False)
         F_.clear_mark_hooks()
         defer_bn_counters(False)
-        if self.disc is not None:
-            self.disc.rng_feed = None
-        self._graphs = None
+        for d in self.discs.values():
+            d.rng_feed = None
+        self._caps = {}

@@ -63,15 +63,36 @@ def _worker(rank, world, port, q):
     try:
         from octave_amd.train import FlatArena
         P = _make_state()
-        params = [p for p in P.values() if isinstance(p, torch.nn.Parameter)]
-        arena = FlatArena(params)
+        named = [(k, p) for k, p in P.items() if isinstance(p, torch.nn.Parameter)]
+        params = [p for _, p in named]
+        # three gradient groups in "completion order" (as TrainStep lays the segmentor out): buckets must tile the arena in order
+        third = (len(named) + 2) // 3
+        groups = [(f"g{i}", [k for k, _ in named[i * third:(i + 1) * third]]) for i in range(3)]
+        arena = FlatArena(named, groups, min_bucket=1)
+        assert [b[0] for b in arena.buckets] == ["g0", "g1", "g2"] and arena.buckets[0][1] == 0 and arena.buckets[-1][2] == arena.numel
+        assert all(a[2] == b[1] for a, b in zip(arena.buckets, arena.buckets[1:]))
+        merged = FlatArena([(k, torch.nn.Parameter(p.detach().clone())) for k, p in named], groups, min_bucket=1 << 30)
+        assert len(merged.buckets) == 1 and merged.buckets[0][1:] == (0, merged.numel)        # small groups merge forward
+        # replicas: rank 1 starts from different parameters; broadcast() makes them rank 0's (DistributedDataParallel's contract)
+        ref0 = arena.p.clone()
+        if rank == 1:
+            with torch.no_grad():
+                arena.p.add_(1.0)
+        arena.broadcast(0)
+        chk = arena.p.clone()
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        assert torch.equal(chk, world * arena.p) and torch.equal(arena.p, ref0)
         assert all(p.grad.data_ptr() >= arena.g.data_ptr() for p in params)
         arena.zero_grad()
         g_local = _local_grads(P, rank, reset=False)
         # the oracle's autograd wrote into the arena views in place (p.grad pre-assigned)
         for (k, p) in [(k, p) for k, p in P.items() if isinstance(p, torch.nn.Parameter)]:
             assert p.grad.data_ptr() >= arena.g.data_ptr() and torch.equal(p.grad, g_local[k])
-        arena.all_reduce(world)
+        for _, lo, hi in arena.buckets:          # the bucket schedule TrainStep walks (one collective per bucket, in arena order)
+            arena._reduce_range(lo, hi, None)
+        sd = arena.state_dict()
+        arena.load_state_dict(sd)
+        assert set(sd["exp_avg"]) == {k for k, _ in named} and sd["step"] == 0
         avg = {k: p.grad.clone() / world for k, p in P.items() if isinstance(p, torch.nn.Parameter)}
         if rank == 0:
             P2 = _make_state()

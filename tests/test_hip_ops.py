@@ -36,7 +36,7 @@ def check(name, got, want, rtol, atol):
                              f"want {want[idx].item():.6g} (|err| {err[idx].item():.3g}, max|want| {want.abs().max().item():.3g})")
 
 
-TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2), torch.float16: dict(rtol=4e-3, atol=4e-3)}
 
 
 # --------------------------------------------------------------------------- layout probes
@@ -93,7 +93,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_fwd_bwd(dev, dtype, case):
     from octave_amd import functional as F_
@@ -101,13 +101,13 @@ def test_conv2d_fwd_bwd(dev, dtype, case):
     x = rnd((B, Cin, H, W), 1)
     w = rnd((Cout, Cin // g, k, k), 2) * (1.0 / (k * k * Cin / g) ** 0.5)
     b = rnd((Cout,), 3)
-    if dtype == torch.bfloat16:   # compare against the same rounded operands
-        x, w = x.bfloat16().float(), w.bfloat16().float()
+    if dtype != torch.float32:   # compare against the same rounded operands
+        x, w = x.to(dtype).float(), w.to(dtype).float()
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = F.conv2d(xr, wr, br, stride=s, padding=p, groups=g)
     gy = rnd(tuple(yr.shape), 4)
-    if dtype == torch.bfloat16:
-        gy = gy.bfloat16().float()
+    if dtype != torch.float32:
+        gy = gy.to(dtype).float()
     (yr * gy).sum().backward()
 
     xd = x.to(dev).to(dtype).requires_grad_(True)
@@ -124,14 +124,14 @@ def test_conv2d_fwd_bwd(dev, dtype, case):
     check(f"conv bias grad {case}", bd.grad, br.grad, rtol=t["rtol"], atol=t["atol"] * sc)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_conv2d_channels_last_weight_and_act(dev, dtype):
     from octave_amd import functional as F_
     from octave_amd._lib import ACT_TANH
     x = rnd((2, 16, 6, 6), 5)
     w = rnd((24, 16, 3, 3), 6) * 0.1
-    if dtype == torch.bfloat16:
-        x, w = x.bfloat16().float(), w.bfloat16().float()
+    if dtype != torch.float32:
+        x, w = x.to(dtype).float(), w.to(dtype).float()
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yr = torch.tanh(F.conv2d(xr, wr, None, padding=1))
     gy = rnd(tuple(yr.shape), 7)
@@ -147,7 +147,7 @@ def test_conv2d_channels_last_weight_and_act(dev, dtype):
     assert wd.grad.stride() == wd.stride()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(16, 8, 2, 5, 3), (64, 32, 2, 6, 6), (24, 40, 1, 4, 7)])
 def test_conv_transpose2x2(dev, dtype, shape):
     from octave_amd import functional as F_
@@ -155,13 +155,13 @@ def test_conv_transpose2x2(dev, dtype, shape):
     x = rnd((B, Cin, H, W), 8)
     w = rnd((Cin, Cout, 2, 2), 9) * 0.2
     b = rnd((Cout,), 10)
-    if dtype == torch.bfloat16:
-        x, w = x.bfloat16().float(), w.bfloat16().float()
+    if dtype != torch.float32:
+        x, w = x.to(dtype).float(), w.to(dtype).float()
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = F.conv_transpose2d(xr, wr, br, stride=2)
     gy = rnd(tuple(yr.shape), 11)
-    if dtype == torch.bfloat16:
-        gy = gy.bfloat16().float()
+    if dtype != torch.float32:
+        gy = gy.to(dtype).float()
     (yr * gy).sum().backward()
     xd = x.to(dev).to(dtype).requires_grad_(True)
     wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
@@ -175,7 +175,7 @@ def test_conv_transpose2x2(dev, dtype, shape):
 
 
 # --------------------------------------------------------------------------- batch norm
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(32, 3, 7, 5, True, True), (64, 2, 6, 6, False, False), (2048, 2, 2, 2, True, False),
                                  (40, 4, 1, 1, True, False), (512, 2, 9, 9, False, True)])
 def test_batch_norm(dev, dtype, cfg):
@@ -185,8 +185,8 @@ def test_batch_norm(dev, dtype, cfg):
     res = rnd((B, C, H, W), 13)
     gam, bet = rnd((C,), 14, 0.5, 1.5), rnd((C,), 15)
     rm, rv = rnd((C,), 16), rnd((C,), 17, 0.5, 1.5)
-    if dtype == torch.bfloat16:
-        x, res = x.bfloat16().float(), res.bfloat16().float()
+    if dtype != torch.float32:
+        x, res = x.to(dtype).float(), res.to(dtype).float()
     xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
     gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
     rmr, rvr = rm.clone(), rv.clone()
@@ -223,15 +223,15 @@ def test_batch_norm_single_value_raises(dev):
 
 
 # --------------------------------------------------------------------------- pooling / copies
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_pools(dev, dtype):
     from octave_amd import functional as F_
     t = TOL[dtype]
     for (B, C, H, W) in [(2, 16, 8, 8), (2, 8, 9, 7), (1, 64, 12, 12)]:
         x = rnd((B, C, H, W), 20, -1, 1)
         x[:, :, ::3, ::2] = 0.0   # ties, like post-ReLU maps
-        if dtype == torch.bfloat16:
-            x = x.bfloat16().float()
+        if dtype != torch.float32:
+            x = x.to(dtype).float()
         for name, fr, fg in [
             ("maxpool3s2", lambda a: F.max_pool2d(a, 3, 2, 1), lambda a: F_.max_pool3s2(a)),
             ("avgpool3s2p1", lambda a: F.avg_pool2d(a, 3, 2, 1), lambda a: F_.avg_pool(a, 3, 2, 1)),
@@ -306,7 +306,7 @@ def test_losses_vs_oracle_random(dev):
     check("wpce strided grad", pd.grad, pr.grad, 2e-4, 1e-8)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_repack_all_matches_per_weight_packs(dev, dtype):
     """octa_pack_many (one launch, linear + LDS-transposed tiles) must reproduce the per-weight pack kernels bit for bit:
     forward, data-gradient and conv-transpose operands, channels-last and plain OIHW parameters, grouped, padded, odd sizes;
@@ -358,15 +358,15 @@ def test_repack_all_matches_per_weight_packs(dev, dtype):
     assert torch.equal(F_._packed(dense, "dgrad", dtype, 1, 64).reshape(-1), single[-1].reshape(-1))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(3, 32, 37, 29), (2, 13, 9, 7), (2, 264, 5, 6), (1, 2048, 3, 3), (4, 8, 50, 50)])
 def test_colsum(dev, dtype, shape):
     """bias-gradient column sums (16-byte vector kernel when C % 8 == 0, scalar kernel otherwise); accumulates into `out`."""
     from octave_amd import functional as F_
     B, C, H, W = shape
     x = rnd(shape, 21)
-    if dtype == torch.bfloat16:
-        x = x.bfloat16().float()
+    if dtype != torch.float32:
+        x = x.to(dtype).float()
     xd = F_.to_nhwc(x.to(dev), dtype=dtype)
     out = torch.full((C,), 0.5, dtype=torch.float32, device=dev)
     F_.raw_colsum(xd, out)
@@ -450,3 +450,85 @@ def test_batch_norm_full_size(dev):
     n = B * H * W
     assert (gam.grad.double() - (gd * xh).sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2
     assert (bet.grad.double() - gd.sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2
+
+
+# ----------------------------------------------------------------------------------------- round 2: 8-wave kernels
+IGEMM8_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, groups
+    (2, 64, 17, 19, 136, 3, 1, 1, 1),      # odd image, N tail, 3x3
+    (3, 128, 12, 10, 320, 1, 1, 0, 1),     # 1x1, two K steps, N = 256 + tail
+    (2, 64, 15, 16, 128, 3, 2, 1, 1),      # stride 2 (forward only on the 8-wave kernel; dgrad falls back)
+    (2, 128, 9, 9, 256, 3, 1, 1, 2),       # grouped (Cg = 64)
+    (1, 192, 20, 20, 130, 2, 2, 0, 1),     # k2 s2 (the ConvTranspose adjoint shape)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("algo", [2, 3])
+@pytest.mark.parametrize("case", IGEMM8_CASES)
+def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
+    """The 8-wave LDS-DMA kernel (octa_conv_desc.algo 2 / 3) on awkward shapes against torch's CPU conv on the same rounded
+    operands (fp32 accumulation on both sides)."""
+    from octave_amd import functional as F_
+    B, Cin, H, W, Cout, k, s, p, g = case
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias, s, p, 1, g))
+    F_._ALGO_OVERRIDE = algo
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), s, p, g, 1)
+        from octave_amd._lib import lib
+        name = lib().octa_last_conv_kernel().decode()
+        assert "conv_igemm8_kernel" in name, name
+        t = TOL[dtype]
+        check(f"igemm8 fwd {case} algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+        dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
+        dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), s, p, g)
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w, None, s, p, 1, g).backward(dy)
+    check(f"igemm8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wgrad_batch_vs_torch(dev, dtype):
+    """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations, a grouped conv, a strided one, a small-N job that falls
+    through to the single-problem kernel, fused bias gradients) in ONE call against torch's CPU gradients."""
+    import ctypes
+    from octave_amd import functional as F_
+    from octave_amd._lib import WgradJob, lib
+    L = lib()
+    cases = [(3, 24, 9, 11, 136, 1, 1, 0, 1, True), (2, 40, 13, 10, 130, 3, 1, 1, 1, True), (2, 16, 15, 17, 256, 3, 2, 1, 1, False),
+             (2, 32, 12, 12, 256, 3, 1, 1, 2, True), (2, 15, 20, 20, 128, 4, 2, 1, 1, True), (2, 320, 9, 9, 384, 3, 1, 1, 1, False),
+             (2, 32, 10, 10, 48, 3, 1, 1, 1, True)]
+    gen = torch.Generator().manual_seed(3)
+    jobs = (WgradJob * len(cases))()
+    keep, want = [], []
+    for j, (B, Cin, H, W, Cout, k, s, p, g, bias) in enumerate(cases):
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+        dy = torch.randn(B, Cout, OH, OW, generator=gen).to(dtype).float()
+        xd, dyd = F_.to_nhwc(x.to(dev), dtype=dtype, cpad=F_.round8(Cin // g) if g == 1 else Cin), F_.to_nhwc(dy.to(dev), dtype=dtype, cpad=F_.round8(Cout // g) if g == 1 else Cout)
+        dw = torch.zeros(Cout, Cin // g, k, k, device=dev).contiguous(memory_format=torch.channels_last)
+        db = torch.zeros(Cout, device=dev) if bias else None
+        d = F_._desc(B, H, W, OH, OW, Cin, Cout, k, k, s, p, g, F_.nhwc_ld(xd), F_.nhwc_ld(dyd), dtype)
+        ctypes.memmove(ctypes.byref(jobs[j].d), ctypes.byref(d), ctypes.sizeof(d))
+        jobs[j].x, jobs[j].dy, jobs[j].dw, jobs[j].dbias = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr() if bias else None
+        for a in range(4):
+            jobs[j].dw_strides[a] = dw.stride(a)
+        wr = torch.zeros(Cout, Cin // g, k, k, requires_grad=True)
+        torch.nn.functional.conv2d(x, wr, None, s, p, 1, g).backward(dy)
+        keep.append((xd, dyd, dw, db))
+        want.append((wr.grad, dy.sum((0, 2, 3))))
+    classes = [int(L.octa_wgrad_job_class(ctypes.byref(jobs[j]))) for j in range(len(cases))]
+    assert set(classes) == {0, 1, 2}, classes
+    L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+    for j, ((xd, dyd, dw, db), (gw, gb)) in enumerate(zip(keep, want)):
+        check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))
+        if db is not None:
+            check(f"wgrad batch bias {j}", db, gb, 0, 1e-3 * float(gb.abs().max()) + 1e-3)

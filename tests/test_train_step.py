@@ -210,7 +210,7 @@ def test_train_step_hipgraph_replay_matches_eager():
             a.step_count = n
         torch.set_rng_state(rng)
         F_.bump_weight_epoch()
-        oe = {k: v.clone() for k, v in st._eager_static().items()}
+        oe = {k: v.clone() for k, v in st._eager_static(st._caps[H]).items()}
         torch.cuda.synchronize()
     finally:
         st.close()
@@ -282,7 +282,7 @@ def test_train_step_launch_paths_are_interchangeable():
         st.capture(x, ys, pyr)
         n0 = st.seg_arena.step_count
         assert st.autotune_launch(x, ys, pyr, rounds=1, steps=1) in ("graph", "eager")
-        assert st.seg_arena.step_count == n0 + 2
+        assert st.seg_arena.step_count == n0       # the timing steps are rolled back (parameters, moments, counters, buffers, RNG)
         for mode in ("eager", "graph", "eager", "graph"):
             st.launch = mode
             rng_before = torch.get_rng_state().clone()
@@ -291,7 +291,247 @@ def test_train_step_launch_paths_are_interchangeable():
             assert all(np.isfinite(v.item()) for v in out.values()), (mode, out)
             # every step draws fresh discriminator noise from the global CPU generator, whichever path launches it
             assert not torch.equal(rng_before, torch.get_rng_state()), mode
-        assert st.seg_arena.step_count == n0 + 6 and st.disc_arena.step_count == n0 + 6
-        assert int(dict(net.named_buffers())["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == n0 + 6
+        assert st.seg_arena.step_count == n0 + 4 and st.disc_arena.step_count == n0 + 4
+        assert int(dict(net.named_buffers())["segmentor.encoder_0_1_2.1.num_batches_tracked"]) == n0 + 4
     finally:
         st.close()
+
+
+# ----------------------------------------------------------------------------------------- round 2
+def _net(Bn, H, dev, seed_fill=True):
+    from architectures.models.octa import OctaScribbleNet
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+    if seed_fill:
+        fill_state_dict(net.state_dict())
+    return net.to(dev).train()
+
+
+def test_train_step_segmentor_only_config2():
+    """BASELINE config 2: TrainStep(adversarial=False) = WPCE + Dice only; the loss matches the module-level evaluation and
+    the discriminator is never touched."""
+    from octave_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    Bn, H = 4, 48
+    net = _net(Bn, H, dev)
+    x, ys, real = _inputs(Bn, H, dev)
+    d_before = {k: v.clone() for k, v in net.discriminator.state_dict().items()}
+    st = TrainStep(net, lr=1e-3, compute_dtype=torch.float32, adversarial=False)
+    try:
+        losses = [float(st(x, ys)["loss_seg"]) for _ in range(5)]
+        out = st(x, ys)
+    finally:
+        st.close()
+    assert set(out) == {"wpce", "dice", "loss_seg"} and st.disc_arena is None
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert abs(float(out["wpce"]) + float(out["dice"]) - float(out["loss_seg"])) < 1e-5
+    for k, v in net.discriminator.state_dict().items():
+        assert torch.equal(v, d_before[k]), k
+
+
+def test_train_step_fp16_mixed_resolution_config5():
+    """BASELINE config 5 on one GPU: fp16 activations (losses accumulate in fp32, static loss scale) and steps alternating
+    between two resolutions.  The reference's discriminator is tied to one resolution, so the second one gets its own
+    head (share_body_with); a step updates the shared body and only the head of ITS resolution."""
+    from architectures.discriminator.blocks import DiscriminatorBlock
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    Bn, Ha, Hb = 4, 64, 96
+    torch.manual_seed(0)
+    net = _net(Bn, Ha, dev, seed_fill=False)           # the reference's own initialisers (the closed-form test fill makes D's logits ~40)
+    d_b = DiscriminatorBlock(torch.Size((Bn, 2, Hb, Hb)), is_training=True, depth=4, num_filters=64).to(dev).train().share_body_with(net.discriminator)
+    assert d_b.out[0].weight.shape[-1] == Hb // 32 and net.discriminator.out[0].weight.shape[-1] == Ha // 32
+    assert d_b.squeeze_dict is net.discriminator.squeeze_dict
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.float16, loss_scale=256.0, extra_discriminators={Hb: d_b})
+    try:
+        batches = {H: _inputs(Bn, H, dev) for H in (Ha, Hb)}
+        head_a, head_b = net.discriminator.out[0].weight, d_b.out[0].weight
+        body = net.discriminator.squeeze_dict["squeeze_0"][0].weight
+        a0, b0, c0 = head_a.detach().clone(), head_b.detach().clone(), body.detach().clone()
+        x, ys, real = batches[Ha]
+        out = st(x, ys, mask_pyramid(real))
+        assert all(np.isfinite(float(v)) for v in out.values()), out
+        assert not torch.equal(head_a, a0) and torch.equal(head_b, b0) and not torch.equal(body, c0)      # only resolution A's head moved
+        a1, c1 = head_a.detach().clone(), body.detach().clone()
+        x, ys, real = batches[Hb]
+        out = st(x, ys, mask_pyramid(real))
+        assert all(np.isfinite(float(v)) for v in out.values()), out
+        assert torch.equal(head_a, a1) and not torch.equal(head_b, b0) and not torch.equal(body, c1)
+        # captured per resolution, replayed alternately
+        for H in (Ha, Hb):
+            x, ys, real = batches[H]
+            st.capture(x, ys, mask_pyramid(real))
+        assert sorted(st._caps) == [Ha, Hb]
+        for H in (Ha, Hb, Ha, Hb):
+            x, ys, real = batches[H]
+            out = st(x, ys, mask_pyramid(real))
+            torch.cuda.synchronize()
+            assert all(np.isfinite(float(v)) for v in out.values()), (H, out)
+        for k, p in net.segmentor.named_parameters():
+            assert torch.isfinite(p).all(), k
+    finally:
+        st.close()
+
+
+def test_train_step_single_rank_rccl_buckets_and_capture():
+    """The RCCL path with ONE rank (backend "nccl" = RCCL): parameter/buffer broadcast at construction, bucketed gradient
+    all-reduce started from the backward stage marks (eager) and after the segmentor graph (replay), side comm stream, capture
+    under thread_local mode.  With one rank the sums are identities, so the step must equal the non-distributed step."""
+    import os
+    import torch.distributed as dist
+    from octave_amd import train as T
+    dev = torch.device("cuda:0")
+    Bn, H = 4, 48
+    x, ys, real = _inputs(Bn, H, dev)
+
+    def run(distributed):
+        torch.manual_seed(0)
+        net = _net(Bn, H, dev, seed_fill=False)        # the reference's own initialisers (tame discriminator logits)
+        net.discriminator._has_noise and setattr(net.discriminator.stack_0[0], "is_training", False)
+        torch.manual_seed(5)
+        st = T.TrainStep(net, lr=1e-4, compute_dtype=torch.float32)
+        try:
+            assert st.overlap_backward == distributed
+            pyr = T.mask_pyramid(real)
+            outs = [{k: float(v) for k, v in st(x, ys, pyr).items()} for _ in range(2)]
+            res = (outs[0], outs[1])
+            nb = len(st.seg_arena.buckets)
+            started = list(st._started)
+            st.capture(x, ys, pyr)
+            st.launch = "graph"
+            o = st(x, ys, pyr)
+            torch.cuda.synchronize()
+            res2 = {k: float(v) for k, v in o.items()}
+            return res, res2, nb, started, st.seg_arena.p.clone()
+        finally:
+            st.close()
+    ref, ref2, _, _, p_ref = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    old = T.FORCE_ALLREDUCE
+    T.FORCE_ALLREDUCE = True
+    try:
+        got, got2, nb, started, p_got = run(True)
+    finally:
+        T.FORCE_ALLREDUCE = old
+        dist.destroy_process_group()
+    assert nb >= 5, nb
+    assert len(started) >= nb - 1, (started, nb)        # every bucket but (at most) the last was started from a stage mark
+    # step 1 starts from identical weights: equal up to the summation order of the float atomics.  Later steps only agree
+    # loosely -- Adam turns a rounding-level gradient difference into a +-lr parameter difference (the graph-vs-eager test
+    # documents the same effect) -- and no parameter may be further apart than (number of steps) x 2 lr
+    for k in ref[0]:
+        assert abs(ref[0][k] - got[0][k]) <= 1e-4 * abs(ref[0][k]) + 1e-5, (k, ref[0][k], got[0][k])
+        assert np.isfinite(got[1][k]) and np.isfinite(got2[k]), (k, got[1][k], got2[k])
+    assert (p_ref - p_got).abs().max().item() <= 5 * 2 * 1e-4 + 1e-6        # 2 eager + 2 capture warm-up + 1 replayed step
+
+
+def test_optimizer_state_roundtrip_and_autotune_has_no_side_effect():
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    Bn, H = 4, 48
+    x, ys, real = _inputs(Bn, H, dev)
+    pyr = mask_pyramid(real)
+    net = _net(Bn, H, dev)
+    st = TrainStep(net, lr=1e-3, compute_dtype=torch.float32)
+    try:
+        st(x, ys, pyr)
+        sd_opt, sd_net = st.state_dict(), {k: v.clone() for k, v in net.state_dict().items()}
+        assert set(sd_opt) == {"segmentor", "discriminator"} and sd_opt["segmentor"]["step"] == 1
+        assert "encoder_1.0.conv1.weight" in sd_opt["segmentor"]["exp_avg"]
+        rng = torch.get_rng_state()
+        want = {k: float(v) for k, v in st(x, ys, pyr).items()}
+        p_want = st.seg_arena.p.clone()
+        # resume: a fresh step object on a fresh network restored from the two state dicts repeats that step exactly
+        net2 = _net(Bn, H, dev, seed_fill=False)
+        net2.load_state_dict(sd_net)
+        st.close()
+        st2 = TrainStep(net2, lr=1e-3, compute_dtype=torch.float32)
+        st2.load_state_dict(sd_opt)
+        torch.set_rng_state(rng)
+        got = {k: float(v) for k, v in st2(x, ys, pyr).items()}
+        for k in want:
+            assert abs(want[k] - got[k]) <= 1e-5 * abs(want[k]) + 1e-6, (k, want[k], got[k])
+        # the gradients differ at rounding level (float atomics): Adam may move an element with a near-zero gradient by up to 2 lr
+        dp = (st2.seg_arena.p - p_want).abs()
+        assert dp.max().item() <= 2.1e-3 and dp.median().item() <= 1e-6, (dp.max().item(), dp.median().item())
+        # autotune_launch runs real steps to time the two launch paths, and must leave no trace of them
+        st2.capture(x, ys, pyr)
+        before = (st2.seg_arena.p.clone(), st2.seg_arena.m.clone(), st2.seg_arena.step_count, torch.get_rng_state(),
+                  {k: v.clone() for k, v in net2.state_dict().items()})
+        assert st2.autotune_launch(x, ys, pyr, rounds=1, steps=1) in ("graph", "eager") and set(st2.launch_timing) == {"graph", "eager"}
+        assert torch.equal(st2.seg_arena.p, before[0]) and torch.equal(st2.seg_arena.m, before[1]) and st2.seg_arena.step_count == before[2]
+        assert torch.equal(torch.get_rng_state(), before[3])
+        for k, v in net2.state_dict().items():
+            assert torch.equal(v, before[4][k]), k
+        st2.close()
+    finally:
+        st.close()
+
+
+def test_checkpoint_roundtrip_through_pretrained_loader(tmp_path):
+    """a reference-keyed ResNet checkpoint (resnest50-528c19ca.pth layout: conv1.*, bn1.*, layer1-4.*, fc.*)
+    loads through resnest50(pretrained=True, model_path=...) as ResnestUNet(pretrain=True, weight_path=...) does (ref
+    extra/resnest.py:456-458, segmentor/compose.py:24,40-73), lands under the U-Net's encoder_* keys, and a whole
+    OctaScribbleNet state_dict round-trips through torch.save / load_state_dict bit for bit."""
+    from architectures.extra.resnest import resnest50
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.compose import ResnestUNet
+    src = resnest50(pretrained=False)
+    fill_state_dict(src.state_dict())
+    ck = tmp_path / "resnest50-test.pth"
+    torch.save({k: v.clone().contiguous() for k, v in src.state_dict().items()}, ck)
+    assert "layer1.0.conv2.fc1.weight" in src.state_dict() and "fc.weight" in src.state_dict()
+    unet = ResnestUNet(2, True, str(ck))
+    sd, ssd = unet.state_dict(), src.state_dict()
+    for a, b in (("encoder_0_1_2.0.0.weight", "conv1.0.weight"), ("encoder_0_1_2.1.running_var", "bn1.running_var"),
+                 ("encoder_1.0.conv2.fc1.weight", "layer1.0.conv2.fc1.weight"), ("encoder_4.2.bn3.bias", "layer4.2.bn3.bias"),
+                 ("encoder_3.5.conv2.conv.weight", "layer3.5.conv2.conv.weight")):
+        assert torch.equal(sd[a], ssd[b]), (a, b)
+    net = OctaScribbleNet(torch.Size((2, 3, 48, 48)), torch.Size((2, 2, 48, 48)), True, True, str(ck))
+    fill_state_dict(net.state_dict(), salt=3)
+    f = tmp_path / "octa.pth"
+    torch.save(net.state_dict(), f)
+    net2 = OctaScribbleNet(torch.Size((2, 3, 48, 48)), torch.Size((2, 2, 48, 48)), True, False)
+    missing = net2.load_state_dict(torch.load(f))
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # ... and the restored network runs on the HIP path
+    dev = torch.device("cuda:0")
+    net2 = net2.to(dev).eval()
+    with torch.no_grad():
+        att, agg, _ = net2.segmentor(hash_input((2, 3, 48, 48), 5).to(dev))
+    assert torch.isfinite(agg).all()
+
+
+@pytest.mark.parametrize("H", [400, 304])
+def test_baseline_size_bf16_vs_fp32_hip(H):
+    """BASELINE sizes on the GPU (the CPU oracle needs minutes there): B = 16 at 400 x 400 and 304 x 304, bf16 against the HIP
+    fp32 run of the same network: finite losses, the same argmax mask on high-margin pixels, Dice within 1e-3."""
+    from octave_amd import functional as F_
+    dev = torch.device("cuda:0")
+    Bn = 16
+    x, ys, real = F_.synth_octa_batch(Bn, H, H, seed=77, device=dev, vessel=True)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        net = _net(Bn, H, dev, seed_fill=False)
+        net.segmentor.compute_dtype = dt
+        with torch.no_grad():
+            att, agg, _ = net.segmentor(x)
+            l = F_.wpce_dice(agg, ys, from_logits=True)
+        assert torch.isfinite(agg).all() and torch.isfinite(l).all()
+        res[dt] = (agg.float(), l)
+        del net
+    a32, a16 = res[torch.float32][0], res[torch.bfloat16][0]
+    margin = (a32[:, 0] - a32[:, 1]).abs()
+    big = margin > 0.25 * a32.abs().max()
+    agree = (a32.argmax(1)[big] == a16.argmax(1)[big]).float().mean().item()
+    d32 = F_.dice_coefficient(F_.predict_one_hot(a32).float(), real[:, :F_.predict_one_hot(a32).shape[1]])
+    d16 = F_.dice_coefficient(F_.predict_one_hot(a16).float(), real[:, :F_.predict_one_hot(a16).shape[1]])
+    print(f"[B16 {H}] argmax agreement on high-margin pixels {agree:.4f} ({int(big.sum())} px), Dice fp32 {d32.mean().item():.4f} bf16 {d16.mean().item():.4f}, "
+          f"loss fp32 {res[torch.float32][1].tolist()} bf16 {res[torch.bfloat16][1].tolist()}")
+    assert agree > 0.98
+    if d32.shape == d16.shape:
+        assert (d32.mean() - d16.mean()).abs().item() <= 1e-3 + 0.02 * (1 - agree)
