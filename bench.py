@@ -27,8 +27,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16 / f16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md
 
 
 def host_cores() -> int:
@@ -46,7 +47,11 @@ def host_cores() -> int:
 
 def synth_batch(B, H, rank, device):
     """SURVEY.md 8d: grayscale OCTA-like plane replicated to 3 channels; scribbles ~5 % per class;
-    dense real vessel mask, one-hot."""
+    dense real vessel mask, one-hot.  On the GPU the batch is generated ON the device (octa_synth_octa, a counter-based
+    generator keyed on (seed, element)); the host generator below serves the CPU baseline leg and the CPU tests."""
+    if torch.device(device).type == "cuda":
+        from octave_amd import functional as F_
+        return F_.synth_octa_batch(B, H, H, seed=1234 + 7919 * rank, device=device)
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand((B, 1, H, H), generator=g).repeat(1, 3, 1, 1)
     g2 = torch.Generator().manual_seed(4321 + rank)
@@ -58,6 +63,19 @@ def synth_batch(B, H, rank, device):
     dense = (torch.rand((B, H, H), generator=g3) > 0.8).long()
     real = torch.nn.functional.one_hot(dense, 2).permute(0, 3, 1, 2).float().contiguous()
     return x.to(device), ys.to(device), real.to(device)
+
+
+def conv_bytes(d, kind):
+    """Algorithmic HBM bytes of one conv-engine launch: every operand once (activations in the compute dtype, the weight
+    gradient in fp32)."""
+    es = 4 if d.dtype == 0 else 2
+    groups = getattr(d, "alg_groups", d.groups)
+    wel = d.Cout * (d.Cin // groups) * d.KH * d.KW
+    xin = d.B * d.H * d.W * d.Cin
+    yout = d.B * d.OH * d.OW * (d.Cout if not d.upshuffle else d.Cout)
+    if kind == "wgrad":
+        return es * (xin + yout) + 4.0 * wel
+    return es * (xin + yout + wel)
 
 
 def conv_flops(d):
@@ -109,32 +127,44 @@ def roofline_leg(step, batch, dtype_name):
         launch()
         e1.record()
         fl = sum(conv_flops(d[i].d) for i in range(ptrs)) if kind == "wgrad_batch" else conv_flops(d)
-        pending.append((e0, e1, L.octa_last_conv_kernel().decode(), fl))
+        by = sum(conv_bytes(d[i].d, "wgrad") for i in range(ptrs)) if kind == "wgrad_batch" else conv_bytes(d, kind)
+        pending.append((e0, e1, L.octa_last_conv_kernel().decode(), fl, by))
     torch.cuda.synchronize()
-    for e0, e1, kname, fl in pending:
+    peak = PEAK_BF16_TFLOPS if dtype_name in ("bf16", "f16") else PEAK_F32_TFLOPS
+    for e0, e1, kname, fl, by in pending:
         ms = e0.elapsed_time(e1)
-        a = agg.setdefault(kname, [0.0, 0.0, 0])
+        a = agg.setdefault(kname, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
         a[0] += fl
         a[1] += ms * 1e-3
         a[2] += 1
+        a[3] += by
+        # the roofline of ONE launch: the slower of its MFMA time and its HBM time
+        a[4] += fl / (peak * 1e12)
+        a[5] += by / (PEAK_HBM_GBS * 1e9)
     tot_f = sum(a[0] for a in agg.values())
     tot_t = sum(a[1] for a in agg.values())
-    name, (f, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
-    peak = PEAK_BF16_TFLOPS if dtype_name == "bf16" else PEAK_F32_TFLOPS
+    name, (f, t, n, byt, t_mfma, t_hbm) = max(agg.items(), key=lambda kv: kv[1][1])
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # their own runs, gfx950 correction applied by tools/pmc_traffic.py); null when the kernel was not profiled
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
         if name in pm and batch[0].shape[0] == 16 and batch[0].shape[-1] == 400:
             traffic = round(pm[name]["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
-    per_kernel = {k: {"launches_per_step": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    per_kernel = {k: {"launches_per_step": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2),
+                      "gbs": round(v[3] / v[1] / 1e9, 1), "bound": "mfma" if v[4] >= v[5] else "hbm",
+                      "frac": round(max(v[4], v[5]) / v[1], 4)} for k, v in agg.items()}
+    # which roofline bounds the dominant kernel: summed over its launches, the larger of the ideal MFMA time (algorithmic FLOPs
+    # at the dense peak) and the ideal HBM time (algorithmic bytes at 8 TB/s); `achieved` is quoted in that roofline's unit
+    if t_mfma >= t_hbm:
+        bound = {"bound": "mfma", "achieved": round(f / t / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / peak, 4)}
+    else:
+        bound = {"bound": "hbm", "achieved": round(byt / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(byt / t / 1e9 / PEAK_HBM_GBS, 4)}
     return {
-        "bound": "mfma", "kernel": name, "achieved": round(f / t / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(f / t / 1e12 / peak, 4), "traffic": traffic,
-        "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n,
+        **bound, "kernel": name, "traffic": traffic, "mfma_frac": round(f / t / 1e12 / peak, 4), "hbm_frac": round(byt / t / 1e9 / PEAK_HBM_GBS, 4),
+        "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n, "bytes_per_launch_avg": byt / n,
         "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
                              "time_ms_per_step": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_f / 1e9, 1)},
         "per_kernel": per_kernel,
@@ -187,11 +217,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--loss-scale", type=float, default=None, help="static loss scale (default 1; 1024 for f16)")
     ap.add_argument("--seg-only", action="store_true", help="BASELINE configs[1]: segmentor-only (WPCE+Dice)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
                     help="after capture: replay the hipGraphs, launch the same static step from Python, or time both and pick (default)")
+    ap.add_argument("--algo-cache", default=None, help="JSON file with measured per-shape conv kernel choices: loaded if present, written after warm-up")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -233,8 +265,9 @@ def main():
     torch.manual_seed(0)      # identical default-init weights on every rank
     net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
     net_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only)
+    cdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    ls = args.loss_scale if args.loss_scale is not None else (1024.0 if args.dtype == "f16" else 1.0)
+    step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only, loss_scale=ls)
     x, ys, real = synth_batch(B, H, rank, dev)
     batch = (x, ys, mask_pyramid(real))
 
@@ -242,6 +275,9 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_begin:7.1f}s] {msg}", file=sys.stderr, flush=True)
     log(f"model built, {B}x3x{H}x{H} {args.dtype}, world {world}")
+    from octave_amd import functional as F_
+    if args.algo_cache and F_.load_algo_cache(args.algo_cache):
+        log(f"loaded {len(F_._ALGO_CACHE)} measured kernel choices from {args.algo_cache}")
     if not args.no_graph:
         step.capture(*batch)
         log("step captured into hipGraphs (2 eager warm-up steps)")
@@ -250,6 +286,8 @@ def main():
             log(f"launch path: {step.launch} (ms/step graph {step.launch_timing['graph'] * 1e3:.1f}, eager {step.launch_timing['eager'] * 1e3:.1f})")
         else:
             step.launch = args.launch
+    if args.algo_cache and rank == 0 and not os.path.exists(args.algo_cache):
+        F_.save_algo_cache(args.algo_cache)
     for i in range(args.warmup):
         step(*batch)
         torch.cuda.synchronize()
@@ -281,7 +319,7 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "images/sec (seg+disc train step) 400x400 bf16" if not args.seg_only else "images/sec (segmentor-only train step)",
+            "metric": f"images/sec (seg+disc train step) {H}x{H} {args.dtype}" if not args.seg_only else f"images/sec (segmentor-only train step) {H}x{H} {args.dtype}",
             "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -289,6 +327,7 @@ def main():
                                     if not args.seg_only else "OctaScribbleNet segmentor-only step (WeightedPartialCE + Dice), ")
                        + f"batch {B}/GPU, {H}x{H}", "global_batch": world * B, "image": H, "parallelism": f"dp{world}",
                        "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)",
+                       "data": "generated on the device (octa_synth_octa)", "grad_buckets": len(step.seg_arena.buckets),
                        "launch": "eager" if args.no_graph else ("hipGraph replay (4 graphs around the 2 gradient all-reduces)" if step.launch == "graph"
                                                                else "eager launches of the captured static step (auto-tuned: faster than graph replay on this host)")},
             "final_loss_seg": round(loss, 5),

@@ -60,8 +60,9 @@ typedef struct octa_conv_desc {
                               n = (di*2+dj)*Cout_t + co is scattered to pixel (2h+di, 2w+dj)   */
     int32_t algo;          /* fwd / dgrad kernel choice: 0 = library heuristic, 1 = 4-wave kernels (3x3 halo
                               / generic tiles), 2 / 3 = 8-wave LDS-DMA kernel with 256x128 / 128x256
-                              (pixels x channels) output slabs.  A choice the shape does not allow falls
-                              back to the heuristic.  Results are identical up to fp32 summation order.  */
+                              (pixels x channels) output slabs, 4 / 5 / 6 = generic 4-wave kernel with 128x128 /
+                              64x64 / 128x64 tiles.  A choice the shape does not allow falls back to the
+                              heuristic.  Results are identical up to fp32 summation order.            */
 } octa_conv_desc;
 
 /* OIHW-logical fp32 weight (any strides, given in elements) -> packed forward operand

@@ -679,6 +679,14 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         }
         if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
     }
+    // explicit 4-wave tile choices (measured per shape by the training step's autotuner): 4 = 128x128, 5 = 64x64, 6 = 128x64
+    if (algo >= 4 && algo <= 6) {
+        if (algo == 4) { conv_igemm_kernel<T, 2, 2, 4, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 128), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 128); }
+        else if (algo == 5) { conv_igemm_kernel<T, 2, 2, 2, 2><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 64, 64); }
+        else { conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 64); }
+        OCTA_CHECK_LAUNCH("conv_igemm");
+        return OCTA_OK;
+    }
     if (conv_variant() >= 1) {
         const bool done = a.mode == 0 ? launch_halo<T, 0>(a, groups, st) : launch_halo<T, 1>(a, groups, st);
         if (done) { OCTA_CHECK_LAUNCH("conv3x3_halo"); return OCTA_OK; }

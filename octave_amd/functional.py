@@ -381,6 +381,23 @@ def set_conv_autotune(on: bool):
     _AUTOTUNE = bool(on)
 
 
+def save_algo_cache(path: str):
+    """Persist the measured per-shape kernel choices (JSON) so that a later process -- a profiled run, a restarted job --
+    starts with them instead of timing every shape again."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), v] for k, v in _ALGO_CACHE.items()], f)
+
+
+def load_algo_cache(path: str) -> int:
+    import json
+    if not os.path.exists(path):
+        return 0
+    for k, v in json.load(open(path)):
+        _ALGO_CACHE[tuple(k)] = int(v)
+    return len(_ALGO_CACHE)
+
+
 def _choose_algo(kind: str, d, launch) -> int:
     if _ALGO_OVERRIDE:
         return _ALGO_OVERRIDE
@@ -393,9 +410,9 @@ def _choose_algo(kind: str, d, launch) -> int:
     if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
     cg = d.cin_g_pad if kind == "fwd" else d.cout_g_pad
-    cands = [1]
+    cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
     if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
-        cands += [2, 3]
+        cands += [2, 3]             # 8-wave LDS-DMA kernel, both slab orientations
     best, best_t = 1, None
     if len(cands) > 1:
         for c in cands:

@@ -15,7 +15,7 @@ net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, 
 step = TrainStep(net, compute_dtype=torch.bfloat16)
 x, ys, real = bench.synth_batch(B, H, 0, dev)
 batch = (x, ys, mask_pyramid(real))
-step(*batch); step(*batch)
+step.capture(*batch); step._caps = {}      # capture() autotunes the kernel choice per shape; then record an eager step
 F_.start_recording(); step(*batch); rec = F_.stop_recording()
 torch.cuda.synchronize()
 L = lib(); st = torch.cuda.current_stream().cuda_stream
@@ -56,7 +56,8 @@ for kind, d, ptrs, keep in rec:
     byt = esz * d.B * (d.H * d.W * d.Cin + d.OH * d.OW * up * (d.Cout // up if d.upshuffle else d.Cout)) + esz * d.Cout * (d.Cin // d.groups) * d.KH * d.KW
     ideal = max(fl / 650e12, byt / 5.0e12) * 1e6
     excess.append((us - ideal, us, ideal, kind, f"B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}"))
-    rows.append((us, kind, f"{'bf16' if d.dtype else 'f32'} B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}", fl))
+    kn = L.octa_last_conv_kernel().decode().replace("conv_", "").replace("_kernel", "")
+    rows.append((us, kind, f"{'bf16' if d.dtype else 'f32'} B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''} [{kn}]", fl))
 tot = sum(r[0] for r in rows)
 print(f"total conv time {tot/1e3:.2f} ms over {len(rows)} launches")
 agg = {}

@@ -18,6 +18,12 @@ def load(d, counter):
 
 def short(name):
     """rocprof kernel name -> the naming bench.py's roofline leg uses."""
+    m8 = re.match(r"void conv_igemm8_kernel<(unsigned short|f16_t), (\d+), (\d+), (\d+)>", name)
+    if m8:
+        return f"conv_igemm8_kernel<{'bf16' if m8.group(1) == 'unsigned short' else 'f16'},{int(m8.group(2)) * 64}x{int(m8.group(3)) * 64}>"
+    mw = re.match(r"void wgrad8_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
+    if mw:
+        return f"wgrad8_kernel<{'f16' if int(mw.group(3)) else 'bf16'},{int(mw.group(1)) * 64}x{int(mw.group(2)) * 64}>"
     m = re.match(r"void (conv_igemm_kernel|conv_wgrad_kernel|conv3x3_halo_kernel)<(unsigned short|float), (\d+), (\d+), (\d+), (\d+)", name)
     if not m:
         return name.split("(")[0].replace("void ", "")
