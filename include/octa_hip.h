@@ -63,6 +63,9 @@ typedef struct octa_conv_desc {
                               (pixels x channels) output slabs, 4 / 5 / 6 = generic 4-wave kernel with 128x128 /
                               64x64 / 128x64 tiles.  A choice the shape does not allow falls back to the
                               heuristic.  Results are identical up to fp32 summation order.            */
+    int32_t zero_pad;      /* 1 (groups == 1, no upshuffle): the kernel also stores zeros into the output's
+                              padding channels [C, round8(C)) (C = Cout for fwd, Cin for dgrad), so the
+                              caller need not pre-clear the buffer; needs off + round8(C) <= ld          */
 } octa_conv_desc;
 
 /* OIHW-logical fp32 weight (any strides, given in elements) -> packed forward operand
@@ -106,7 +109,8 @@ int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_pac
                       octa_stream_t stream);
 /* Strided data gradient as GEMM + col2im: Z[(b,oh,ow)][(ci*KH+kh)*KW+kw] = dy x W^T comes from
  * octa_conv2d_fwd (1x1, operand = the data-grad packed weight); this folds the overlapping taps:
- * dx[b,ih,iw,ci] = sum_{kh,kw : ih+pad-kh = stride*oh, ...} Z[...].  (discriminator/blocks.py:46,97) */
+ * dx[b,ih,iw,ci] = sum_{kh,kw : ih+pad-kh = stride*oh, ...} Z[...].  (discriminator/blocks.py:46,97)
+ * The padding channels [Cin, min(round8(Cin), lddx)) of every dx pixel are stored as zeros. */
 int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int Cin,
                 int KH, int KW, int stride, int pad, int dtype, octa_stream_t stream);
 /* dw[o,i,kh,kw] += sum_pixels dy * x   (fp32 gradient of the OIHW-logical parameter, addressed
@@ -363,13 +367,17 @@ int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask, float* ds
                         int H, int W, int dtype, octa_stream_t stream);
 /* Spectral norm (torch.nn.utils.spectral_norm, 1 power iteration; blocks.py:105-108).
  * w: fp32 [Cout][K] dense (OIHW flattened).  Updates u,v in place when do_power_iter, writes
- * sigma[0] and w_sn = w / sigma. */
+ * sigma[0] and w_sn = w / sigma.  uv_saved (optional, Cout + K floats) receives the u then v this call
+ * used, for the backward pass (u and v keep changing with every later forward).  ws_prezeroed: the first K
+ * floats of ws are already zero (the caller's step-wide zero slab), so no clearing launch is issued. */
 int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter,
                            float eps, float* sigma, float* w_sn, float* ws /* K + Cout floats */,
-                           octa_stream_t stream);
-/* dw += (dw_sn - (sum(dw_sn * w_sn)) u v^T) / sigma      (ws: 1 float) */
+                           float* uv_saved, int ws_prezeroed, octa_stream_t stream);
+/* dw (+)= (dw_sn - (sum(dw_sn * w_sn)) u v^T) / sigma      (ws: 1 float; accumulate 0 overwrites dw).
+ * dwsn_khw: 0 = dw_sn is dense OIHW like w_sn; KH*KW = dw_sn is channels-last [Cout][KH][KW][Cin], the layout
+ * octa_conv2d_wgrad's atomics prefer. */
 int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v,
-                           const float* sigma, int Cout, int K, float* dw, float* ws,
+                           const float* sigma, int Cout, int K, float* dw, float* ws, int accumulate, int ws_prezeroed, int dwsn_khw,
                            octa_stream_t stream);
 /* Full-extent conv = per-sample dot product (blocks.py:68-72): out[b] = x[b,:].w + bias.
  * x NHWC [B, n] of dtype, w fp32 [n] in the same (h,w,c) order. */

@@ -27,6 +27,7 @@ struct ConvArgs {
     int act, mode;        // mode 0: forward gather, 1: data-gradient gather
     int upshuffle, CoutT;
     int vec_store;
+    int NgSt;             // channels stored per group: Ng, or round8(Ng) when the pad channels are zero-filled here
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int nb = n0 + (wn * TN + i) * 16 + q * 4;
-            if (nb >= a.Ng) continue;
+            if (nb >= a.NgSt) continue;
             int chan = g * a.Ng + nb;
             int bidx = chan;
             if (a.upshuffle) {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+                for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? v[e] : 0.f);
             }
         }
     }
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int nb = n0 + (wn * TN + i) * 16 + q * 4;
-            if (nb >= a.Ng) continue;
+            if (nb >= a.NgSt) continue;
             int chan = g * a.Ng + nb;
             int bidx = chan;
             if (a.upshuffle) {
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
                 else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+                for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? v[e] : 0.f);
             }
         }
     }
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int nb = n0 + (wn * TN + i) * 16 + q * 4;
-            if (nb >= a.Ng) continue;
+            if (nb >= a.NgSt) continue;
             const int chan = g * a.Ng + nb;
             float v[4];
 #pragma unroll
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
                 else *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+                for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? v[e] : 0.f);
             }
         }
     }
@@ -763,6 +764,11 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     a.M = d->B * d->OH * d->OW; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = d->act; a.mode = 0; a.upshuffle = d->upshuffle; a.CoutT = d->upshuffle ? d->Cout / 4 : 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->yoff % 4 == 0) && (d->ldy % 4 == 0) && (!d->upshuffle || a.CoutT % 4 == 0);
+    a.NgSt = a.Ng;
+    if (d->zero_pad) {
+        OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
+        a.NgSt = (a.Ng + 7) / 8 * 8;
+    }
     if (d->upshuffle) OCTA_REQUIRE(d->ldy >= a.CoutT + d->yoff, "octa_conv2d_fwd: ldy too small for upshuffle");
     else OCTA_REQUIRE(d->ldy >= d->Cout + d->yoff, "octa_conv2d_fwd: ldy %d < yoff+Cout", d->ldy);
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
@@ -790,6 +796,11 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     a.M = d->B * d->H * d->W; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
+    a.NgSt = a.Ng;
+    if (d->zero_pad) {
+        OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
+        a.NgSt = (a.Ng + 7) / 8 * 8;
+    }
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
          : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
                                  : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
@@ -1484,15 +1495,16 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ z, int ldz, T* __restrict__ dx, int lddx, int B, int H, int W, int OH,
                                                      int OW, int Cin, int KH, int KW, int stride, int pad) {
-    const int64_t total = (int64_t)B * H * W * Cin;
+    const int CinP = min((Cin + 7) / 8 * 8, lddx);     // the chunk's padding channels are stored as zeros
+    const int64_t total = (int64_t)B * H * W * CinP;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ci = (int)(i % Cin);
-        int64_t p = i / Cin;
+        const int ci = (int)(i % CinP);
+        int64_t p = i / CinP;
         const int iw = (int)(p % W); p /= W;
         const int ih = (int)(p % H);
         const int b = (int)(p / H);
         float acc = 0.f;
-        for (int kh = 0; kh < KH; ++kh) {
+        for (int kh = 0; kh < KH && ci < Cin; ++kh) {
             const int th = ih + pad - kh;
             if (th < 0 || th % stride) continue;
             const int oh = th / stride;
@@ -1511,7 +1523,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ z, in
 extern "C" int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int Cin, int KH, int KW, int stride,
                            int pad, int dtype, octa_stream_t stream) {
     OCTA_REQUIRE(z && dx && B > 0 && Cin > 0 && stride > 0, "octa_col2im: bad arguments");
-    const int64_t total = (int64_t)B * H * W * Cin;
+    const int64_t total = (int64_t)B * H * W * (Cin + 7) / 8 * 8;
     const int blocks = (int)(cdiv64(total, 256) > 131072 ? 131072 : cdiv64(total, 256));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32) col2im_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, Cin, KH, KW, stride, pad);

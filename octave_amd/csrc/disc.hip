@@ -103,7 +103,7 @@ __device__ float block_total256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 __global__ __launch_bounds__(256) void spectral_B_kernel(const float* __restrict__ w, const float* __restrict__ vraw, float* __restrict__ v, float* __restrict__ wv,
-                                                         int Cout, int K, int iter, float eps) {
+                                                         int Cout, int K, int iter, float eps, float* __restrict__ vsave) {
     extern __shared__ float sm[];   // vs[K], red[4]
     float* vs = sm;
     float* red = sm + K;
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256) void spectral_B_kernel(const float* __restrict
         __syncthreads();
         if (blockIdx.x == 0) for (int j = threadIdx.x; j < K; j += 256) v[j] = vs[j];
     }
+    if (vsave && blockIdx.x == 0) {                  // the v this step used, kept for the backward pass
+        __syncthreads();
+        for (int j = threadIdx.x; j < K; j += 256) vsave[j] = vs[j];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
     for (int i = r0 + wave; i < r1; i += 4) {
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void spectral_B_kernel(const float* __restrict
     }
 }
 __global__ __launch_bounds__(256) void spectral_C_kernel(const float* __restrict__ w, const float* __restrict__ wv, float* __restrict__ u, float* __restrict__ sigma,
-                                                         float* __restrict__ wsn, int Cout, int K, int iter, float eps) {
+                                                         float* __restrict__ wsn, int Cout, int K, int iter, float eps, float* __restrict__ usave) {
     __shared__ float red[4];
     float a = 0.f, b = 0.f;     // |wv|^2 and u_old . wv
     for (int i = threadIdx.x; i < Cout; i += 256) { const float x = wv[i]; a += x * x; b += u[i] * x; }
@@ -136,9 +140,10 @@ __global__ __launch_bounds__(256) void spectral_C_kernel(const float* __restrict
     if (iter) {
         const float d = fmaxf(sqrtf(a), eps);
         sg = a / d;                                   // u_new . wv with u_new = wv / d
-        if (blockIdx.x == 0) for (int i = threadIdx.x; i < Cout; i += 256) u[i] = wv[i] / d;
+        if (blockIdx.x == 0) for (int i = threadIdx.x; i < Cout; i += 256) { const float un = wv[i] / d; u[i] = un; if (usave) usave[i] = un; }
     } else {
         sg = b;
+        if (usave && blockIdx.x == 0) for (int i = threadIdx.x; i < Cout; i += 256) usave[i] = u[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sigma[0] = sg;
     const float inv = 1.f / sg;
@@ -146,53 +151,61 @@ __global__ __launch_bounds__(256) void spectral_C_kernel(const float* __restrict
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) wsn[i] = w[i] * inv;
 }
 extern "C" int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, int do_power_iter, float eps, float* sigma,
-                                      float* w_sn, float* ws, octa_stream_t stream) {
+                                      float* w_sn, float* ws, float* uv_saved, int ws_prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(w && u && v && sigma && w_sn && ws && Cout > 0 && K > 0, "octa_spectral_norm_fwd: bad arguments (ws: K + Cout floats)");
     hipStream_t st = (hipStream_t)stream;
     float* vraw = ws;
     float* wv = ws + K;
     const int nb = cdiv(Cout, SN_ROWS);
     if (do_power_iter) {
-        if (octa_zero_async(vraw, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
+        if (!ws_prezeroed && octa_zero_async(vraw, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
         spectral_A_kernel<<<nb, 256, 0, st>>>(w, u, vraw, Cout, K);
         OCTA_CHECK_LAUNCH("spectral_A");
     }
-    spectral_B_kernel<<<nb, 256, (size_t)(K + 4) * sizeof(float), st>>>(w, vraw, v, wv, Cout, K, do_power_iter, eps);
+    spectral_B_kernel<<<nb, 256, (size_t)(K + 4) * sizeof(float), st>>>(w, vraw, v, wv, Cout, K, do_power_iter, eps, uv_saved ? uv_saved + Cout : nullptr);
     OCTA_CHECK_LAUNCH("spectral_B");
     int nc = (int)cdiv64((int64_t)Cout * K, 256 * 8);
     if (nc < 1) nc = 1;
-    spectral_C_kernel<<<nc, 256, 0, st>>>(w, wv, u, sigma, w_sn, Cout, K, do_power_iter, eps);
+    spectral_C_kernel<<<nc, 256, 0, st>>>(w, wv, u, sigma, w_sn, Cout, K, do_power_iter, eps, uv_saved);
     OCTA_CHECK_LAUNCH("spectral_C");
     return OCTA_OK;
 }
 // backward: dot = sum(dw_sn * w_sn) (atomics into ws[0]), then dw += (dw_sn - dot * u v^T) / sigma
-__global__ __launch_bounds__(256) void spectral_bwd_dot_kernel(const float* __restrict__ dwsn, const float* __restrict__ wsn, int64_t n, float* __restrict__ dot) {
+// dw_sn may be channels-last ([Cout][KH][KW][Cin], what the weight-gradient kernels prefer): khw = KH*KW then, 0 for dense OIHW
+__device__ __forceinline__ int64_t sn_src(int64_t i, int K, int khw) {
+    if (!khw) return i;
+    const int r = (int)(i / K), c = (int)(i % K), cin = K / khw;
+    return (int64_t)r * K + (int64_t)(c % khw) * cin + c / khw;
+}
+__global__ __launch_bounds__(256) void spectral_bwd_dot_kernel(const float* __restrict__ dwsn, const float* __restrict__ wsn, int64_t n, float* __restrict__ dot,
+                                                               int K, int khw) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += dwsn[i] * wsn[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += dwsn[sn_src(i, K, khw)] * wsn[i];
     s = block_total256(s, red);
     if (threadIdx.x == 0) atomicAdd(dot, s);
 }
 __global__ __launch_bounds__(256) void spectral_bwd_apply_kernel(const float* __restrict__ dwsn, const float* __restrict__ u, const float* __restrict__ v,
                                                                  const float* __restrict__ sigma, const float* __restrict__ dot, int K, int64_t n,
-                                                                 float* __restrict__ dw) {
+                                                                 float* __restrict__ dw, int accumulate, int khw) {
     const float inv = 1.f / sigma[0], s = dot[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / K), c = (int)(i % K);
-        dw[i] += (dwsn[i] - s * u[r] * v[c]) * inv;
+        const float g = (dwsn[sn_src(i, K, khw)] - s * u[r] * v[c]) * inv;
+        dw[i] = accumulate ? dw[i] + g : g;
     }
 }
 extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma, int Cout, int K,
-                                      float* dw, float* ws, octa_stream_t stream) {
-    OCTA_REQUIRE(dw_sn && w_sn && u && v && sigma && dw && ws, "octa_spectral_norm_bwd: bad arguments (ws: 1 float)");
+                                      float* dw, float* ws, int accumulate, int ws_prezeroed, int dwsn_khw, octa_stream_t stream) {
+    OCTA_REQUIRE(dw_sn && w_sn && u && v && sigma && dw && ws && dwsn_khw >= 0 && (dwsn_khw == 0 || K % dwsn_khw == 0), "octa_spectral_norm_bwd: bad arguments (ws: 1 float; dwsn_khw divides K)");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Cout * K;
     int nb = (int)cdiv64(n, 256 * 8);
     if (nb < 1) nb = 1;
-    if (octa_zero_async(ws, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
-    spectral_bwd_dot_kernel<<<nb, 256, 0, st>>>(dw_sn, w_sn, n, ws);
+    if (!ws_prezeroed && octa_zero_async(ws, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
+    spectral_bwd_dot_kernel<<<nb, 256, 0, st>>>(dw_sn, w_sn, n, ws, K, dwsn_khw);
     OCTA_CHECK_LAUNCH("spectral_bwd_dot");
-    spectral_bwd_apply_kernel<<<nb, 256, 0, st>>>(dw_sn, u, v, sigma, ws, K, n, dw);
+    spectral_bwd_apply_kernel<<<nb, 256, 0, st>>>(dw_sn, u, v, sigma, ws, K, n, dw, accumulate, dwsn_khw);
     OCTA_CHECK_LAUNCH("spectral_bwd_apply");
     return OCTA_OK;
 }

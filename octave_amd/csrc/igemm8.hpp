@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nb = n0 + (wn * 4 + i) * 16 + q * 4;
-            if (nb >= a.Ng) continue;
+            if (nb >= a.NgSt) continue;
             int chan = g * a.Ng + nb;
             int bidx = chan;
             if (a.upshuffle) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
                 *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (nb + e < a.Ng) DT<T>::st(dst + e, v[e]);
+                for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? v[e] : 0.f);
             }
         }
     }

@@ -492,7 +492,8 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     if Cin != Cin_g * groups:
         raise OctaError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
     x, ldx = _conv_input(x, round8(Cin_g), groups)
-    y = out if out is not None else nhwc_empty(B, Cout, OH, OW, x.dtype, x.device)
+    zp = out is None and groups == 1 and Cout % 8 != 0       # the kernel zero-fills the padding channels itself
+    y = out if out is not None else nhwc_empty(B, Cout, OH, OW, x.dtype, x.device, pad_written=zp)
     ldy = nhwc_ld(y)
     if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, x.dtype):
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, ldx, ldy, x.dtype, act)
@@ -500,6 +501,7 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
         wp = _packed(w, "fwd_dense", x.dtype, groups, d.cin_g_pad)
     else:
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
+        d.zero_pad = int(zp)
         wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
     _launch_fwd(d, x, wp, bias, y)
     _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
@@ -516,7 +518,9 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
     if ldy < need:
         dy = to_nhwc(dy.contiguous(), cpad=need)
         ldy = nhwc_ld(dy)
-    dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device)
+    col2im = stride > 1 and groups == 1 and (Cin * KH * KW) % 8 == 0
+    zp = groups == 1 and Cin % 8 != 0 and not col2im
+    dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device, pad_written=zp or col2im)      # octa_col2im stores the pad channels too
     if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, dy.dtype):
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, nhwc_ld(dx), ldy, dy.dtype)
         d.alg_groups = groups
@@ -526,7 +530,8 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         return dx
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
-    if stride > 1 and groups == 1 and (Cin * KH * KW) % 8 == 0:
+    d.zero_pad = int(zp)
+    if col2im:
         # strided data gradient = dense GEMM Z = dy x W^T (no wasted taps, N = Cin*KH*KW) + col2im fold;
         # the data-grad operand [ci][kh][kw][co] is exactly the [N][K] matrix the 1x1 forward wants
         N = Cin * KH * KW
@@ -644,7 +649,13 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
     if dw is None:
         # channels-last storage: the kernel's atomics then land in contiguous runs along Cin (17x the
         # rate of a strided OIHW target; MI355X_MICROARCH.md "Global float atomics")
-        dw = torch.empty(tuple(w.shape), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
+        if w.numel() <= (1 << 18):
+            flat, pz = _zeroed_f32((w.numel(),), w.device)
+        else:
+            flat, pz = torch.empty((w.numel(),), dtype=torch.float32, device=w.device), 0
+        if not pz:
+            flat.zero_()
+        dw = flat.view(Cout, KH, KW, Cin_g).permute(0, 3, 1, 2)
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
     if defer and _WGRAD_Q is not None:
         j = WgradJob()
@@ -677,7 +688,7 @@ def raw_act_bwd(y: Tensor, dy: Tensor, act: int) -> Tensor:
         dy = _match_ld(dy, nhwc_ld(y))
     B, C, H, W = y.shape
     ld = nhwc_ld(y)
-    dx = nhwc_empty(B, C, H, W, y.dtype, y.device)
+    dx = nhwc_empty(B, C, H, W, y.dtype, y.device, pad_written=True)      # all ld channels are computed (dy's padding is zero)
     lib().octa_act_bwd(_p(y), _p(dy), _p(dx), B * H * W * ld, act, _dt(y), _st())
     return dx
 
@@ -1414,21 +1425,28 @@ class SpectralNormFn(Function):
         K = wd.numel() // Cout
         sigma = torch.empty((1,), dtype=torch.float32, device=w.device)
         wsn = torch.empty_like(wd)
-        ws = torch.empty((K + Cout,), dtype=torch.float32, device=w.device)
-        lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _p(ws), _st())
-        ctx.save_for_backward(wsn, u.clone(), v.clone(), sigma)
+        ws, pz = _zeroed_f32((K + Cout,), w.device)
+        uv = torch.empty((Cout + K,), dtype=torch.float32, device=w.device)      # the u, v THIS forward used (later forwards move them on)
+        lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _p(ws), _p(uv), pz, _st())
+        ctx.save_for_backward(wsn, uv, sigma)
         return wsn
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dwsn):
-        wsn, u, v, sigma = ctx.saved_tensors
+        wsn, uv, sigma = ctx.saved_tensors
         Cout = wsn.shape[0]
         K = wsn.numel() // Cout
-        dwsn = dwsn.float().contiguous()
-        dw = torch.zeros_like(wsn)
-        ws = torch.empty((1,), dtype=torch.float32, device=wsn.device)
-        lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(u), _p(v), _p(sigma), Cout, K, _p(dw), _p(ws), _st())
+        dwsn = dwsn.float()
+        khw = 0
+        if not dwsn.is_contiguous():
+            if dwsn.dim() == 4 and dwsn.is_contiguous(memory_format=torch.channels_last):
+                khw = dwsn.shape[2] * dwsn.shape[3]
+            else:
+                dwsn = dwsn.contiguous()
+        dw = torch.empty_like(wsn)
+        ws, pz = _zeroed_f32((1,), wsn.device)
+        lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(uv), _p(uv[Cout:]), _p(sigma), Cout, K, _p(dw), _p(ws), 0, pz, khw, _st())
         return dw, None, None, None, None
 
 
