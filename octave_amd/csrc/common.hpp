@@ -143,6 +143,22 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// Activation of a whole accumulator tile behind ONE decision.  act_apply() inside the fully unrolled epilogue loops costs a
+// scalar compare-and-branch chain PER ELEMENT (the switch is on a kernel argument; nothing hoists it out of straight-line
+// code): ~3,000 SALU instructions per tile of the persistent conv kernel, more time than its MFMAs.
+template <typename V4, int NI, int NJ>
+__device__ __forceinline__ void act_tile(V4 (&acc)[NI][NJ], int act) {
+    if (act == OCTA_ACT_NONE) return;
+#define OCTA_ACT_TILE(EXPR)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e]; acc[i][j][e] = (EXPR); }
+    if (act == OCTA_ACT_RELU) { OCTA_ACT_TILE(v > 0.f ? v : 0.f) }
+    else if (act == OCTA_ACT_LEAKY02) { OCTA_ACT_TILE(v > 0.f ? v : 0.2f * v) }
+    else if (act == OCTA_ACT_SIGMOID) { OCTA_ACT_TILE(1.f / (1.f + __expf(-v))) }
+    else if (act == OCTA_ACT_TANH) { OCTA_ACT_TILE(tanhf(v)) }
+#undef OCTA_ACT_TILE
+}
+
 // Stream-ordered zero fill as a KERNEL.  hipMemsetAsync is not used anywhere in this library: captured into a hipGraph it
 // becomes a memset node, and memset nodes were observed (ROCm 7.2, gfx950) to lose their ordering against the neighbouring
 // kernel nodes when graphs are replayed back-to-back without host synchronisation - accumulators were cleared AFTER the

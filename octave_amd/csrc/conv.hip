@@ -27,6 +27,7 @@ struct ConvArgs {
     int act, mode;        // mode 0: forward gather, 1: data-gradient gather
     int upshuffle, CoutT;
     int vec_store;
+    int vec16;            // 16-byte output stores are aligned: ldy, yoff (and the upshuffle channel count) are multiples of 8
     int NgSt;             // channels stored per group: Ng, or round8(Ng) when the pad channels are zero-filled here
 };
 
@@ -65,6 +66,29 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     }
 };
+
+
+// Bias and activation of a whole accumulator tile BEFORE the store loops: one activation decision per tile (act_tile), one
+// bias fetch per output-channel group instead of one per (channel group, pixel row).  nbase = first channel of this lane in
+// fragment 0 (n0 + wn * TN * 16 + q * 4); fragment i adds 16 i.
+template <typename V4, int TN, int TM>
+__device__ __forceinline__ void bias_act_tile(V4 (&acc)[TN][TM], const ConvArgs& a, int nbase, int g) {
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = nbase + i * 16;
+            const int bidx = a.upshuffle ? nb % a.CoutT : g * a.Ng + nb;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (nb + e < a.Ng) ? a.bias[bidx + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += bv[e];
+        }
+    }
+    act_tile(acc, a.act);
+}
 
 template <typename T, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     // epilogue: lane holds, per (tn,tm), 4 consecutive output channels (rows of D) of pixel column r
     T* __restrict__ yb = (T*)a.y + a.yoff;
+    bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
@@ -207,11 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             }
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f = acc[i][j][e];
-                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
-                v[e] = act_apply(f, a.act);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -401,6 +422,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
 
     T* __restrict__ yb = (T*)a.y + a.yoff;
+    bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
@@ -422,11 +444,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
             }
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f = acc[i][j][e];
-                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
-                v[e] = act_apply(f, a.act);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -571,6 +589,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
 
     T* __restrict__ yb = (T*)a.y + a.yoff;
     const int ox = x0 + r;
+    bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int oy = y0 + wm * TM + j;
@@ -583,11 +602,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
             const int chan = g * a.Ng + nb;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f = acc[i][j][e];
-                if (a.bias && nb + e < a.Ng) f += a.bias[chan + e];
-                v[e] = act_apply(f, a.act);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -649,6 +664,7 @@ static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
 }
 
 #include "igemm8.hpp"
+#include "convres.hpp"
 
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
 static int conv_variant() {
@@ -679,6 +695,9 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             if (gf >= thr && a.Cg % 64 == 0) want = (a.Ng >= 256) ? 3 : 2;
         }
         if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
+        // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
+        static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
+        if ((want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
     }
     // explicit 4-wave tile choices (measured per shape by the training step's autotuner): 4 = 128x128, 5 = 64x64, 6 = 128x64
     if (algo >= 4 && algo <= 6) {
@@ -764,6 +783,7 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     a.M = d->B * d->OH * d->OW; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = d->act; a.mode = 0; a.upshuffle = d->upshuffle; a.CoutT = d->upshuffle ? d->Cout / 4 : 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->yoff % 4 == 0) && (d->ldy % 4 == 0) && (!d->upshuffle || a.CoutT % 4 == 0);
+    a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
@@ -796,6 +816,7 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     a.M = d->B * d->H * d->W; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
+    a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");

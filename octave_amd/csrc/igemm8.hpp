@@ -188,6 +188,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
 
     // epilogue: lane holds, per (tn, tm), 4 consecutive output channels (rows of D) of pixel column r
     T* __restrict__ yb = (T*)a.y + a.yoff;
+    bias_act_tile(acc, a, n0 + wn * 4 * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + (wm * 4 + j) * 16 + r;
@@ -209,11 +210,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
             }
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f = acc[i][j][e];
-                if (a.bias && nb + e < a.Ng) f += a.bias[bidx + e];
-                v[e] = act_apply(f, a.act);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             T* dst = yb + pix * a.ldy + chan;
             if (a.vec_store && nb + 3 < a.Ng) {
                 *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));

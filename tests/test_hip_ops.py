@@ -495,6 +495,84 @@ def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     check(f"igemm8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+RES_CASES = [
+    # B, Cin, H, W, Cout, k, pad : the resident-weight persistent kernel (algo 7); enough tiles for several per workgroup,
+    # ragged right / bottom tiles, every channel-count bucket (13 -> zero-filled padding channels)
+    (3, 32, 150, 170, 64, 3, 1),
+    (2, 64, 100, 97, 32, 3, 1),
+    (2, 32, 67, 300, 24, 3, 1),
+    (2, 64, 150, 131, 13, 1, 0),
+    (2, 64, 130, 120, 256, 1, 0),
+    (3, 32, 140, 140, 64, 1, 0),
+    (2, 64, 90, 200, 40, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("grid", [0, 7])
+@pytest.mark.parametrize("case", RES_CASES)
+def test_resident_weight_conv_vs_torch(dev, case, grid, dtype, monkeypatch):
+    """convres.hpp (octa_conv_desc.algo 7): forward (+bias, ReLU) and data gradient against torch's CPU conv on the same
+    rounded operands; the padding channels of a 13-channel output must come back as zeros (zero_pad)."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, k, p = case
+    if grid:
+        monkeypatch.setenv("OCTA_CONVRES_GRID", str(grid))      # 7 workgroups: dozens of tiles each through the patch ring
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, p))
+    t = TOL[dtype]
+    F_._ALGO_OVERRIDE = 7
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, p, 1, 1)
+        name = lib().octa_last_conv_kernel().decode()
+        assert "conv_res" in name, name
+        check(f"res fwd {case}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+        ld = F_.nhwc_ld(y)
+        if ld != Cout:
+            buf = y.permute(0, 2, 3, 1)
+            full = torch.as_strided(buf, (B, H, W, ld), (H * W * ld, W * ld, ld, 1))
+            assert float(full[..., Cout:].float().abs().max()) == 0.0, "padding channels not zero-filled"
+        # the data gradient of a conv with Cout in {32, 64} gathers dy with 32 / 64 channels: the same kernel family
+        dx = None
+        if Cout in (32, 64):
+            dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
+            dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, p, 1)
+            assert "conv_res" in lib().octa_last_conv_kernel().decode()
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    if dx is not None:
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.conv2d(xr, w, None, 1, p).backward(dy)
+        check(f"res dgrad {case}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_resident_weight_upshuffle_vs_torch(dev, dtype):
+    """ConvTranspose2d k2 s2 (64 -> 64) as the 1x1 'upshuffle' GEMM on the resident-weight kernel."""
+    import octave_amd.layers as L_
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    gen = torch.Generator().manual_seed(5)
+    m = L_.ConvTranspose2d(64, 64, 2, 2).to(dev)
+    x = torch.randn(2, 64, 120, 136, generator=gen).to(dtype)
+    ref = torch.nn.functional.conv_transpose2d(x.float(), m.weight.detach().cpu().to(dtype).float(), m.bias.detach().cpu(), 2)
+    F_._ALGO_OVERRIDE = 7
+    try:
+        with torch.no_grad():
+            y = m(F_.to_nhwc(x.to(dev), dtype=dtype))
+        assert "conv_res1x1" in lib().octa_last_conv_kernel().decode(), lib().octa_last_conv_kernel().decode()
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    t = TOL[dtype]
+    check("res upshuffle", y, ref, t["rtol"], t["atol"] * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_wgrad_batch_vs_torch(dev, dtype):
     """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations, a grouped conv, a strided one, a small-N job that falls
