@@ -22,12 +22,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (the bit-twiddled form cost 6 VALU ops per element in every
+// epilogue; same results for every finite input)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+typedef __bf16 octa_bf2_t __attribute__((ext_vector_type(2)));
+typedef float octa_f2_t __attribute__((ext_vector_type(2)));
 
 struct f16_t { unsigned short v; };   // raw IEEE half bits; a distinct type (bf16_t is a plain unsigned short) so that templates can specialise
 __device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
@@ -52,7 +51,10 @@ template <> struct DT<f16_t> {
 };
 // two fp32 values -> one dword of two 16-bit elements of T
 template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
-template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) {
+    const octa_f2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, octa_bf2_t));
+}
 template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) { return (unsigned)f2h(a) | ((unsigned)f2h(b) << 16); }
 template <typename T> struct DTName;
 template <> struct DTName<float> { static constexpr const char* v = "f32"; };
@@ -82,10 +84,10 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
     uint4 c;
-    c.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-    c.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-    c.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-    c.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    c.x = pack2<bf16_t>(f[0], f[1]);
+    c.y = pack2<bf16_t>(f[2], f[3]);
+    c.z = pack2<bf16_t>(f[4], f[5]);
+    c.w = pack2<bf16_t>(f[6], f[7]);
     return c;
 }
 
