@@ -15,6 +15,14 @@ from octave_amd import functional as F_
 logger = logging.getLogger("octave_amd")
 
 
+def _check_eps(eps: float, who: str) -> float:
+    """The HIP loss kernels carry the reference's default smoothing constant (1e-12) as a literal; any other value would be
+    silently ignored, so it is refused instead."""
+    if float(eps) != 1e-12:
+        raise NotImplementedError(f"{who}: eps={eps} is not supported by the HIP loss kernels (compiled for the reference default 1e-12)")
+    return float(eps)
+
+
 class WeightedPartialCE(nn.Module):
 
     def __init__(self, num_classes, eps=1e-12, manual: bool = False):
@@ -22,7 +30,7 @@ class WeightedPartialCE(nn.Module):
         ``OctaScribbleNet`` builds, models/octa.py:52).  `y_hat` are class probabilities."""
         super().__init__()
         self.num_classes = num_classes
-        self.eps = eps
+        self.eps = _check_eps(eps, "WeightedPartialCE")
         self.manual = manual
 
     def forward(self, y_hat: Tensor, ys: Tensor, ignore_bg: bool = False, reduction: Literal['mean', 'sum'] = 'mean', **kwargs) -> Tensor:
@@ -56,7 +64,7 @@ class DiceLoss(nn.Module):
 
     def __init__(self, eps: float = 1e-12):
         super().__init__()
-        self.eps = eps
+        self.eps = _check_eps(eps, "DiceLoss")
 
     def forward(self, input: Tensor, target: Tensor):
         return F_.wpce_dice(input, target, from_logits=False)[1]
@@ -72,7 +80,7 @@ class InterlayerDivergence(nn.Module):
         super().__init__()
         assert mode in ['mean', 'sum'], f'mode {mode} is not exists/implemented.'
         self.mode = mode
-        self.eps = eps
+        self.eps = _check_eps(eps, "InterlayerDivergence(KLD)") if divergence == 'KLD' else float(eps)     # the JSD kernels take eps as an argument
         self.stop_gradient = stop_gradient
         self.divergence = divergence
         self.check_nan = True

@@ -285,3 +285,14 @@ def test_device_side_synthetic_batch_and_pyramid(dev):
         assert torch.equal(p, real[:, :, ::2 ** i, ::2 ** i]), i       # == the contract of discriminator/blocks.py:114-125
     xv, ysv, realv = F_.synth_octa_batch(B, H, H, seed=7, device=dev, vessel=True)
     assert 0.05 < float(realv[:, 1].mean()) < 0.6 and float((ysv[:, 1] * realv[:, 0]).sum()) == 0.0
+
+
+def test_loss_eps_other_than_reference_default_is_refused():
+    """a non-default eps used to be silently ignored (the kernels carry 1e-12 as a literal)."""
+    import pytest as _pt
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence, WeightedPartialCE
+    DiceLoss(); WeightedPartialCE(2, manual=True); InterlayerDivergence(); InterlayerDivergence(eps=1e-6, divergence='JSD')
+    for make in (lambda: DiceLoss(eps=1e-6), lambda: WeightedPartialCE(2, eps=1e-8), lambda: InterlayerDivergence(eps=1e-6)):
+        with _pt.raises(NotImplementedError):
+            make()
+
