@@ -114,6 +114,15 @@ int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_pac
  * The padding channels [Cin, min(round8(Cin), lddx)) of every dx pixel are stored as zeros. */
 int octa_col2im(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int Cin,
                 int KH, int KW, int stride, int pad, int dtype, octa_stream_t stream);
+/* Tap-major form of the same path for small Cin (the 15-channel discriminator inputs): the packed operand's rows are
+ * n = (kh*KW + kw) * cin_pad + ci (octa_pack_weight_dgrad_taps), the GEMM output Z has KH*KW*cin_pad columns, and the
+ * fold reads one 16-byte channel vector per (pixel, tap).  dx receives cin_pad channels per pixel (the padding ones are
+ * zeros because their operand rows are).  groups == 1. */
+int octa_pack_weight_dgrad_taps(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                                void* packed, int Cout, int Cin, int KH, int KW, int cin_pad,
+                                int cout_pad, int dtype, octa_stream_t stream);
+int octa_col2im_taps(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW,
+                     int cin_pad, int KH, int KW, int stride, int pad, int dtype, octa_stream_t stream);
 /* dw[o,i,kh,kw] += sum_pixels dy * x   (fp32 gradient of the OIHW-logical parameter, addressed
  * through its element strides so OIHW-dense and channels-last storage both work; accumulated
  * with atomics, so the caller zeroes it once per step). */

@@ -828,6 +828,90 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Tap-major variant of the GEMM + col2im data gradient (small Cin, e.g. the 15-channel discriminator inputs): the GEMM's
+// N axis is ordered n = (kh*KW + kw) * cin_pad + ci, so the fold reads, per (pixel, tap), the channels as 16-byte vectors
+// instead of one 2-byte element per (channel, tap) - the strided form spent 60 scalar loads per output pixel.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_taps_kernel(const float* __restrict__ w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                                                              T* __restrict__ out, int Cout, int Cin, int KH, int KW, int cin_pad, int cout_pad) {
+    const int64_t total = (int64_t)KH * KW * cin_pad * cout_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int co = (int)(idx % cout_pad);
+        int64_t t = idx / cout_pad;
+        const int ci = (int)(t % cin_pad);
+        const int tap = (int)(t / cin_pad);
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const float v = (co < Cout && ci < Cin) ? w[(int64_t)co * s_o + (int64_t)ci * s_i + kh * s_h + kw * s_w] : 0.f;
+        DT<T>::st(out + idx, v);
+    }
+}
+extern "C" int octa_pack_weight_dgrad_taps(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, void* packed, int Cout, int Cin,
+                                           int KH, int KW, int cin_pad, int cout_pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(w && packed, "octa_pack_weight_dgrad_taps: null pointer");
+    OCTA_REQUIRE(cin_pad % 8 == 0 && cin_pad >= Cin && cout_pad % 8 == 0 && cout_pad >= Cout, "octa_pack_weight_dgrad_taps: bad padded sizes");
+    const int64_t total = (int64_t)KH * KW * cin_pad * cout_pad;
+    const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) pack_dgrad_taps_kernel<float><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (float*)packed, Cout, Cin, KH, KW, cin_pad, cout_pad);
+    else if (dtype == OCTA_BF16) pack_dgrad_taps_kernel<bf16_t><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (bf16_t*)packed, Cout, Cin, KH, KW, cin_pad, cout_pad);
+    else if (dtype == OCTA_F16) pack_dgrad_taps_kernel<f16_t><<<blocks, 256, 0, st>>>(w, s_o, s_i, s_h, s_w, (f16_t*)packed, Cout, Cin, KH, KW, cin_pad, cout_pad);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_pack_weight_dgrad_taps: bad dtype %d", dtype);
+    OCTA_CHECK_LAUNCH("pack_dgrad_taps");
+    return OCTA_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_taps_kernel(const T* __restrict__ z, int ldz, T* __restrict__ dx, int lddx, int B, int H, int W, int OH,
+                                                          int OW, int cin_pad, int KH, int KW, int stride, int pad) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cpc = cin_pad / EPC;                        // 16-byte chunks per pixel
+    const int64_t total = (int64_t)B * H * W * cpc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % cpc);
+        int64_t p = i / cpc;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int th = ih + pad - kh;
+            if (th < 0 || th % stride) continue;
+            const int oh = th / stride;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int tw = iw + pad - kw;
+                if (tw < 0 || tw % stride) continue;
+                const int ow = tw / stride;
+                if (ow >= OW) continue;
+                float v[EPC];
+                unpack16<T>(*(const uint4*)(z + ((int64_t)(b * OH + oh) * OW + ow) * ldz + (kh * KW + kw) * cin_pad + ck * EPC), v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += v[e];
+            }
+        }
+        *(uint4*)(dx + ((int64_t)(b * H + ih) * W + iw) * lddx + ck * EPC) = pack16<T>(acc);
+    }
+}
+extern "C" int octa_col2im_taps(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int cin_pad, int KH, int KW,
+                                int stride, int pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(z && dx && B > 0 && stride > 0, "octa_col2im_taps: bad arguments");
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    OCTA_REQUIRE(cin_pad > 0 && cin_pad % 8 == 0 && lddx >= cin_pad && lddx % epc == 0 && ldz % epc == 0 && ldz >= KH * KW * cin_pad,
+                 "octa_col2im_taps: cin_pad %% 8, lddx >= cin_pad, ldz >= KH*KW*cin_pad");
+    const int64_t total = (int64_t)B * H * W * (cin_pad / epc);
+    const int blocks = (int)(cdiv64(total, 256) > 131072 ? 131072 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) col2im_taps_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
+    else if (dtype == OCTA_BF16) col2im_taps_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
+    else if (dtype == OCTA_F16) col2im_taps_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)z, ldz, (f16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_col2im_taps: bad dtype");
+    OCTA_CHECK_LAUNCH("col2im_taps");
+    return OCTA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
 template <typename T>

@@ -219,6 +219,8 @@ def _pack_numel(w: Tensor, kind: str, groups: int, pad_to: int) -> int:
         return O * KH * KW * pad_to
     if kind == "dgrad_dense":
         return groups * Ig * KH * KW * pad_to
+    if kind == "dgrad_taps":
+        return KH * KW * round8(Ig) * pad_to
     return 4 * Ig * pad_to      # convT: w is (CinT, CoutT, 2, 2)
 
 
@@ -269,6 +271,9 @@ def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     elif kind == "dgrad":
         out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
         L.octa_pack_weight_dgrad(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, groups, pad_to, _dt(dtype), _st())
+    elif kind == "dgrad_taps":  # rows (kh, kw, ci < round8(Cin)), columns co < pad_to: the tap-major GEMM + col2im data gradient
+        out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
+        L.octa_pack_weight_dgrad_taps(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, KH, KW, round8(Ig), pad_to, _dt(dtype), _st())
     elif kind == "convT":      # w: (CinT, CoutT, 2, 2)
         out = out if out is not None else torch.empty((n,), dtype=dtype, device=w.device)
         L.octa_pack_weight_convT(_p(wd), s[0], s[1], s[2], s[3], _p(out), O, Ig, pad_to, _dt(dtype), _st())
@@ -310,7 +315,7 @@ def repack_all(params) -> int:
     todo = []
     for key, e in _PACK_CACHE.items():
         w = e.wref()
-        if w is None or key[0] not in ids or e.direct:
+        if w is None or key[0] not in ids or e.direct or e.kind not in _PACK_KIND:      # kinds without a multi-pack form refresh lazily on next use
             if w is not None and key[0] in ids and e.direct:
                 e.tag = _pack_tag(w)          # the parameter storage is the operand: always current
             continue
@@ -510,6 +515,9 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     return y
 
 
+_COL2IM_TAPS = os.environ.get("OCTA_NO_COL2IM_TAPS") is None
+
+
 def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int) -> Tensor:
     B, Cin, H, W = xshape
     Cout, Cin_g, KH, KW = w.shape
@@ -531,6 +539,17 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
         return dx
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
+    if col2im and Cin <= 16 and _COL2IM_TAPS:
+        # few input channels (the discriminator's 15-channel inputs): tap-major N axis, the fold moves 16-byte channel vectors
+        cp = round8(Cin)
+        N = KH * KW * cp
+        wt = _packed(w, "dgrad_taps", dy.dtype, 1, d.cout_g_pad)
+        z = nhwc_empty(B, N, OH, OW, dy.dtype, dy.device)
+        dz = _desc(B, OH, OW, OH, OW, d.cout_g_pad, N, 1, 1, 1, 0, 1, ldy, N, dy.dtype)
+        _launch_fwd(dz, dy, wt, None, z)
+        _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
+        lib().octa_col2im_taps(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, cp, KH, KW, stride, pad, _dt(dy), _st())
+        return dx
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
     d.zero_pad = int(zp)
     if col2im:

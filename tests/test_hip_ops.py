@@ -495,6 +495,29 @@ def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     check(f"igemm8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 15, 40, 44, 128, 4, 2, 1), (3, 2, 50, 38, 64, 4, 2, 1), (2, 13, 21, 21, 72, 4, 2, 1)])
+def test_strided_dgrad_tap_major_col2im_vs_torch(dev, case, dtype):
+    """Stride-2 data gradient of the few-channel discriminator convs: GEMM with the tap-major operand + octa_col2im_taps
+    (16-byte channel vectors per tap) against torch's CPU gradient; the padding channels of dx come back as zeros."""
+    from octave_amd import functional as F_
+    B, Cin, H, W, Cout, k, s_, p_ = case
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xr, w, None, s_, p_)
+    dy = torch.randn(tuple(y.shape), generator=gen).to(dtype).float()
+    y.backward(dy)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)      # a plain tensor, like the spectral-normalised weights
+    dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), s_, p_, 1)
+    t = TOL[dtype]
+    check(f"tap-major dgrad {case}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+    ld = F_.nhwc_ld(dx)
+    full = torch.as_strided(dx.permute(0, 2, 3, 1), (B, H, W, ld), (H * W * ld, W * ld, ld, 1))
+    assert float(full[..., Cin:].float().abs().max()) == 0.0, "padding channels not zero"
+
+
 RES_CASES = [
     # B, Cin, H, W, Cout, k, pad : the resident-weight persistent kernel (algo 7); enough tiles for several per workgroup,
     # ragged right / bottom tiles, every channel-count bucket (13 -> zero-filled padding channels)
