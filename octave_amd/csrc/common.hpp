@@ -103,9 +103,15 @@ template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
 #define OCTA_DTYPE_OK(dtype) ((dtype) == OCTA_F32 || (dtype) == OCTA_BF16 || (dtype) == OCTA_F16)
 
 // ---------------------------------------------------------------- reductions (wave = 64)
+// The four steps inside a 16-lane row are DPP moves (VALU rate); only the two cross-row steps go through the LDS crossbar
+// (ds_bpermute, what __shfl_xor compiles to - six of those per sum made the small reduction kernels latency-bound).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]: lane ^ 1
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: lane ^ 2
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {

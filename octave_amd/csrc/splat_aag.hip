@@ -248,42 +248,55 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
 // channels, B <= 32 accumulators per lane, wavefront shuffles for the sums).
 #define SPLAT_MAXB 32
 
-// block (4 waves splitting the input channels) per fc1 output channel j
+// Thread layout of the three reduction-shaped kernels (fwd1, fwd2, bwdA): lane bits = batch index bl (BT = 16 or 32 lanes),
+// the remaining bits = slice s of the reduced axis.  One accumulator per thread, the slices meet through one or two cross-row
+// shuffles and a 4-entry LDS column, and the batch statistics are a DPP reduction over the BT lanes.  (The first version kept
+// 32 accumulators per thread and ran a full 64-lane wave_sum per batch entry: ~100 LDS-crossbar shuffles per block, 12-16 us
+// for a few kFLOP.)
+template <int BT>
+__device__ __forceinline__ float splat_row_sum(float v) {       // sum over the BT lanes that share the slice; every lane gets it
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
+    if (BT == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+template <int BT>
+__device__ __forceinline__ float splat_slice_sum(float v, float (*red)[32]) {   // sum over the 256 / BT slices; valid in threads < BT
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (BT == 16) v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < BT) red[wave][lane] = v;
+    __syncthreads();
+    return (threadIdx.x < BT) ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+}
+
+// block per fc1 output channel j
+template <int BT>
 __global__ __launch_bounds__(256) void splat_mlp_fwd1_kernel(const float* __restrict__ gap, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rm,
                                                              float* __restrict__ rv, float momentum, float eps, int training, float* __restrict__ h1,
                                                              float* __restrict__ h2, float* __restrict__ mean, float* __restrict__ invstd, int B, int C,
                                                              int inter, int groups) {
-    __shared__ float red[4][SPLAT_MAXB];
-    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[4][32];
+    constexpr int NS = 256 / BT;
+    const int j = blockIdx.x, tid = threadIdx.x, bl = tid & (BT - 1), sl = tid / BT;
     const int Cg = C / groups, grp = j / (inter / groups);
     const float* wr = w1 + (size_t)j * Cg;
-    float acc[SPLAT_MAXB];
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int c = tid; c < Cg; c += 256) {
-        const float wv = wr[c];
-#pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) acc[b] += wv * gap[(size_t)b * C + grp * Cg + c];
-    }
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
-    __syncthreads();
-    const float bias = b1 ? b1[j] : 0.f;
-    float m = 0.f;
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { acc[b] = ((red[0][b] + red[1][b]) + (red[2][b] + red[3][b])) + bias; m += acc[b]; }
+    const float* gr = gap + (size_t)(bl < B ? bl : 0) * C + grp * Cg;
+    float acc = 0.f;
+    if (bl < B)
+        for (int c = sl; c < Cg; c += NS) acc += wr[c] * gr[c];
+    const float hsum = splat_slice_sum<BT>(acc, red);
+    if (tid >= BT) return;                                  // threads 0 .. BT-1 (one row of wave 0) finish the channel
+    const bool live = bl < B;
+    const float h = live ? hsum + (b1 ? b1[j] : 0.f) : 0.f;
     float mu, is;
     if (training) {
-        mu = m / (float)B;
-        float var = 0.f;
-#pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) { const float d = acc[b] - mu; var += d * d; }
-        var /= (float)B;
+        mu = splat_row_sum<BT>(h) / (float)B;
+        const float d = live ? h - mu : 0.f;
+        const float var = splat_row_sum<BT>(d * d) / (float)B;
         is = 1.f / sqrtf(var + eps);
         if (tid == 0) {
             if (rm) rm[j] = (1.f - momentum) * rm[j] + momentum * mu;
@@ -294,36 +307,27 @@ __global__ __launch_bounds__(256) void splat_mlp_fwd1_kernel(const float* __rest
         is = 1.f / sqrtf(rv[j] + eps);
     }
     if (tid == 0) { mean[j] = mu; invstd[j] = is; }
-    const float g = gamma[j], be = beta[j];
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B && tid == b) {
-            h1[(size_t)b * inter + j] = acc[b];
-            const float o = (acc[b] - mu) * is * g + be;
-            h2[(size_t)b * inter + j] = o > 0.f ? o : 0.f;
-        }
+    if (live) {
+        h1[(size_t)bl * inter + j] = h;
+        const float o = (h - mu) * is * gamma[j] + beta[j];
+        h2[(size_t)bl * inter + j] = o > 0.f ? o : 0.f;
+    }
 }
 // block per fc2 output channel n: logits[b][n]
+template <int BT>
 __global__ __launch_bounds__(256) void splat_mlp_fwd2_kernel(const float* __restrict__ h2, const float* __restrict__ w2, const float* __restrict__ b2,
                                                              float* __restrict__ logits, int B, int inter, int N, int groups) {
-    __shared__ float red[4][SPLAT_MAXB];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[4][32];
+    constexpr int NS = 256 / BT;
+    const int n = blockIdx.x, tid = threadIdx.x, bl = tid & (BT - 1), sl = tid / BT;
     const int Ig = inter / groups, grp = n / (N / groups);
     const float* wr = w2 + (size_t)n * Ig;
-    float acc[SPLAT_MAXB];
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int j = tid; j < Ig; j += 256) {
-        const float wv = wr[j];
-#pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) acc[b] += wv * h2[(size_t)b * inter + grp * Ig + j];
-    }
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
-    __syncthreads();
-    if (tid < B) logits[(size_t)tid * N + n] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + (b2 ? b2[n] : 0.f);
+    const float* hr = h2 + (size_t)(bl < B ? bl : 0) * inter + grp * Ig;
+    float acc = 0.f;
+    if (bl < B)
+        for (int j = sl; j < Ig; j += NS) acc += wr[j] * hr[j];
+    const float v = splat_slice_sum<BT>(acc, red);
+    if (tid < BT && bl < B) logits[(size_t)bl * N + n] = v + (b2 ? b2[n] : 0.f);
 }
 extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* gamma, const float* beta, float* rm, float* rv,
                                   float momentum, float eps, int training, const float* w2, const float* b2, float* h1, float* h2, float* mean,
@@ -332,60 +336,41 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
     OCTA_REQUIRE(B >= 1 && B <= SPLAT_MAXB && groups >= 1 && C % groups == 0 && inter % groups == 0, "octa_splat_mlp_fwd: needs 1 <= B <= 32 (got %d)", B);
     OCTA_REQUIRE(training ? B > 1 : (rm && rv), "octa_splat_mlp_fwd: batch statistics need B > 1, eval needs running stats");
     hipStream_t st = (hipStream_t)stream;
-    splat_mlp_fwd1_kernel<<<inter, 256, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
+    if (B <= 16) splat_mlp_fwd1_kernel<16><<<inter, 256, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
+    else splat_mlp_fwd1_kernel<32><<<inter, 256, 0, st>>>(gap, w1, b1, gamma, beta, rm, rv, momentum, eps, training, h1, h2, mean, invstd, B, C, inter, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd1");
-    splat_mlp_fwd2_kernel<<<2 * C, 256, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
+    if (B <= 16) splat_mlp_fwd2_kernel<16><<<2 * C, 256, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
+    else splat_mlp_fwd2_kernel<32><<<2 * C, 256, 0, st>>>(h2, w2, b2, logits, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_fwd2");
     return OCTA_OK;
 }
 
 // backward A: block per j.  dh2[b][j] = sum_n dl[b][n] W2[n][j]  -> relu mask -> bn1 backward -> dh1[b][j]; dgamma/dbeta +=
+template <int BT>
 __device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
                                                             const float* __restrict__ h2, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dh1,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1, int B,
-                                                            int inter, int N, int groups) {
-    // 4 waves split the n range (the kernel is a chain of dependent memory round trips: 4x fewer of them), partials meet in LDS
-    __shared__ float red[4][SPLAT_MAXB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                            int inter, int N, int groups, float (*red)[32]) {
+    constexpr int NS = 256 / BT;
+    const int tid = threadIdx.x, bl = tid & (BT - 1), sl = tid / BT;
     const int Ig = inter / groups, Ng = N / groups, grp = j / Ig, jl = j - grp * Ig;
-    float acc[SPLAT_MAXB];
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
-    for (int nn = threadIdx.x; nn < Ng; nn += 256) {
-        const int n = grp * Ng + nn;
-        const float wv = w2[(size_t)n * Ig + jl];
-#pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) acc[b] += wv * dl[(size_t)b * N + n];
-    }
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) { const float v = wave_sum(acc[b]); if (lane == 0) red[wave][b] = v; }
-    __syncthreads();
-    if (wave != 0) return;
+    const float* dr = dl + (size_t)(bl < B ? bl : 0) * N + grp * Ng;
+    const float* wc = w2 + (size_t)grp * Ng * Ig + jl;
+    float acc = 0.f;
+    if (bl < B)
+        for (int nn = sl; nn < Ng; nn += NS) acc += wc[(size_t)nn * Ig] * dr[nn];
+    float d = splat_slice_sum<BT>(acc, red);
+    if (tid >= BT) return;
+    const bool live = bl < B;
     const float mu = mean[j], is = invstd[j], g = gamma[j];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) {
-            float d = (red[0][b] + red[1][b]) + (red[2][b] + red[3][b]);
-            if (!(h2[(size_t)b * inter + j] > 0.f)) d = 0.f;
-            acc[b] = d;
-            s1 += d;
-            s2 += d * (h1[(size_t)b * inter + j] - mu) * is;
-        }
-    const float m1 = s1 / (float)B, m2 = s2 / (float)B;
-    float sdh = 0.f;
-#pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) {
-            const float xh = (h1[(size_t)b * inter + j] - mu) * is;
-            const float v = g * is * (acc[b] - m1 - xh * m2);
-            sdh += v;
-            if (lane == (b & 63)) dh1[(size_t)b * inter + j] = v;
-        }
-    if (lane == 0) {
+    const float xh = live ? (h1[(size_t)bl * inter + j] - mu) * is : 0.f;
+    if (!live || !(h2[(size_t)bl * inter + j] > 0.f)) d = 0.f;
+    const float s1 = splat_row_sum<BT>(d), s2 = splat_row_sum<BT>(d * xh);
+    const float v = live ? g * is * (d - s1 / (float)B - xh * (s2 / (float)B)) : 0.f;
+    const float sdh = splat_row_sum<BT>(v);
+    if (live) dh1[(size_t)bl * inter + j] = v;
+    if (tid == 0) {
         dgamma[j] += s2;
         dbeta[j] += s1;
         if (db1) db1[j] += sdh;
@@ -456,12 +441,14 @@ __device__ __forceinline__ void splat_mlp_bwdD_body(int j, const float* __restri
         dw1[(size_t)j * Cg + c] += a;
     }
 }
+template <int BT>
 __global__ __launch_bounds__(256) void splat_mlp_bwdAB_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
                                                              const float* __restrict__ h2, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, float* __restrict__ dh1, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ db1, float* __restrict__ dw2,
                                                              float* __restrict__ db2, int B, int inter, int N, int groups) {
-    if ((int)blockIdx.x < inter) splat_mlp_bwdA_body(blockIdx.x, dl, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups);
+    __shared__ float red[4][32];
+    if ((int)blockIdx.x < inter) splat_mlp_bwdA_body<BT>(blockIdx.x, dl, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups, red);
     else splat_mlp_bwdB_body(blockIdx.x - inter, dl, h2, dw2, db2, B, inter, N, groups);
 }
 __global__ __launch_bounds__(256) void splat_mlp_bwdCD_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, const float* __restrict__ gap,
@@ -482,7 +469,8 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
     hipStream_t st = (hipStream_t)stream;
     // two launches instead of four (+ a zero fill): A and B only read dlogits, C and D only read dh1 -- each pair shares a grid,
     // the block index selects the role
-    splat_mlp_bwdAB_kernel<<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    if (B <= 16) splat_mlp_bwdAB_kernel<16><<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    else splat_mlp_bwdAB_kernel<32><<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdAB");
     if (!prezeroed && octa_zero_async(dgap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
     {
