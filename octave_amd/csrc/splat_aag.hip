@@ -377,37 +377,38 @@ __device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restri
     }
 }
 // backward B: block per n.  dW2[n][j] += sum_b dl[b][n] h2[b][j];  db2[n] += sum_b dl[b][n]
+template <int BT>
 __device__ __forceinline__ void splat_mlp_bwdB_body(int n, const float* __restrict__ dl, const float* __restrict__ h2, float* __restrict__ dw2,
                                                             float* __restrict__ db2, int B, int inter, int N, int groups) {
-    const int lane = threadIdx.x;          // one wave does the work (the merged launch has 256-thread blocks)
-    if (lane >= 64) return;
     const int Ig = inter / groups, grp = n / (N / groups);
-    float d[SPLAT_MAXB];
+    float d[BT];
     float sb = 0.f;
 #pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) { d[b] = b < B ? dl[(size_t)b * N + n] : 0.f; sb += d[b]; }
-    for (int j = lane; j < Ig; j += 64) {
+    for (int b = 0; b < BT; ++b) { d[b] = b < B ? dl[(size_t)b * N + n] : 0.f; sb += d[b]; }     // uniform addresses: scalar loads
+    for (int j = threadIdx.x; j < Ig; j += 256) {
         float a = 0.f;
 #pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) a += d[b] * h2[(size_t)b * inter + grp * Ig + j];
+        for (int b = 0; b < BT; ++b) a += d[b] * h2[(size_t)(b < B ? b : 0) * inter + grp * Ig + j];
         dw2[(size_t)n * Ig + j] += a;
     }
-    if (lane == 0 && db2) db2[n] += sb;
+    if (threadIdx.x == 0 && db2) db2[n] += sb;
 }
 // backward C: dgap[b][c] += sum_j dh1[b][j] W1[j][c].  Block = 64 channels c (lanes) x 4 waves; the j range of the
 // channel's group is split over gridDim.y blocks and the block's 4 waves (coalesced W1 rows), partial sums meet in
 // LDS and leave with one atomic per (b, c).  dgap is zeroed by the host wrapper.
-__device__ __forceinline__ void splat_mlp_bwdC_body(int bx, int by, int ny, float (*red)[SPLAT_MAXB][64], const float* __restrict__ dh1, const float* __restrict__ w1, float* __restrict__ dgap, int B,
+template <int BT>
+__device__ __forceinline__ void splat_mlp_bwdC_body(int bx, int by, int ny, float (*red)[BT][64], const float* __restrict__ dh1, const float* __restrict__ w1, float* __restrict__ dgap, int B,
                                                              int C, int inter, int groups) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = bx * 64 + lane;
     const int Cg = C / groups, Ig = inter / groups;
     const bool live = c < C;
+    // the 64 channels of a block may straddle two groups only when Cg % 64 != 0; the group is per lane, the dh1 row index is
+    // uniform whenever it is not (the common case), so those loads become scalar
     const int grp = live ? c / Cg : 0, cl = live ? c - grp * Cg : 0;
-    float acc[SPLAT_MAXB];
+    float acc[BT];
 #pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) acc[b] = 0.f;
+    for (int b = 0; b < BT; ++b) acc[b] = 0.f;
     const int per = (Ig + ny - 1) / ny;
     const int j0 = by * per, j1 = min(Ig, j0 + per);
     if (live)
@@ -415,29 +416,26 @@ __device__ __forceinline__ void splat_mlp_bwdC_body(int bx, int by, int ny, floa
             const int j = grp * Ig + jj;
             const float wv = w1[(size_t)j * Cg + cl];
 #pragma unroll
-            for (int b = 0; b < SPLAT_MAXB; ++b)
-                if (b < B) acc[b] += wv * dh1[(size_t)b * inter + j];
+            for (int b = 0; b < BT; ++b) acc[b] += wv * dh1[(size_t)(b < B ? b : 0) * inter + j];
         }
 #pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b)
-        if (b < B) red[wave][b][lane] = acc[b];
+    for (int b = 0; b < BT; ++b) red[wave][b][lane] = acc[b];
     __syncthreads();
     for (int b = wave; b < B; b += 4)
         if (live) atomicAdd(dgap + (size_t)b * C + c, red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]);
 }
 // backward D: block per j.  dW1[j][c] += sum_b dh1[b][j] gap[b][c]
+template <int BT>
 __device__ __forceinline__ void splat_mlp_bwdD_body(int j, const float* __restrict__ dh1, const float* __restrict__ gap, float* __restrict__ dw1, int B,
                                                             int C, int inter, int groups) {
-    const int lane = threadIdx.x;
     const int Cg = C / groups, grp = j / (inter / groups);
-    float d[SPLAT_MAXB];
+    float d[BT];
 #pragma unroll
-    for (int b = 0; b < SPLAT_MAXB; ++b) d[b] = b < B ? dh1[(size_t)b * inter + j] : 0.f;
-    for (int c = lane; c < Cg; c += 256) {
+    for (int b = 0; b < BT; ++b) d[b] = b < B ? dh1[(size_t)b * inter + j] : 0.f;
+    for (int c = threadIdx.x; c < Cg; c += 256) {
         float a = 0.f;
 #pragma unroll
-        for (int b = 0; b < SPLAT_MAXB; ++b)
-            if (b < B) a += d[b] * gap[(size_t)b * C + grp * Cg + c];
+        for (int b = 0; b < BT; ++b) a += d[b] * gap[(size_t)(b < B ? b : 0) * C + grp * Cg + c];
         dw1[(size_t)j * Cg + c] += a;
     }
 }
@@ -449,15 +447,16 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdAB_kernel(const float* __res
                                                              float* __restrict__ db2, int B, int inter, int N, int groups) {
     __shared__ float red[4][32];
     if ((int)blockIdx.x < inter) splat_mlp_bwdA_body<BT>(blockIdx.x, dl, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups, red);
-    else splat_mlp_bwdB_body(blockIdx.x - inter, dl, h2, dw2, db2, B, inter, N, groups);
+    else splat_mlp_bwdB_body<BT>(blockIdx.x - inter, dl, h2, dw2, db2, B, inter, N, groups);
 }
+template <int BT>
 __global__ __launch_bounds__(256) void splat_mlp_bwdCD_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, const float* __restrict__ gap,
                                                              float* __restrict__ dgap, float* __restrict__ dw1, int B, int C, int inter, int groups,
                                                              int nx, int ny) {
-    __shared__ float red[4][SPLAT_MAXB][64];
+    __shared__ float red[4][BT][64];
     const int nC = nx * ny;
-    if ((int)blockIdx.x < nC) splat_mlp_bwdC_body(blockIdx.x % nx, blockIdx.x / nx, ny, red, dh1, w1, dgap, B, C, inter, groups);
-    else splat_mlp_bwdD_body(blockIdx.x - nC, dh1, gap, dw1, B, C, inter, groups);
+    if ((int)blockIdx.x < nC) splat_mlp_bwdC_body<BT>(blockIdx.x % nx, blockIdx.x / nx, ny, red, dh1, w1, dgap, B, C, inter, groups);
+    else splat_mlp_bwdD_body<BT>(blockIdx.x - nC, dh1, gap, dw1, B, C, inter, groups);
 }
 extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
                                   const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1, float* db1,
@@ -479,7 +478,8 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
         if (js < 1) js = 1;
         if (js > 8) js = 8;
         const int nC = cdiv(C, 64) * js;
-        splat_mlp_bwdCD_kernel<<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
+        if (B <= 16) splat_mlp_bwdCD_kernel<16><<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
+        else splat_mlp_bwdCD_kernel<32><<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
     }
     OCTA_CHECK_LAUNCH("splat_mlp_bwdCD");
     return OCTA_OK;
