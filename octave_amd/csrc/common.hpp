@@ -114,9 +114,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+template <int CTRL> __device__ __forceinline__ double octa_dpp_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += octa_dpp_d<0xB1>(v);
+    v += octa_dpp_d<0x4E>(v);
+    v += octa_dpp_d<0x124>(v);
+    v += octa_dpp_d<0x128>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 // block-wide sum of NV values per thread; result valid in thread 0 (and broadcast via smem[0..NV))

@@ -125,49 +125,35 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
     }
 }
 
-// one wavefront per channel: lanes merge a strided subset of the block partials, then a butterfly of
-// Chan merges combines the 64 lane results (the merge is associative)
+// one workgroup per channel.  The block partials (n_b, mean_b, M2_b) are re-expressed around a common reference r (the first
+// block's mean): S1 = sum n_b (mean_b - r), S2 = sum M2_b + n_b (mean_b - r)^2, after which mean = r + S1/n and
+// M2 = S2 - S1^2/n (parallel-axis form of the Chan merge, evaluated in double: r is within a few sigma/sqrt(n_b) of the mean,
+// so nothing cancels).  Plain sums reduce with DPP adds; the pairwise-merge butterfly this replaces spent 36 LDS-crossbar
+// shuffles and 9 double divisions on the critical path of a kernel that runs 70 times per step.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nby, int rpb, int C, int64_t rows, float eps,
                                                                float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                                float* __restrict__ rm, float* __restrict__ rv) {
-    __shared__ double wred[4][3];
+    __shared__ double wred[4][2];
     const int c = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double n = 0.0, m = 0.0, m2 = 0.0;
-    for (int b = threadIdx.x; b < nby; b += 256) {       // 4 waves: a quarter of the dependent round trips
+    const double r = (double)partial[c];                 // block 0's mean
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nby; b += 256) {
         const int64_t lo = (int64_t)b * rpb;
         const double nb = (double)((rows - lo) < rpb ? (rows - lo) : rpb);
-        const double mb = (double)partial[((size_t)b * 2) * C + c], m2b = (double)partial[((size_t)b * 2 + 1) * C + c];
-        const double delta = mb - m, tot = n + nb;
-        m += delta * nb / tot;
-        m2 += m2b + delta * delta * n * nb / tot;
-        n = tot;
+        const double d = (double)partial[((size_t)b * 2) * C + c] - r;
+        s1 += nb * d;
+        s2 += (double)partial[((size_t)b * 2 + 1) * C + c] + nb * d * d;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double n2 = __shfl_xor(n, o, 64), mm2 = __shfl_xor(m, o, 64), q2 = __shfl_xor(m2, o, 64);
-        const double tot = n + n2;
-        if (tot > 0.0) {
-            const double delta = mm2 - m;
-            m2 = m2 + q2 + delta * delta * n * n2 / tot;
-            m = m + delta * n2 / tot;
-        }
-        n = tot;
-    }
-    if (lane == 0) { wred[wave][0] = n; wred[wave][1] = m; wred[wave][2] = m2; }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = s1; wred[threadIdx.x >> 6][1] = s2; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int w = 1; w < 4; ++w) {
-        const double n2 = wred[w][0], mm2 = wred[w][1], q2 = wred[w][2];
-        const double tot = n + n2;
-        if (tot > 0.0) {
-            const double delta = mm2 - m;
-            m2 = m2 + q2 + delta * delta * n * n2 / tot;
-            m = m + delta * n2 / tot;
-        }
-        n = tot;
-    }
-    double var = m2 / n;
+    s1 = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
+    s2 = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
+    const double n = (double)rows;
+    const double m = r + s1 / n;
+    double var = (s2 - s1 * s1 / n) / n;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
