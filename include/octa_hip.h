@@ -410,6 +410,14 @@ int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);
 
+/* dst <- slot (*dev_counter % slots) of a ring of `slots` x slot_bytes in pinned, device-addressable HOST memory, copied
+ * by a kernel (no hipMemcpy).  dev_counter is the step counter octa_host_tick advances. */
+int octa_ring_fetch(const void* ring_host, int64_t slot_bytes, int slots, const int* dev_counter, void* dst,
+                    octa_stream_t stream);
+/* Step tick: *dev_counter += 1 and the new value is stored (system scope) to host_flag, a word of pinned host memory
+ * that the device can address.  Lets the host pace queued hipGraph replays with plain loads (train.py). */
+int octa_host_tick(int* dev_counter, int* host_flag, octa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

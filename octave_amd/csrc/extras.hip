@@ -419,3 +419,41 @@ extern "C" int octa_mask_pyramid(const float* src, float* const* levels_host, in
     OCTA_CHECK_LAUNCH("mask_pyramid");
     return OCTA_OK;
 }
+
+// ------------------------------------------------------------------------------------------ step tick
+// The last kernel of a training step bumps a device counter and publishes it to a word of pinned HOST memory (system-scope
+// store).  The host paces hipGraph replays by reading that word: event queries proved unusable for this (an event behind a
+// few queued graph launches was reported 70-100 ms after it had actually completed), an ordinary load from coherent pinned
+// memory has no such latency and needs no HIP call.
+__global__ void host_tick_kernel(int* __restrict__ dev_counter, int* host_flag) {
+    const int v = *dev_counter + 1;
+    *dev_counter = v;
+    __hip_atomic_store(host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int octa_host_tick(int* dev_counter, int* host_flag, octa_stream_t stream) {
+    OCTA_REQUIRE(dev_counter && host_flag, "octa_host_tick: null pointer");
+    host_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dev_counter, host_flag);
+    OCTA_CHECK_LAUNCH("host_tick");
+    return OCTA_OK;
+}
+
+// Slot (*dev_counter % slots) of a ring in pinned HOST memory -> device buffer, as a kernel.  The per-step host updates
+// (discriminator noise drawn on the CPU, Adam bias corrections) reach the device through this instead of hipMemcpyAsync: a
+// pinned H2D copy queued between hipGraph launches made the device wait for the host runtime (replayed steps stalled for
+// ~3 step times whenever the host was not inside a HIP call), a kernel that reads host memory has no such dependency.
+__global__ __launch_bounds__(256) void ring_fetch_kernel(const unsigned* __restrict__ ring, int64_t slot_words, int slots,
+                                                         const int* __restrict__ dev_counter, unsigned* __restrict__ dst) {
+    const int slot = (int)((unsigned)(*dev_counter) % (unsigned)slots);
+    const unsigned* src = ring + (int64_t)slot * slot_words;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < slot_words; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int octa_ring_fetch(const void* ring_host, int64_t slot_bytes, int slots, const int* dev_counter, void* dst, octa_stream_t stream) {
+    OCTA_REQUIRE(ring_host && dev_counter && dst && slots > 0 && slot_bytes > 0 && slot_bytes % 4 == 0, "octa_ring_fetch: bad arguments (slot_bytes %% 4)");
+    const int64_t words = slot_bytes / 4;
+    int blocks = (int)((words + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    ring_fetch_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned*)ring_host, words, slots, dev_counter, (unsigned*)dst);
+    OCTA_CHECK_LAUNCH("ring_fetch");
+    return OCTA_OK;
+}
+

@@ -185,6 +185,20 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     return OCTA_OK;
 }
 
+// Column-aligned grid stride: the launch makes (gridDim.x * 256) a multiple of the chunks per row, so a thread keeps ONE channel
+// chunk for its whole life and loads that chunk's coefficients once.  (The one-chunk-per-thread form fetched 128 bytes of
+// per-channel parameters for every 16 bytes of activations: the L1 request rate, not HBM, set its speed.)
+static inline int ew_blocks_aligned(int64_t total, int cpr) {
+    int64_t b = cdiv64(total, 256);
+    const int64_t cap = 256 * 10;                       // ~10 resident workgroups per CU
+    if (b > cap) b = cap;
+    int a = cpr, g = 256;                               // unit = cpr / gcd(cpr, 256)
+    while (g) { const int t = a % g; a = g; g = t; }
+    const int unit = cpr / a;
+    b = (b + unit - 1) / unit * unit;
+    return (int)(b < 1 ? 1 : b);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, int xoff, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -193,45 +207,45 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        uint8_t* __restrict__ rmask) {
     constexpr int EPC = DT<T>::EPC;
     const int64_t total = rows * cpr;
+    const int64_t stride = (int64_t)gridDim.x * 256;     // multiple of cpr (ew_blocks_aligned)
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rstep = stride / cpr;
+    int64_t r = i0 / cpr;
+    const int c0 = (int)(i0 - r * cpr) * EPC;
+    float mu[EPC], sc[EPC], be[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC / 4; ++k) {
+        const float4 m4 = *(const float4*)(mean + c0 + 4 * k), i4 = *(const float4*)(invstd + c0 + 4 * k);
+        const float4 g4 = *(const float4*)(gamma + c0 + 4 * k), b4 = *(const float4*)(beta + c0 + 4 * k);
+        mu[4 * k] = m4.x; mu[4 * k + 1] = m4.y; mu[4 * k + 2] = m4.z; mu[4 * k + 3] = m4.w;
+        sc[4 * k] = g4.x * i4.x; sc[4 * k + 1] = g4.y * i4.y; sc[4 * k + 2] = g4.z * i4.z; sc[4 * k + 3] = g4.w * i4.w;
+        be[4 * k] = b4.x; be[4 * k + 1] = b4.y; be[4 * k + 2] = b4.z; be[4 * k + 3] = b4.w;
+    }
     // block-uniform trip count: the mask bytes of 4 neighbouring lanes leave as ONE dword (byte stores ran 5x slower)
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += stride, r += rstep) {
         const int64_t i = base + threadIdx.x;
         const bool live = i < total;
-        const int64_t r = live ? i / cpr : 0;
-        const int c0 = live ? (int)(i - r * cpr) * EPC : 0;
+        const int64_t rr_ = live ? r : 0;
         float v[EPC], rr[EPC];
         unsigned mb = 0u;
-        unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), v);
-        if (res) unpack16<T>(*(const uint4*)(res + r * ldr + roff + c0), rr);
-        // per-channel parameters as 16-byte loads issued together (32 scalar loads were being serialised)
-        float mu[EPC], isd[EPC], ga[EPC], be[EPC];
-#pragma unroll
-        for (int k = 0; k < EPC / 4; ++k) {
-            *(float4*)&mu[4 * k] = *(const float4*)(mean + c0 + 4 * k);
-            *(float4*)&isd[4 * k] = *(const float4*)(invstd + c0 + 4 * k);
-            *(float4*)&ga[4 * k] = *(const float4*)(gamma + c0 + 4 * k);
-            *(float4*)&be[4 * k] = *(const float4*)(beta + c0 + 4 * k);
-        }
+        unpack16<T>(*(const uint4*)(x + rr_ * ldx + xoff + c0), v);
+        if (res) unpack16<T>(*(const uint4*)(res + rr_ * ldr + roff + c0), rr);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float sc = ga[e] * isd[e];
-            float o = (v[e] - mu[e]) * sc + be[e];
+            float o = (v[e] - mu[e]) * sc[e] + be[e];
             if (res) o += rr[e];
             if (relu) { if (o > 0.f) mb |= 1u << e; else o = 0.f; }
             v[e] = o;
         }
-        if (live) *(uint4*)(y + r * ldy + yoff + c0) = pack16<T>(v);
+        if (live) *(uint4*)(y + rr_ * ldy + yoff + c0) = pack16<T>(v);
         if (rmask) {
             unsigned w = live ? (mb << (8 * (threadIdx.x & 3))) : 0u;
-            w |= __shfl_xor(w, 1, 64);
-            w |= __shfl_xor(w, 2, 64);
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);      // lane ^ 2
             if ((threadIdx.x & 3) == 0 && live) *(unsigned*)(rmask + i) = w;     // buffer is padded to a multiple of 4 bytes
         }
     }
 }
-
-// one 16-byte chunk per thread up to 131072 blocks (caps of 4096 .. 32768 blocks with a grid-stride loop were 1-4 % slower)
-static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 131072 ? 131072 : (b < 1 ? 1 : b)); }
 
 extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, const void* residual, int ldr, int roff, void* y, int ldy, int yoff, int64_t rows,
@@ -241,11 +255,11 @@ extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean
                  "octa_bn_apply: C/ld/off must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OCTA_F32)
-        bn_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu, relu_mask);
+        bn_apply_kernel<float><<<ew_blocks_aligned(rows * (C / 4), C / 4), 256, 0, st>>>((const float*)x, ldx, xoff, mean, invstd, gamma, beta, (const float*)residual, ldr, roff, (float*)y, ldy, yoff, rows, C / 4, relu, relu_mask);
     else if (dtype == OCTA_BF16)
-        bn_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
+        bn_apply_kernel<bf16_t><<<ew_blocks_aligned(rows * (C / 8), C / 8), 256, 0, st>>>((const bf16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const bf16_t*)residual, ldr, roff, (bf16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
     else if (dtype == OCTA_F16)
-        bn_apply_kernel<f16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const f16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const f16_t*)residual, ldr, roff, (f16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
+        bn_apply_kernel<f16_t><<<ew_blocks_aligned(rows * (C / 8), C / 8), 256, 0, st>>>((const f16_t*)x, ldx, xoff, mean, invstd, gamma, beta, (const f16_t*)residual, ldr, roff, (f16_t*)y, ldy, yoff, rows, C / 8, relu, relu_mask);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_bn_apply: bad dtype");
     OCTA_CHECK_LAUNCH("bn_apply");
     return OCTA_OK;
@@ -281,9 +295,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int EPC = DT<T>::EPC;
     const int cpr = C / EPC;
     const int64_t total = rows * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / cpr;
-        const int c0 = (int)(i - r * cpr) * EPC;
+    const int64_t stride = (int64_t)gridDim.x * 256;     // multiple of cpr: one channel chunk per thread (see bn_apply_kernel)
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rstep = stride / cpr;
+    int64_t r = i0 / cpr;
+    const int c0 = (int)(i0 - r * cpr) * EPC;
+    float mu[EPC], isd[EPC], gi[EPC], f0[EPC], f1[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC / 4; ++k) {
+        const float4 m4 = *(const float4*)(mean + c0 + 4 * k), i4 = *(const float4*)(invstd + c0 + 4 * k), g4 = *(const float4*)(gamma + c0 + 4 * k);
+        const float4 a4 = *(const float4*)(fin + c0 + 4 * k), b4 = *(const float4*)(fin + C + c0 + 4 * k);
+        mu[4 * k] = m4.x; mu[4 * k + 1] = m4.y; mu[4 * k + 2] = m4.z; mu[4 * k + 3] = m4.w;
+        isd[4 * k] = i4.x; isd[4 * k + 1] = i4.y; isd[4 * k + 2] = i4.z; isd[4 * k + 3] = i4.w;
+        gi[4 * k] = g4.x * i4.x; gi[4 * k + 1] = g4.y * i4.y; gi[4 * k + 2] = g4.z * i4.z; gi[4 * k + 3] = g4.w * i4.w;
+        f0[4 * k] = a4.x; f0[4 * k + 1] = a4.y; f0[4 * k + 2] = a4.z; f0[4 * k + 3] = a4.w;
+        f1[4 * k] = b4.x; f1[4 * k + 1] = b4.y; f1[4 * k + 2] = b4.z; f1[4 * k + 3] = b4.w;
+    }
+    for (int64_t i = i0; i < total; i += stride, r += rstep) {
         float dv[EPC], xv[EPC], yv[EPC], o[EPC];
         unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + c0), dv);
         unpack16<T>(*(const uint4*)(x + r * ldx + xoff + c0), xv);
@@ -292,22 +320,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
         } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + c0), yv);
-        float mu[EPC], isd[EPC], ga[EPC], f0[EPC], f1[EPC];
-#pragma unroll
-        for (int k = 0; k < EPC / 4; ++k) {
-            *(float4*)&mu[4 * k] = *(const float4*)(mean + c0 + 4 * k);
-            *(float4*)&isd[4 * k] = *(const float4*)(invstd + c0 + 4 * k);
-            *(float4*)&ga[4 * k] = *(const float4*)(gamma + c0 + 4 * k);
-            *(float4*)&f0[4 * k] = *(const float4*)(fin + c0 + 4 * k);
-            *(float4*)&f1[4 * k] = *(const float4*)(fin + C + c0 + 4 * k);
-        }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
             dv[e] = d;
-            const float is = isd[e];
-            const float xh = (xv[e] - mu[e]) * is;
-            o[e] = ga[e] * is * (d - f0[e] - xh * f1[e]);
+            const float xh = (xv[e] - mu[e]) * isd[e];
+            o[e] = gi[e] * (d - f0[e] - xh * f1[e]);
         }
         *(uint4*)(dx + r * lddx + dxoff + c0) = pack16<T>(o);
         if (dres) *(uint4*)(dres + r * lddr + droff + c0) = pack16<T>(dv);
@@ -341,11 +359,11 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");
     if (dtype == OCTA_F32)
-        bn_bwd_apply_kernel<float><<<ew_blocks(rows * (C / 4)), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
+        bn_bwd_apply_kernel<float><<<ew_blocks_aligned(rows * (C / 4), C / 4), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
     else if (dtype == OCTA_BF16)
-        bn_bwd_apply_kernel<bf16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
+        bn_bwd_apply_kernel<bf16_t><<<ew_blocks_aligned(rows * (C / 8), C / 8), 256, 0, st>>>((const bf16_t*)dy, lddy, dyoff, (const bf16_t*)x, ldx, xoff, (const bf16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (bf16_t*)dx, lddx, dxoff, (bf16_t*)dres, lddr, droff, rows, C, relu);
     else
-        bn_bwd_apply_kernel<f16_t><<<ew_blocks(rows * (C / 8)), 256, 0, st>>>((const f16_t*)dy, lddy, dyoff, (const f16_t*)x, ldx, xoff, (const f16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (f16_t*)dx, lddx, dxoff, (f16_t*)dres, lddr, droff, rows, C, relu);
+        bn_bwd_apply_kernel<f16_t><<<ew_blocks_aligned(rows * (C / 8), C / 8), 256, 0, st>>>((const f16_t*)dy, lddy, dyoff, (const f16_t*)x, ldx, xoff, (const f16_t*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (f16_t*)dx, lddx, dxoff, (f16_t*)dres, lddr, droff, rows, C, relu);
     OCTA_CHECK_LAUNCH("bn_bwd_apply");
     return OCTA_OK;
 }

@@ -12,7 +12,9 @@ laid out in reverse execution order, and then consumed by ONE fused Adam launch 
 statistics and the WPCE class weights are per-replica, like DistributedDataParallel on the reference
 would be; parameters and buffers are broadcast from rank 0 at construction.
 """
+import collections
 import os
+import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -224,28 +226,46 @@ def mask_pyramid(mask: Tensor, levels: int = 5) -> List[Tensor]:
     return [mask[:, :, ::2 ** i, ::2 ** i] for i in range(levels)]
 
 
-class _PinnedRing:
-    """Rotating pinned staging buffers for small host->device updates issued while the GPU still runs
-    earlier steps: a slot is only rewritten after the async copy that read it has completed (event)."""
+class _StepTick:
+    """Step counter the device publishes to pinned host memory (octa_host_tick, the last kernel of every step).  Reading it is
+    a plain load: the one way found to learn on the host, promptly and without a HIP call, how far the device has got while
+    graph launches are queued (event queries came back 70-100 ms late in that situation)."""
 
-    def __init__(self, shape, device, slots=4):
-        self.host = [torch.zeros(shape, pin_memory=True) for _ in range(slots)]
-        self.events = [None] * slots
+    def __init__(self, device):
+        self.dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.np = self.host.numpy()
+        self.launched = 0            # steps handed to the device so far (eager launches and replays)
+
+    def done(self) -> int:
+        return int(self.np[0])
+
+    def wait_until(self, step: int):
+        while int(self.np[0]) < step:
+            time.sleep(0.00005)
+
+
+class _PinnedRing:
+    """Per-step host -> device updates (Adam bias corrections, the discriminator's CPU random draws) while the GPU still runs
+    earlier steps: the host writes slot (step % slots) of a pinned ring, a KERNEL (octa_ring_fetch) copies the slot selected by
+    the device's own step counter into the static buffer the step reads.  No hipMemcpyAsync: a pinned H2D copy queued between
+    hipGraph launches made the device depend on the host runtime and replayed steps stalled.  A slot is rewritten only after
+    the step that read it has finished (step tick); with more slots than the host can run ahead that never waits."""
+
+    def __init__(self, shape, device, tick: "_StepTick", slots=8):
+        self.ring = torch.zeros((slots,) + tuple(shape), dtype=torch.float32).pin_memory()
+        self.slots = slots
         self.dev = torch.zeros(shape, device=device)
-        self.i = 0
+        self.tick = tick
+        self.slot_bytes = self.dev.numel() * 4
 
     def slot(self) -> Tensor:
-        ev = self.events[self.i]
-        if ev is not None:
-            ev.synchronize()
-        return self.host[self.i]
+        n = self.tick.launched + 1                       # the step being launched now
+        self.tick.wait_until(n - self.slots)             # the step that read this slot last
+        return self.ring[self.tick.launched % self.slots]
 
     def push(self):
-        self.dev.copy_(self.host[self.i], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[self.i] = ev
-        self.i = (self.i + 1) % len(self.host)
+        lib().octa_ring_fetch(F_._p(self.ring), self.slot_bytes, self.slots, F_._p(self.tick.dev), F_._p(self.dev), F_._st())
 
 
 class _RngFeed:
@@ -253,14 +273,14 @@ class _RngFeed:
     uniform, per call, from the GLOBAL CPU generator exactly like the reference: blocks.py:149-170), staged in
     pinned memory and copied to static device buffers so that a captured hipGraph can consume them."""
 
-    def __init__(self, disc, device, calls=3):
+    def __init__(self, disc, device, tick, calls=3):
         self.has_noise, self.has_label = disc._has_noise, disc._has_label_noise
         self.noise_mod = disc.stack_0[0] if self.has_noise else None
         self.label_mod = disc.out[2] if self.has_label else None
         hw = self.noise_mod.size if self.has_noise else (1, 1)
         self.calls = calls
-        self.noise_ring = _PinnedRing((calls,) + tuple(hw), device)
-        self.sign_ring = _PinnedRing((calls,), device)
+        self.noise_ring = _PinnedRing((calls,) + tuple(hw), device, tick)
+        self.sign_ring = _PinnedRing((calls,), device, tick)
         self.noise_dev, self.sign_dev = self.noise_ring.dev, self.sign_ring.dev
         self.sign_dev.fill_(1.0)
         self.i_noise = self.i_sign = 0
@@ -355,6 +375,8 @@ class TrainStep:
         self._started: List[int] = []
         self._tag_to_bucket = {tag: i for i, (tag, _, _) in enumerate(self.seg_arena.buckets)}
         self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
+        self.max_ahead = int(os.environ.get("OCTA_MAX_AHEAD", "0"))      # replayed steps the host may be ahead of the device (0: no pacing; pacing did not cure the stalls)
+        self._tick = _StepTick(next(net.parameters()).device)
         self.launch_timing = None
 
     # ------------------------------------------------------------------ replicas
@@ -462,6 +484,10 @@ class TrainStep:
     def _phase_finish(self, disc, dyn=None):
         if self.adversarial:
             self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ranges=self._disc_ranges[id(disc)])
+        # last kernel of the step: publish "step n done" to pinned host memory (paces the replayed path, see __call__)
+        lib().octa_host_tick(F_._p(self._tick.dev), F_._p(self._tick.host), F_._st())
+        if not torch.cuda.is_current_stream_capturing():
+            self._tick.launched += 1           # an eagerly launched step (training or capture warm-up); replays count in __call__
 
     def _comm(self):
         if self._comm_stream is None:
@@ -473,7 +499,14 @@ class TrainStep:
             raise ValueError("the adversarial step needs the real mask pyramid")
         cap = self._caps.get(int(x.shape[-1]))
         if cap is not None and self.launch == "graph":
-            return self._replay(cap, x, ys, real_pyramid)
+            # Optional pacing (OCTA_MAX_AHEAD > 0): at most that many replayed steps queued, measured with the step tick in
+            # pinned host memory.  Off by default: on this ROCm stack a loop of replays stalls intermittently either way (the
+            # device idles ~3 step times while the host waits in a HIP call, a sleep or a poll), see autotune_launch.
+            if self.max_ahead > 0:
+                self._tick.wait_until(self._tick.launched + 1 - self.max_ahead)
+            out = self._replay(cap, x, ys, real_pyramid)
+            self._tick.launched += 1
+            return out
         # launch == "eager" (or nothing captured for this size): the step launched kernel by kernel from Python.  Same arenas,
         # step counters and global CPU generator as the replayed path, so the two can be mixed freely.
         out: Dict[str, Tensor] = {}
@@ -509,10 +542,10 @@ class TrainStep:
         cap.disc = self._pick_disc(x)
         cap.feed = None
         if self.adversarial:
-            cap.feed = _RngFeed(cap.disc, dev)
+            cap.feed = _RngFeed(cap.disc, dev, self._tick)
             cap.disc.rng_feed = cap.feed
         if self._dyn is None:
-            self._dyn = [_PinnedRing((2,), dev) for _ in range(2)]
+            self._dyn = [_PinnedRing((2,), dev, self._tick) for _ in range(2)]
             self._dyn_dev = [r.dev for r in self._dyn]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -608,7 +641,7 @@ class TrainStep:
                 b.copy_(c)
         torch.set_rng_state(rng)
 
-    def autotune_launch(self, x, ys, real_pyramid=None, rounds: int = 3, steps: int = 4) -> str:
+    def autotune_launch(self, x, ys, real_pyramid=None, rounds: int = 3, steps: int = 6) -> str:
         """Pick the faster launch path for THIS process on THIS host: hipGraph replay needs almost no host time but pays a few
         microseconds of dependency handling per node and stalls when the box is busy; launching the ~1400 kernels from Python
         costs the host ~33 ms/step.  Both paths run the identical step on the same arenas; `rounds` alternating timings of
@@ -631,7 +664,10 @@ class TrainStep:
                 torch.cuda.synchronize()
                 t[mode].append((time.perf_counter() - t0) / steps)
         med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
-        self.launch = "eager" if med["eager"] < med["graph"] else "graph"
+        # The replayed path must win clearly.  On this ROCm stack a loop of replays is erratic once a few steps are queued: the
+        # device intermittently sits idle for ~3 step times while the host waits (31 ms/step in one run, 45-60 in the next;
+        # tools/graph_host_cost.py, DESIGN.md "launch path"), whereas Python launches are steady.
+        self.launch = "graph" if med["graph"] < 0.9 * med["eager"] else "eager"
         self.launch_timing = med
         self._restore(snap)
         torch.cuda.synchronize()
