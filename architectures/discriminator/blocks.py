@@ -51,8 +51,14 @@ class InstanceNoise(nn.Module):
         self.is_training = is_training
         self.compute_dtype = None
 
-    def draw(self) -> Tensor:
-        return torch.normal(mean=self.mean, std=self.std, size=self.size)      # CPU generator, like ref :150
+    def draw(self, out: Tensor = None) -> Tensor:
+        """One (H, W) plane from the global CPU generator, like ref :150.  `out` (e.g. a slot of pinned staging memory)
+        receives the draw directly: copying a 160k-element CPU tensor afterwards runs as an OpenMP parallel region, and the
+        idle OpenMP workers then spin for ~100-200 ms on every core the process may use - which starved the HIP runtime's
+        helper threads and stalled queued hipGraph replays (train.py, DESIGN.md 'launch path')."""
+        if out is not None:
+            return torch.normal(mean=self.mean, std=self.std, size=self.size, out=out)
+        return torch.normal(mean=self.mean, std=self.std, size=self.size)
 
     def forward(self, x: Tensor, noise_dev: Tensor = None, fed: bool = False):
         """`fed=True`: the (H, W) plane was drawn by the caller (same CPU-generator order) and already lives on

@@ -289,7 +289,7 @@ class _RngFeed:
         nh, sh = self.noise_ring.slot(), self.sign_ring.slot()
         for c in range(self.calls):
             if self.has_noise:
-                nh[c].copy_(self.noise_mod.draw())
+                self.noise_mod.draw(out=nh[c])       # straight into the pinned slot: no parallel CPU copy (see InstanceNoise.draw)
             sh[c] = self.label_mod.draw_sign() if self.has_label else 1.0
         self.noise_ring.push()
         self.sign_ring.push()
@@ -664,10 +664,11 @@ class TrainStep:
                 torch.cuda.synchronize()
                 t[mode].append((time.perf_counter() - t0) / steps)
         med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
-        # The replayed path must win clearly.  On this ROCm stack a loop of replays is erratic once a few steps are queued: the
-        # device intermittently sits idle for ~3 step times while the host waits (31 ms/step in one run, 45-60 in the next;
-        # tools/graph_host_cost.py, DESIGN.md "launch path"), whereas Python launches are steady.
-        self.launch = "graph" if med["graph"] < 0.9 * med["eager"] else "eager"
+        # Prefer the replayed path unless eager launches are clearly faster: a replay costs the host < 2 ms per step, Python
+        # launches ~30 ms - right at the device time, so they are the first to suffer on a busy host.  (Replays used to
+        # stall for ~3 step times at a stretch; the cause was on the CPU side - OpenMP workers spinning after a parallel
+        # tensor copy starved the HIP runtime's helper threads - and is gone, see InstanceNoise.draw / DESIGN.md.)
+        self.launch = "eager" if med["eager"] < 0.97 * med["graph"] else "graph"
         self.launch_timing = med
         self._restore(snap)
         torch.cuda.synchronize()
