@@ -21,6 +21,10 @@ def short(name):
     m8 = re.match(r"void conv_igemm8_kernel<(unsigned short|f16_t), (\d+), (\d+), (\d+)>", name)
     if m8:
         return f"conv_igemm8_kernel<{'bf16' if m8.group(1) == 'unsigned short' else 'f16'},{int(m8.group(2)) * 64}x{int(m8.group(3)) * 64}>"
+    mr = re.match(r"void conv_res_kernel<(unsigned short|f16_t), (\d+), (\d+), (\d+), (\d+)>", name)
+    if mr:      # <T, TAPS, NCH, TN, MODE> -> the name launch_res() reports (256 pixels x TN*16 channels)
+        fam = "conv_res3x3_kernel" if int(mr.group(2)) == 9 else "conv_res1x1_kernel"
+        return f"{fam}<{'bf16' if mr.group(1) == 'unsigned short' else 'f16'},256x{int(mr.group(4)) * 16}>"
     mw = re.match(r"void wgrad8_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if mw:
         return f"wgrad8_kernel<{'f16' if int(mw.group(3)) else 'bf16'},{int(mw.group(1)) * 64}x{int(mw.group(2)) * 64}>"
