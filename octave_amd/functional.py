@@ -678,15 +678,25 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
             flat.zero_()
         dw = flat.view(Cout, KH, KW, Cin_g).permute(0, 3, 1, 2)
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype)
+    j = WgradJob()
+    ctypes.memmove(ctypes.byref(j.d), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+    j.x, j.dy, j.dw, j.dbias = _p(x), _p(dy), _p(dw), _p(dbias)
+    for a, sv in enumerate(dw.stride()):
+        j.dw_strides[a] = sv
+    keep = (x, dy, tuple(dw.shape), tuple(dw.stride()), dw, dbias)
     if defer and _WGRAD_Q is not None:
-        j = WgradJob()
-        ctypes.memmove(ctypes.byref(j.d), ctypes.byref(d), ctypes.sizeof(ConvDesc))
-        j.x, j.dy, j.dw, j.dbias = _p(x), _p(dy), _p(dw), _p(dbias)
-        for a, sv in enumerate(dw.stride()):
-            j.dw_strides[a] = sv
-        _WGRAD_Q.append((j, (x, dy, tuple(dw.shape), tuple(dw.stride()), dw, dbias)))
+        _WGRAD_Q.append((j, keep))
         return dw
-    lib().octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
+    L = lib()
+    if int(L.octa_wgrad_job_class(ctypes.byref(j))) > 0:
+        # not deferrable (e.g. the gradient of a spectral-normalised weight is consumed right away) but wide enough for the
+        # 8-wave kernel: a batch of one, split over the whole chip (the 15-channel discriminator convs: 83 -> ~25 us)
+        arr = (WgradJob * 1)(j)
+        L.octa_conv2d_wgrad_batch(arr, 1, _st())
+        if _RECORD is not None:
+            _RECORD.append(("wgrad_batch", arr, 1, [keep]))
+        return dw
+    L.octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw
 
