@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--loss-scale", type=float, default=None, help="static loss scale (default 1; 1024 for f16)")
+    ap.add_argument("--loss-scale", default=None, help="static loss scale (default 1; 1024 for f16) or 'dynamic'")
     ap.add_argument("--seg-only", action="store_true", help="BASELINE configs[1]: segmentor-only (WPCE+Dice)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
@@ -266,7 +266,7 @@ def main():
     net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
     net_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
     cdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    ls = args.loss_scale if args.loss_scale is not None else (1024.0 if args.dtype == "f16" else 1.0)
+    ls = (1024.0 if args.dtype == "f16" else 1.0) if args.loss_scale is None else ("dynamic" if args.loss_scale == "dynamic" else float(args.loss_scale))
     step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only, loss_scale=ls)
     x, ys, real = synth_batch(B, H, rank, dev)
     batch = (x, ys, mask_pyramid(real))

@@ -405,7 +405,16 @@ int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx
  * from `step` on the host, so a captured hipGraph can be replayed with advancing bias corrections. */
 int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale,
-                   const float* dyn, octa_stream_t stream);
+                   const float* dyn, const float* ls_state /* optional */, int ls_flag, octa_stream_t stream);
+
+/* Dynamic loss scaling for fp16 training, all on the device (capturable, no host sync).  state (8 floats): [0] loss scale,
+ * [1] clean steps since the last change, [2..7] found-inf flags, one per optimiser.  octa_nonfinite_flag sets *flag = 1 if
+ * the (already all-reduced) gradient arena holds an inf / nan; octa_adam_step with ls_state divides its grad_scale by
+ * state[0] and does nothing when state[ls_flag] != 0; octa_loss_scale_update (once per step, after the optimisers) halves
+ * the scale on a flagged step (x backoff), multiplies it by `growth` after `interval` clean steps, and clears the flags. */
+int octa_nonfinite_flag(const float* g, int64_t n, float* flag, octa_stream_t stream);
+int octa_loss_scale_update(float* state, int nflags, float growth, float backoff, int interval,
+                           octa_stream_t stream);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);

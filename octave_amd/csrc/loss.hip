@@ -204,9 +204,10 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ b
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
 }
 __global__ void kl_final_kernel(const float* __restrict__ partial, int n, int64_t npix, float* __restrict__ out) {
+    double s = 0.0;                       // one wavefront: a single thread walking 1024 partials took 43 us
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+    s = wave_sum_d(s);
     if (threadIdx.x != 0) return;
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)partial[i];
     const float l = (float)(s / (double)npix);
     out[0] = l;
     out[1] = (l != l) ? 1.f : 0.f;

@@ -344,8 +344,12 @@ extern "C" int octa_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
 // ------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs,
-                                                   const float* __restrict__ dyn) {
+                                                   const float* __restrict__ dyn, const float* __restrict__ ls_state, int ls_flag) {
     if (dyn) { bc1 = dyn[0]; bc2s = dyn[1]; }     // bias corrections from device memory (hipGraph replay)
+    if (ls_state) {                               // dynamic loss scaling: the scale lives on the device, a flagged step is skipped
+        if (ls_state[ls_flag] != 0.f) return;
+        gs /= ls_state[0];
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gg = g[i] * gs;
         const float pp = p[i];
@@ -358,12 +362,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 extern "C" int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, int step, float grad_scale, const float* dyn, octa_stream_t stream) {
+                              float weight_decay, int step, float grad_scale, const float* dyn, const float* ls_state, int ls_flag,
+                              octa_stream_t stream) {
     OCTA_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || dyn), "octa_adam_step: bad arguments");
+    OCTA_REQUIRE(!ls_state || (ls_flag >= 2 && ls_flag < 8), "octa_adam_step: ls_flag indexes the found-inf slots 2..7 of the loss-scale state");
     if (step < 1) step = 1;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, dyn);
+    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, dyn, ls_state, ls_flag);
     OCTA_CHECK_LAUNCH("adam");
     return OCTA_OK;
 }
+
+// ------------------------------------------------------------------------------------------ dynamic loss scaling (fp16)
+// state[0] = loss scale, state[1] = clean steps since the last change, state[2..7] = "a non-finite gradient was found" flags
+// (one per optimiser).  Everything stays on the device, so the scheme is hipGraph-capturable and needs no host sync.
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned u = __float_as_uint(g[i]) & 0x7fffffffu;
+        bad |= u >= 0x7f800000u;                     // inf or nan
+    }
+    if (bad) *flag = 1.f;                            // benign race: every writer stores the same value
+}
+extern "C" int octa_nonfinite_flag(const float* g, int64_t n, float* flag, octa_stream_t stream) {
+    OCTA_REQUIRE(g && flag && n > 0, "octa_nonfinite_flag: bad arguments");
+    int64_t b = cdiv64(n, 256 * 8);
+    nonfinite_flag_kernel<<<(int)(b > 4096 ? 4096 : b), 256, 0, (hipStream_t)stream>>>(g, n, flag);
+    OCTA_CHECK_LAUNCH("nonfinite_flag");
+    return OCTA_OK;
+}
+__global__ void loss_scale_update_kernel(float* state, int nflags, float growth, float backoff, int interval) {
+    bool found = false;
+    for (int k = 0; k < nflags; ++k) { found |= state[2 + k] != 0.f; state[2 + k] = 0.f; }
+    if (found) { state[0] = fmaxf(state[0] * backoff, 1.f); state[1] = 0.f; }
+    else {
+        const float t = state[1] + 1.f;
+        if (t >= (float)interval) { state[0] = fminf(state[0] * growth, 16777216.f); state[1] = 0.f; }
+        else state[1] = t;
+    }
+}
+extern "C" int octa_loss_scale_update(float* state, int nflags, float growth, float backoff, int interval, octa_stream_t stream) {
+    OCTA_REQUIRE(state && nflags >= 1 && nflags <= 6 && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1, "octa_loss_scale_update: bad arguments");
+    loss_scale_update_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, nflags, growth, backoff, interval);
+    OCTA_CHECK_LAUNCH("loss_scale_update");
+    return OCTA_OK;
+}
+

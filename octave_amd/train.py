@@ -195,16 +195,20 @@ class FlatArena:
         F_.bump_weight_epoch()
 
     def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None,
-             ranges: Optional[List[Tuple[int, int]]] = None):
+             ranges: Optional[List[Tuple[int, int]]] = None, ls_state: Optional[Tensor] = None, ls_flag: int = 2):
         """One fused Adam launch over the arena (or one per element range in `ranges`).  `dyn` (device, 2 floats) carries the
         bias corrections when the launch is captured in a hipGraph; the caller then advances step_count / dyn itself."""
         if dyn is None:
             self.step_count += 1
         st = torch.cuda.current_stream().cuda_stream
+        if ls_state is not None:
+            # dynamic loss scaling: flag the arena (after the all-reduce: every rank sees the same infs) before the update
+            lib().octa_nonfinite_flag(self.g.data_ptr(), self.numel, ls_state.data_ptr() + 4 * ls_flag, st)
         for lo, hi in (ranges or [(0, self.numel)]):
             o = lo * 4
             lib().octa_adam_step(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, hi - lo, lr, betas[0],
-                                 betas[1], eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(), st)
+                                 betas[1], eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
+                                 None if ls_state is None else ls_state.data_ptr(), ls_flag, st)
         # one launch refreshes every cached packed conv operand of THIS network; nothing else went stale, so the global
         # weight epoch is left alone (bumping it here made the other network's operands look stale: ~170 redundant
         # per-weight pack launches were captured into every replayed step)
@@ -326,14 +330,26 @@ class TrainStep:
 
     def __init__(self, net: nn.Module, lr: float = 1e-4, lr_disc: Optional[float] = None, betas=(0.9, 0.999), compute_dtype=torch.bfloat16,
                  adversarial: bool = True, use_dice: bool = True, kl_weight: float = 0.1, adv_weight: float = 0.1,
-                 loss_scale: float = 1.0, grad_comm_dtype=None, extra_discriminators: Optional[Dict[int, nn.Module]] = None,
-                 overlap_backward: Optional[bool] = None):
+                 loss_scale=1.0, grad_comm_dtype=None, extra_discriminators: Optional[Dict[int, nn.Module]] = None,
+                 overlap_backward: Optional[bool] = None, loss_scale_growth: float = 2.0, loss_scale_backoff: float = 0.5,
+                 loss_scale_interval: int = 2000):
         self.net = net
         self.seg, self.disc = net.segmentor, getattr(net, "discriminator", None)
         self.adversarial = adversarial and self.disc is not None
         self.use_dice, self.kl_weight, self.adv_weight = use_dice, kl_weight, adv_weight
         self.lr, self.lr_disc, self.betas = lr, lr_disc or lr, betas
-        self.loss_scale = float(loss_scale)
+        # loss_scale: a float (static), or "dynamic" (fp16): the scale lives in device memory (8 floats, octa_hip.h), starts at
+        # 65536, is halved when an optimiser finds a non-finite gradient (that optimiser skips its update) and doubled after
+        # `loss_scale_interval` clean steps - all by kernels inside the step, so it survives hipGraph capture with no host sync
+        self.dynamic_scale = isinstance(loss_scale, str)
+        if self.dynamic_scale and loss_scale != "dynamic":
+            raise ValueError(f"loss_scale must be a number or 'dynamic', got {loss_scale!r}")
+        self.loss_scale = 1.0 if self.dynamic_scale else float(loss_scale)
+        self.ls_cfg = (float(loss_scale_growth), float(loss_scale_backoff), int(loss_scale_interval))
+        self.ls_state = None
+        if self.dynamic_scale:
+            self.ls_state = torch.zeros(8, dtype=torch.float32, device=next(net.parameters()).device)
+            self.ls_state[0] = 65536.0
         self.grad_comm_dtype = grad_comm_dtype
         self.seg.compute_dtype = compute_dtype
         self.discs: Dict[Optional[int], nn.Module] = {}
@@ -404,12 +420,16 @@ class TrainStep:
         sd = {"segmentor": self.seg_arena.state_dict()}
         if self.disc_arena is not None:
             sd["discriminator"] = self.disc_arena.state_dict()
+        if self.ls_state is not None:
+            sd["loss_scale_state"] = self.ls_state.detach().cpu().clone()
         return sd
 
     def load_state_dict(self, sd: Dict):
         self.seg_arena.load_state_dict(sd["segmentor"])
         if self.disc_arena is not None and "discriminator" in sd:
             self.disc_arena.load_state_dict(sd["discriminator"])
+        if self.ls_state is not None and "loss_scale_state" in sd:
+            self.ls_state.copy_(sd["loss_scale_state"])
 
     def _pick_disc(self, x: Tensor):
         if not self.adversarial:
@@ -450,7 +470,7 @@ class TrainStep:
         if hooks:
             F_.add_mark_hook(self._on_mark)
         try:
-            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+            self._scaled(loss).backward()
             F_.flush_wgrads()
         finally:
             if hooks:
@@ -471,19 +491,28 @@ class TrainStep:
             d_real = disc(real_pyramid)
             d_fake = disc(att)
             l_d = F_.lsgan_discriminator(d_real, d_fake)
-            (l_d * self.loss_scale if self.loss_scale != 1.0 else l_d).backward()
+            self._scaled(l_d).backward()
             F_.flush_wgrads()
             out["loss_disc"] = l_d.detach()
+
+    def _scaled(self, loss: Tensor) -> Tensor:
+        if self.dynamic_scale:
+            return loss * self.ls_state[0:1].reshape(())        # device scalar: the captured graph follows the scale
+        return loss * self.loss_scale if self.loss_scale != 1.0 else loss
 
     def _grad_scale(self) -> float:
         return 1.0 / (self.world * self.loss_scale)
 
     def _phase_seg_update(self, dyn=None):
-        self.seg_arena.adam(self.lr, self.betas, grad_scale=self._grad_scale(), dyn=dyn)
+        self.seg_arena.adam(self.lr, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ls_state=self.ls_state, ls_flag=2)
 
     def _phase_finish(self, disc, dyn=None):
         if self.adversarial:
-            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ranges=self._disc_ranges[id(disc)])
+            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ranges=self._disc_ranges[id(disc)],
+                                 ls_state=self.ls_state, ls_flag=3)
+        if self.dynamic_scale:
+            g, b, n = self.ls_cfg
+            lib().octa_loss_scale_update(F_._p(self.ls_state), 2 if self.adversarial else 1, g, b, n, F_._st())
         # last kernel of the step: publish "step n done" to pinned host memory (paces the replayed path, see __call__)
         lib().octa_host_tick(F_._p(self._tick.dev), F_._p(self._tick.host), F_._st())
         if not torch.cuda.is_current_stream_capturing():
@@ -628,10 +657,13 @@ class TrainStep:
                 if id(b) not in seen:
                     seen.add(id(b))
                     bufs.append((b, b.detach().clone()))
-        return ([(a, a.p.clone(), a.m.clone(), a.v.clone(), a.step_count) for a in arenas], bufs, torch.get_rng_state())
+        ls = None if self.ls_state is None else self.ls_state.clone()
+        return ([(a, a.p.clone(), a.m.clone(), a.v.clone(), a.step_count) for a in arenas], bufs, torch.get_rng_state(), ls)
 
     def _restore(self, snap):
-        arenas, bufs, rng = snap
+        arenas, bufs, rng, ls = snap
+        if ls is not None:
+            self.ls_state.copy_(ls)
         with torch.no_grad():
             for a, p, m, v, sc in arenas:
                 a.p.copy_(p); a.m.copy_(m); a.v.copy_(v)
@@ -664,6 +696,12 @@ class TrainStep:
                 torch.cuda.synchronize()
                 t[mode].append((time.perf_counter() - t0) / steps)
         med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
+        if _dist_on(self.world):
+            # every rank takes the same decision (the slowest rank's timings): the two paths issue the same collectives in the
+            # same order, but a job is easier to reason about when all ranks launch the same way
+            tt = torch.tensor([med["graph"], med["eager"]], dtype=torch.float64, device=x.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            med = {"graph": float(tt[0]), "eager": float(tt[1])}
         # Prefer the replayed path unless eager launches are clearly faster: a replay costs the host < 2 ms per step, Python
         # launches ~30 ms - right at the device time, so they are the first to suffer on a busy host.  (Replays used to
         # stall for ~3 step times at a stretch; the cause was on the CPU side - OpenMP workers spinning after a parallel

@@ -535,3 +535,55 @@ def test_baseline_size_bf16_vs_fp32_hip(H):
     assert agree > 0.98
     if d32.shape == d16.shape:
         assert (d32.mean() - d16.mean()).abs().item() <= 1e-3 + 0.02 * (1 - agree)
+
+
+def test_dynamic_loss_scale_fp16_skips_and_backs_off():
+    """TrainStep(loss_scale="dynamic") in fp16: the scale lives on the device; a step whose gradients overflow is skipped by both
+    optimisers (parameters bit-identical) and halves the scale, clean steps count up and double it after the interval; the
+    state survives a captured-graph replay and a state_dict round trip."""
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, H = 2, 64
+    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.float16, loss_scale="dynamic", loss_scale_interval=3)
+    x = torch.rand(B, 3, H, H, device=dev)
+    ys = (torch.rand(B, 2, H, H, device=dev) > 0.7).float()
+    pyr = mask_pyramid((torch.rand(B, 2, H, H, device=dev) > 0.5).float())
+    assert float(st.ls_state[0]) == 65536.0
+    # 1) force an overflow: with a scale of 2^24 * 64 the fp16 gradients are inf
+    st.ls_state[0] = 2.0 ** 30
+    before = [p.detach().clone() for p in net.parameters()]
+    out = st(x, ys, pyr)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss_seg"]).all()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters())), "an overflowed step must not move the weights"
+    assert float(st.ls_state[0]) == 2.0 ** 29 and float(st.ls_state[1]) == 0.0 and float(st.ls_state[2:4].abs().sum()) == 0.0
+    # 2) clean steps at a sane scale: weights move, the tracker counts, the third clean step doubles the scale
+    st.ls_state[0] = 1024.0
+    out = st(x, ys, pyr)
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+    assert float(st.ls_state[0]) == 1024.0 and float(st.ls_state[1]) == 1.0
+    st(x, ys, pyr); st(x, ys, pyr)
+    torch.cuda.synchronize()
+    assert float(st.ls_state[0]) == 2048.0 and float(st.ls_state[1]) == 0.0
+    for p in net.parameters():
+        assert torch.isfinite(p).all()
+    # 3) captured graphs follow the device-side scale; the checkpoint carries it
+    st.capture(x, ys, pyr)
+    st.launch = "graph"
+    st.ls_state[0] = 2.0 ** 30
+    snap = [p.detach().clone() for p in net.parameters()]
+    st(x, ys, pyr)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
+    assert float(st.ls_state[0]) == 2.0 ** 29
+    sd = st.state_dict()
+    assert float(sd["loss_scale_state"][0]) == 2.0 ** 29
+    st.ls_state[0] = 1.0
+    st.load_state_dict(sd)
+    assert float(st.ls_state[0]) == 2.0 ** 29
+    st.close()
+
