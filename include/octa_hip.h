@@ -61,7 +61,8 @@ typedef struct octa_conv_desc {
     int32_t algo;          /* fwd / dgrad kernel choice: 0 = library heuristic, 1 = 4-wave kernels (3x3 halo
                               / generic tiles), 2 / 3 = 8-wave LDS-DMA kernel with 256x128 / 128x256
                               (pixels x channels) output slabs, 4 / 5 / 6 = generic 4-wave kernel with 128x128 /
-                              64x64 / 128x64 tiles, 7 = resident-weight persistent kernel (Cin/group 32 or 64,
+                              64x64 / 128x64 tiles, 8 = the LDS-DMA kernel as a 4-wave 128x128 slab (two workgroups
+                              per CU), 7 = resident-weight persistent kernel (Cin/group 32 or 64,
                               <= 256 (1x1) / 64 (3x3 s1 p1) output channels).  A choice the shape does not allow falls back to the
                               heuristic.  Results are identical up to fp32 summation order.            */
     int32_t zero_pad;      /* 1 (groups == 1, no upshuffle): the kernel also stores zeros into the output's

@@ -695,6 +695,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             if (gf >= thr && a.Cg % 64 == 0) want = (a.Ng >= 256) ? 3 : 2;
         }
         if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
+        if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }     // 4-wave 128x128 slab
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
         if ((want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }

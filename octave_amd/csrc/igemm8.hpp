@@ -41,14 +41,19 @@ template <> struct Mma8<bf16_t> {
 };
 
 // MODE 0: forward gather (any stride); 1: data-gradient gather, stride 1
+// WM x WN waves of 64 x 64: 4 x 2 / 2 x 4 (8 waves, one workgroup per CU, 3-stage ring) or 2 x 2 (4 waves, 128 x 128 slab,
+// 2-stage ring = 64 KB so that TWO workgroups share a CU: the mid-size layers - 25x25 / 50x50 1x1 convs, grouped 3x3 - have
+// too few 256-wide slabs for 256 CUs and were left to the generic 64x64 kernel, whose loop is address arithmetic around 4 MFMAs)
 template <typename T, int WM, int WN, int MODE>
-__global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArgs a) {
     constexpr int EPC = 8;
-    constexpr int BM = WM * 64, BN = WN * 64, KP = 8, STAGES = 3;
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * 64, BN = WN * 64, KP = 8, STAGES = NW == 8 ? 3 : 2, PF = STAGES - 1;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SBYTES = A_BYTES + B_BYTES;
-    constexpr int A_IPW = BM / 64, B_IPW = BN / 64;        // DMA instructions per wave and stage (8 rows each)
+    constexpr int RPR = NW * 8;                            // rows one round of DMA instructions (one per wave) covers
+    constexpr int A_IPW = BM / RPR, B_IPW = BN / RPR;      // DMA instructions per wave and stage (8 rows each)
     constexpr int LPT = A_IPW + B_IPW;
-    static_assert(WM * WN == 8 && LPT == 6, "8 waves of 64x64");
+    static_assert(NW == 8 || NW == 4, "8 or 4 waves of 64x64");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SBYTES];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -61,8 +66,8 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
     const int Kc = a.Kc, CgC = a.Cg / EPC, KW = a.KW, Wimg = a.W, ldx = a.ldx;
     const unsigned long zaddr = (unsigned long)(const void*)octa_zero_page;
 
-    // ---- DMA roles.  Instruction j of this wave fills lines 4 (wave + 8 j) .. + 3 of the stage image: lane l writes slot
-    // l & 15 of line Lc + 32 j, i.e. row rowc + 64 j, chunk (l & 7) ^ (Lc & 7) -- row offset and chunk are lane constants.
+    // ---- DMA roles.  Instruction j of this wave fills lines 4 (wave + NW j) .. + 3 of the stage image: lane l writes slot
+    // l & 15 of line Lc + 4 NW j, i.e. row rowc + RPR j, chunk (l & 7) ^ (Lc & 7) -- row offset and chunk are lane constants.
     const int Lc = 4 * wave + (lane >> 4);
     const int rowc = (Lc & 7) + 8 * ((lane >> 3) & 1) + 16 * (Lc >> 3);
     const int chunk = (lane & 7) ^ (Lc & 7);
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
     unsigned rmask[A_IPW];
 #pragma unroll
     for (int j = 0; j < A_IPW; ++j) {
-        const int m = m0 + rowc + 64 * j;
+        const int m = m0 + rowc + RPR * j;
         const bool rvalid = m < a.M;
         const int mm = rvalid ? m : 0;
         const int ow = mm % a.OW;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
     unsigned long wstep[B_IPW];
 #pragma unroll
     for (int j = 0; j < B_IPW; ++j) {
-        const int n = n0 + rowc + 64 * j;
+        const int n = n0 + rowc + RPR * j;
         const bool wvalid = n < a.Ng;
         wptr[j] = wvalid ? (unsigned long)((const T*)a.w + ((size_t)g * a.Ng + n) * Kelem + (size_t)chunk * EPC) : zaddr;
         wstep[j] = wvalid ? 128ul : 0ul;
@@ -122,12 +127,12 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
         for (int j = 0; j < A_IPW; ++j) {
             const bool ok = (rmask[j] & tbit) != 0;
             const unsigned long src = ok ? (abase[j] + soff) : zaddr;
-            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(ab + (unsigned)((wave + 8 * j) * 1024)));
+            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(ab + (unsigned)((wave + NW * j) * 1024)));
         }
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
             const unsigned long src = kin ? wptr[j] : zaddr;
-            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(bb + (unsigned)((wave + 8 * j) * 1024)));
+            glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(bb + (unsigned)((wave + NW * j) * 1024)));
             wptr[j] += wstep[j];
         }
         // advance by one K step (8 chunks); CgC >= 8 (checked by the launcher): at most one tap wrap
@@ -156,14 +161,15 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
     const unsigned bfrag0 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((0 + q) ^ (r & 7)) << 4));
     const unsigned bfrag1 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((4 + q) ^ (r & 7)) << 4));
     const int nk = (Kc + KP - 1) / KP;
-    const bool late = wave >= 4;
+    const bool late = wave >= NW / 2;
     issue(0);
-    if (nk > 1) issue(1);
+    if (PF > 1 && nk > 1) issue(1);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        // stage kt has landed once only the younger stages (PF - 1 of them, none in the 2-stage ring) are outstanding
+        if (PF > 1 && kt + 1 < nk) wait_vmcnt<(PF - 1) * LPT>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!late && kt + 2 < nk) issue((kt + 2) % STAGES);
+        if (!late && kt + PF < nk) issue((kt + PF) % STAGES);
         const unsigned so = (unsigned)((kt % STAGES) * SBYTES);
         {
             ig8_u32x4_t xf0[4], wf0[4], xf1[4], wf1[4];
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Mma8<T>::run(wf1[i], xf1[j], acc[i][j]);
         }
-        if (late && kt + 2 < nk) issue((kt + 2) % STAGES);
+        if (late && kt + PF < nk) issue((kt + PF) % STAGES);
     }
 
     // epilogue: lane holds, per (tn, tm), 4 consecutive output channels (rows of D) of pixel column r
@@ -222,14 +228,20 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(const ConvArgs a) {
     }
 }
 
-// eligibility + launch; variant 0: 256(M) x 128(N), 1: 128(M) x 256(N).  Returns false when the legacy kernels must run.
+// eligibility + launch; variant 0: 256(M) x 128(N), 1: 128(M) x 256(N), 2: 128 x 128 with 4 waves.  Returns false when the
+// legacy kernels must run.
 template <typename T>
 static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_t st) {
     if (a.KH * a.KW > 32) return false;
     if (a.mode == 1 && a.stride != 1) return false;
     if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 30)) return false;
     if (a.Cg % 64 != 0) return false;                     // whole 128-byte lines per tap: at most one tap wrap per K step
-    if (variant == 0) {
+    if (variant == 2) {
+        dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
+        if (a.mode == 0) conv_igemm8_kernel<T, 2, 2, 0><<<grid, 256, 0, st>>>(a);
+        else conv_igemm8_kernel<T, 2, 2, 1><<<grid, 256, 0, st>>>(a);
+        note_kernel<T>("conv_igemm8_kernel", 128, 128);
+    } else if (variant == 0) {
         dim3 grid(cdiv(a.M, 256), cdiv(a.Ng, 128), groups);
         if (a.mode == 0) conv_igemm8_kernel<T, 4, 2, 0><<<grid, 512, 0, st>>>(a);
         else conv_igemm8_kernel<T, 4, 2, 1><<<grid, 512, 0, st>>>(a);

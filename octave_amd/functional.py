@@ -417,7 +417,7 @@ def _choose_algo(kind: str, d, launch) -> int:
     cg = d.cin_g_pad if kind == "fwd" else d.cout_g_pad
     cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
     if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
-        cands += [2, 3]             # 8-wave LDS-DMA kernel, both slab orientations
+        cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
     if cg in (32, 64) and d.groups == 1 and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
     best, best_t = 1, None

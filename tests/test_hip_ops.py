@@ -464,7 +464,7 @@ IGEMM8_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("algo", [2, 3])
+@pytest.mark.parametrize("algo", [2, 3, 8])
 @pytest.mark.parametrize("case", IGEMM8_CASES)
 def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     """The 8-wave LDS-DMA kernel (octa_conv_desc.algo 2 / 3) on awkward shapes against torch's CPU conv on the same rounded

@@ -61,7 +61,7 @@ def run(name):
     line = f"{name:11s}"
     for kind in ("fwd", "dgrad"):
         res = {}
-        for algo in (1, 2, 3):
+        for algo in (1, 5, 2, 3, 8):
             F_._ALGO_OVERRIDE = algo
             fn = (lambda: F_.raw_conv_fwd(x, w, bias, s, p, g, 1)) if kind == "fwd" else (lambda: F_.raw_conv_dgrad(dy, w, tuple(x.shape), s, p, g))
             out = fn()
