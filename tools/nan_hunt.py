@@ -63,8 +63,8 @@ if args.asyn:
                 if step.disc_arena is not None:
                     h["F_dp"], h["F_dg"], h["F_dm"], h["F_dv"] = fin(step.disc_arena.p), fin(step.disc_arena.g), fin(step.disc_arena.m), fin(step.disc_arena.v)
                     h["vmin_d"] = step.disc_arena.v.min()
-                    h["noise_absmax"] = step._feed.noise_dev.abs().max()
-                    h["sign0"], h["sign1"], h["sign2"] = step._feed.sign_dev[0].clone(), step._feed.sign_dev[1].clone(), step._feed.sign_dev[2].clone()
+                    h["noise_absmax"] = step._caps[H].feed.noise_dev.abs().max()
+                    h["sign0"], h["sign1"], h["sign2"] = step._caps[H].feed.sign_dev[0].clone(), step._caps[H].feed.sign_dev[1].clone(), step._caps[H].feed.sign_dev[2].clone()
                     h["dynD0"], h["dynD1"] = step._dyn_dev[1][0].clone(), step._dyn_dev[1][1].clone()
                     for j, a in enumerate(step._att):
                         h[f"F_att{j}"] = fin(a)
