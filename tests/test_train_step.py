@@ -239,7 +239,7 @@ def test_train_step_hipgraph_back_to_back_replays_stay_finite():
     of the graphs must stay ordered.  Regression test: hipMemsetAsync calls captured as memset NODES lost their order
     against the neighbouring kernel nodes in exactly this mode (accumulators cleared after the atomics that fill them;
     spectral-norm v = 0 -> 0/0 -> non-finite discriminator within a few steps).  The library now zero-fills with
-    kernels (csrc/common.hpp: octa_zero_async); tools/nan_hunt.py is the step-by-step diagnostic."""
+    kernels (csrc/common.hpp: octa_zero_async); tools/long_run.py replays hundreds of steps and checks parameter health."""
     from architectures.models.octa import OctaScribbleNet
     from octave_amd.train import TrainStep, mask_pyramid
     dev = torch.device("cuda:0")
