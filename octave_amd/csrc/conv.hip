@@ -90,7 +90,10 @@ __device__ __forceinline__ void bias_act_tile(V4 (&acc)[TN][TM], const ConvArgs&
     act_tile(acc, a.act);
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+// PW: pointwise fast path (1x1, stride 1, no padding - three of the four convs of every bottleneck): the gathered pixel IS the
+// output pixel, so the per-K-step tap decode, bounds tests and 64-bit address rebuild of the general loader collapse into
+// one running pointer per row (the general loop spends ~100 instructions around its 4 MFMAs).
+template <typename T, int WM, int WN, int TM, int TN, bool PW = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -127,6 +130,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (a.mode == 0) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
         else { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
     }
+    const T* arow[A_CH];                 // PW: running pointer of the row's current 16-byte chunk
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) arow[i] = xg + (size_t)(rv[i] ? m0 + trow + i * 64 : 0) * a.ldx + kc * EPC;
     const T* wrow[B_CH];
     bool wv[B_CH];
 #pragma unroll
@@ -147,7 +153,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (rv[i] && kvalid) {
+            if constexpr (PW) {
+                if (rv[i] && kvalid) v = *(const uint4*)arow[i];
+            } else if (rv[i] && kvalid) {
                 int ih, iw;
                 bool ok;
                 if (a.mode == 0) {
@@ -171,8 +179,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     auto advance = [&]() {
-        kcg += 4; cc += 4;
-        while (cc >= CgC) { cc -= CgC; if (++kw == a.KW) { kw = 0; ++kh; } }
+        kcg += 4;
+        if constexpr (PW) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) arow[i] += 4 * EPC;
+        } else {
+            cc += 4;
+            while (cc >= CgC) { cc -= CgC; if (++kw == a.KW) { kw = 0; ++kh; } }
+        }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -683,6 +697,7 @@ static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
 template <typename T>
 static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo = 0) {
     dim3 block(256);
+    const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW;
     if constexpr (sizeof(T) == 2) {
         static const int force8 = getenv("OCTA_IGEMM8") ? atoi(getenv("OCTA_IGEMM8")) : 0;
         int want = algo;
@@ -702,9 +717,17 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
     }
     // explicit 4-wave tile choices (measured per shape by the training step's autotuner): 4 = 128x128, 5 = 64x64, 6 = 128x64
     if (algo >= 4 && algo <= 6) {
-        if (algo == 4) { conv_igemm_kernel<T, 2, 2, 4, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 128), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 128); }
-        else if (algo == 5) { conv_igemm_kernel<T, 2, 2, 2, 2><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 64, 64); }
-        else { conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 64); }
+        if (algo == 4) {
+            if (pw) conv_igemm_kernel<T, 2, 2, 4, 4, true><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 128), groups), block, 0, st>>>(a);
+            else conv_igemm_kernel<T, 2, 2, 4, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 128), groups), block, 0, st>>>(a);
+            note_kernel<T>("conv_igemm_kernel", 128, 128);
+        }
+        else if (algo == 5) {
+            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a);
+            else conv_igemm_kernel<T, 2, 2, 2, 2><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a);
+            note_kernel<T>("conv_igemm_kernel", 64, 64);
+        }
+        else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
         OCTA_CHECK_LAUNCH("conv_igemm");
         return OCTA_OK;
     }
@@ -726,23 +749,24 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             // also: too few 128x128 tiles to fill 256 CUs twice (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
             // (threshold swept 320 / 520 / 800 / 1300: 520 best)
             dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
-            conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
+            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true><<<g64, block, 0, st>>>(a);
+            else conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
             note_kernel<T>("conv_igemm_kernel", 64, 64);
         } else if (dma) { launch_dma<T, 2, 2, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 128, 128); }
-        else { conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 128); }
+        else { { if (pw) conv_igemm_kernel<T, 2, 2, 4, 4, true><<<grid, block, 0, st>>>(a); else conv_igemm_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 128); }
     } else {
         // Ng <= 64: 128-row tiles (4-5 waves per SIMD instead of 3: measured faster than the 256-row tiles on every launch of
         // the step, -0.4 ms/step); the LDS-DMA variant keeps its 256-row shapes
         dim3 grid(cdiv(a.M, 256), 1, groups), g128(cdiv(a.M, 128), 1, groups);
         if (a.Ng > 32) {
             if (dma) { launch_dma<T, 4, 1, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 64); }
-            else { conv_igemm_kernel<T, 4, 1, 2, 4><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 64); }
+            else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
         } else if (a.Ng > 16) {
             if (dma) { launch_dma<T, 4, 1, 4, 2>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 32); }
-            else { conv_igemm_kernel<T, 4, 1, 2, 2><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 32); }
+            else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 2, true><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 2><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 32); }
         } else {
             if (dma) { launch_dma<T, 4, 1, 4, 1>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 16); }
-            else { conv_igemm_kernel<T, 4, 1, 2, 1><<<g128, block, 0, st>>>(a); note_kernel<T>("conv_igemm_kernel", 128, 16); }
+            else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 1, true><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 1><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 16); }
         }
     }
     OCTA_CHECK_LAUNCH("conv_igemm");
