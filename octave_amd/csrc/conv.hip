@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                     else { ih = th / a.stride; iw = tw / a.stride; ok = (th >= 0) && (tw >= 0) && (ih * a.stride == th) && (iw * a.stride == tw); }
                     ok = ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
                 }
-                if (ok) v = *(const uint4*)(xg + ((size_t)(rb[i] * a.H + ih) * a.W + iw) * a.ldx + cc * EPC);
+                // 32-bit pixel index, ONE 64-bit multiply-add (check_desc bounds B*H*W to 2^31)
+                if (ok) v = *(const uint4*)(xg + (int64_t)((rb[i] * a.H + ih) * a.W + iw) * a.ldx + cc * EPC);
             }
             ra[i] = v;
         }
@@ -713,7 +714,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }     // 4-wave 128x128 slab
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
-        if ((want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
+        if ((want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
     }
     // explicit 4-wave tile choices (measured per shape by the training step's autotuner): 4 = 128x128, 5 = 64x64, 6 = 128x64
     if (algo >= 4 && algo <= 6) {

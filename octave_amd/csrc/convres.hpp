@@ -364,7 +364,7 @@ static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int ex
 
 // eligibility + launch.  Returns false when another kernel must run.
 template <typename T>
-static bool launch_res(const ConvArgs& a, int groups, hipStream_t st) {
+static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool forced = true) {
     if constexpr (sizeof(T) != 2) return false;
     else {
         if (groups != 1 || (a.Cg != 32 && a.Cg != 64)) return false;
@@ -383,6 +383,7 @@ static bool launch_res(const ConvArgs& a, int groups, hipStream_t st) {
         } else {
             tn = need <= 16 ? 1 : need <= 32 ? 2 : need <= 64 ? 4 : 16;
             if (need > 256 || (nch == 1 && (tn == 1 || tn == 16))) return false;
+            if (tn == 16 && !forced) return false;      // 128 accumulator registers per lane: spills; only when asked for (autotune)
         }
         const int exact = a.vec16 && a.Ng == tn * 16 && a.NgSt == a.Ng;
         int ntiles, tx = 0, ty = 0;
