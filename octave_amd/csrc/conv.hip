@@ -93,15 +93,19 @@ __device__ __forceinline__ void bias_act_tile(V4 (&acc)[TN][TM], const ConvArgs&
 // PW: pointwise fast path (1x1, stride 1, no padding - three of the four convs of every bottleneck): the gathered pixel IS the
 // output pixel, so the per-K-step tap decode, bounds tests and 64-bit address rebuild of the general loader collapse into
 // one running pointer per row (the general loop spends ~100 instructions around its 4 MFMAs).
-template <typename T, int WM, int WN, int TM, int TN, bool PW = false>
+// KS: 16-byte chunks of K per stage (4 = one MFMA k-step; 8 = two per barrier, pointwise 16-bit instantiations only)
+template <typename T, int WM, int WN, int TM, int TN, bool PW = false, int KS = 4>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int A_CH = BM / 64;
-    constexpr int B_CH = (BN + 63) / 64;
+    constexpr int RPP = 256 / KS;                      // rows one pass of the 256 threads covers
+    constexpr int A_CH = BM / RPP;
+    constexpr int B_CH = (BN + RPP - 1) / RPP;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ uint4 sA[2][BM * 4];
-    __shared__ uint4 sB[2][BN * 4];
+    static_assert(KS == 4 || (KS == 8 && PW && sizeof(T) == 2), "8-chunk stages: pointwise 16-bit kernels only");
+    __shared__ uint4 sA[2][BM * KS];
+    __shared__ uint4 sB[2][BN * KS];
+    auto slot = [](int row, int c) { return KS == 4 ? (c ^ swz(row)) : (c ^ (row & 7)); };
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -113,14 +117,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const size_t Kelem = (size_t)a.Kc * EPC;
     const T* __restrict__ wg = (const T*)a.w + (size_t)g * a.Ng * Kelem;
     const int CgC = a.Cg / EPC;
-    const int kc = t & 3;
-    const int trow = t >> 2;
+    const int kc = t & (KS - 1);
+    const int trow = t / KS;
 
     int rb[A_CH], rh[A_CH], rw[A_CH];
     bool rv[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int m = m0 + trow + i * 64;
+        const int m = m0 + trow + i * RPP;
         rv[i] = m < a.M;
         const int mm = rv[i] ? m : 0;
         const int ow = mm % a.OW;
@@ -132,12 +136,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     const T* arow[A_CH];                 // PW: running pointer of the row's current 16-byte chunk
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) arow[i] = xg + (size_t)(rv[i] ? m0 + trow + i * 64 : 0) * a.ldx + kc * EPC;
+    for (int i = 0; i < A_CH; ++i) arow[i] = xg + (size_t)(rv[i] ? m0 + trow + i * RPP : 0) * a.ldx + kc * EPC;
     const T* wrow[B_CH];
     bool wv[B_CH];
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
-        const int nr = trow + j * 64;
+        const int nr = trow + j * RPP;
         const int n = n0 + nr;
         wv[j] = (nr < BN) && (n < a.Ng);
         wrow[j] = wg + (size_t)(wv[j] ? n : 0) * Kelem;
@@ -180,10 +184,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     auto advance = [&]() {
-        kcg += 4;
+        kcg += KS;
         if constexpr (PW) {
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) arow[i] += 4 * EPC;
+            for (int i = 0; i < A_CH; ++i) arow[i] += KS * EPC;
         } else {
             cc += 4;
             while (cc >= CgC) { cc -= CgC; if (++kw == a.KW) { kw = 0; ++kh; } }
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) { const int row = trow + i * 64; sA[buf][row * 4 + (kc ^ swz(row))] = ra[i]; }
+        for (int i = 0; i < A_CH; ++i) { const int row = trow + i * RPP; sA[buf][row * KS + slot(row, kc)] = ra[i]; }
 #pragma unroll
-        for (int j = 0; j < B_CH; ++j) { const int row = trow + j * 64; if (row < BN) sB[buf][row * 4 + (kc ^ swz(row))] = rbv[j]; }
+        for (int j = 0; j < B_CH; ++j) { const int row = trow + j * RPP; if (row < BN) sB[buf][row * KS + slot(row, kc)] = rbv[j]; }
     };
 
     f32x4_t acc[TN][TM];
@@ -203,22 +207,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int r = lane & 15, q = lane >> 4;
-    const int nk = (a.Kc + 3) >> 2;
+    const int nk = (a.Kc + KS - 1) / KS;
     load_tile();
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { advance(); load_tile(); }
-        uint4 xf[TM], wf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { const int row = (wm * TM + i) * 16 + r; xf[i] = sA[buf][row * 4 + (q ^ swz(row))]; }
+        for (int ks = 0; ks < KS / 4; ++ks) {
+            uint4 xf[TM], wf[TN];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) { const int row = (wn * TN + i) * 16 + r; wf[i] = sB[buf][row * 4 + (q ^ swz(row))]; }
+            for (int i = 0; i < TM; ++i) { const int row = (wm * TM + i) * 16 + r; xf[i] = sA[buf][row * KS + slot(row, ks * 4 + q)]; }
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i) { const int row = (wn * TN + i) * 16 + r; wf[i] = sB[buf][row * KS + slot(row, ks * 4 + q)]; }
 #pragma unroll
-            for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
@@ -724,11 +731,11 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             note_kernel<T>("conv_igemm_kernel", 128, 128);
         }
         else if (algo == 5) {
-            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a);
+            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true, (sizeof(T) == 2 ? 8 : 4)><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a);
             else conv_igemm_kernel<T, 2, 2, 2, 2><<<dim3(cdiv(a.M, 64), cdiv(a.Ng, 64), groups), block, 0, st>>>(a);
             note_kernel<T>("conv_igemm_kernel", 64, 64);
         }
-        else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
+        else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true, (sizeof(T) == 2 ? 8 : 4)><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
         OCTA_CHECK_LAUNCH("conv_igemm");
         return OCTA_OK;
     }
@@ -750,7 +757,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             // also: too few 128x128 tiles to fill 256 CUs twice (13x13 / 25x25 stages): quarter-size tiles, 4x the workgroups
             // (threshold swept 320 / 520 / 800 / 1300: 520 best)
             dim3 g64(cdiv(a.M, 64), cdiv(a.Ng, 64), groups);
-            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true><<<g64, block, 0, st>>>(a);
+            if (pw) conv_igemm_kernel<T, 2, 2, 2, 2, true, (sizeof(T) == 2 ? 8 : 4)><<<g64, block, 0, st>>>(a);
             else conv_igemm_kernel<T, 2, 2, 2, 2><<<g64, block, 0, st>>>(a);
             note_kernel<T>("conv_igemm_kernel", 64, 64);
         } else if (dma) { launch_dma<T, 2, 2, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 128, 128); }
@@ -761,7 +768,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         dim3 grid(cdiv(a.M, 256), 1, groups), g128(cdiv(a.M, 128), 1, groups);
         if (a.Ng > 32) {
             if (dma) { launch_dma<T, 4, 1, 4, 4>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 64); }
-            else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
+            else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true, (sizeof(T) == 2 ? 8 : 4)><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
         } else if (a.Ng > 16) {
             if (dma) { launch_dma<T, 4, 1, 4, 2>(a, grid, st); note_kernel<T>("conv_igemm_dma_kernel", 256, 32); }
             else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 2, true><<<g128, block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 2><<<g128, block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 32); }
