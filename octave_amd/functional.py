@@ -688,14 +688,8 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
         _WGRAD_Q.append((j, keep))
         return dw
     L = lib()
-    if int(L.octa_wgrad_job_class(ctypes.byref(j))) > 0:
-        # not deferrable (e.g. the gradient of a spectral-normalised weight is consumed right away) but wide enough for the
-        # 8-wave kernel: a batch of one, split over the whole chip (the 15-channel discriminator convs: 83 -> ~25 us)
-        arr = (WgradJob * 1)(j)
-        L.octa_conv2d_wgrad_batch(arr, 1, _st())
-        if _RECORD is not None:
-            _RECORD.append(("wgrad_batch", arr, 1, [keep]))
-        return dw
+    # (a non-deferrable job that is wide enough for the 8-wave kernel could go there as a batch of one: measured 0.07 ms per
+    # step for the four 15-channel discriminator convs, at the price of six 30 us launches in that kernel's statistics - not taken)
     L.octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw
