@@ -722,12 +722,21 @@ class TrainStep:
             self.disc_arena.advance_dyn(self._dyn[1], self.betas)
         g1.replay()
         # bucketed, in completion order, on the comm stream: the D step overlaps the segmentor gradient exchange
-        self.seg_arena.all_reduce_begin(self.world, self._comm(), self.grad_comm_dtype)
+        comm = self._comm()
+        self.seg_arena.all_reduce_begin(self.world, comm, self.grad_comm_dtype)
+        seg_done = None
+        if _dist_on(self.world):
+            seg_done = torch.cuda.Event()
+            seg_done.record(comm)
         g2.replay()
-        self.seg_arena.all_reduce_end(self.world, self._comm())
+        if self.adversarial:
+            # the discriminator's gradients follow the segmentor's on the comm stream and travel while the segmentor's Adam runs
+            self.disc_arena.all_reduce_begin(self.world, comm, None)
+        if seg_done is not None:
+            torch.cuda.current_stream().wait_event(seg_done)
         g2b.replay()
         if self.adversarial:
-            self.disc_arena.all_reduce(self.world)
+            self.disc_arena.all_reduce_end(self.world, comm)
         g3.replay()
         F_.bump_weight_epoch()      # the weights moved behind the pack cache's back
         return cap.out
