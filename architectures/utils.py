@@ -20,4 +20,9 @@ def rand_uniform(x: Optional[Tensor] = None):
     """One U[0,1) draw from the global CPU generator, as reference utils.py:20-22 (the order in
     which the CPU generator is consumed is part of the parity contract)."""
     rand = torch.FloatTensor(1).uniform_(0, 1)
+    # the reference ends with `.type_as(x)`.  For a CPU `x` that is reproduced; for a device tensor the draw stays on the host:
+    # its only use is a Python-side comparison (`rand < prob`), and shipping it to the device just to read it back costs a
+    # host-device round trip per discriminator call
+    if x is not None and not x.is_cuda:
+        rand = rand.type_as(x)
     return rand
