@@ -7,6 +7,7 @@ names and state_dict keys.  The unreachable options of the reference (DropBlock,
 radix 1, dilation) raise NotImplementedError instead of being reproduced.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -16,6 +17,8 @@ from octave_amd import functional as F_
 from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_counter, conv_bn
 
 BN_MOMENTUM = 0.1
+_FUSE_FANOUT = os.environ.get("OCTA_FUSE_FANOUT", "1") != "0"     # Bottleneck: shortcut gradient added in conv1's data-gradient epilogue
+_FUSE_FANOUT_DEC = os.environ.get("OCTA_FUSE_FANOUT_DEC", "1") != "0"     # ResNestDecoder: 3x3 gradient added in the shortcut conv's data gradient
 
 
 class SplAtConv2d(nn.Module):
@@ -89,11 +92,15 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        # x feeds conv1 AND the shortcut: the shortcut's gradient is parked in `h` and conv1's data gradient adds it in its
+        # epilogue (one read) instead of autograd summing the two in a separate kernel (three passes over the tensor)
+        h = F_.GradHolder() if (_FUSE_FANOUT and torch.is_grad_enabled() and x.requires_grad) else None
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, grad_holder=h)
         out = self.conv2(out)
         if self.avd:
             out = F_.avg_pool(out, 3, self.avd_stride, 1)
-        residual = self.downsample(x) if self.downsample is not None else x
+        xs = F_.stash_grad(x, h) if h is not None else x
+        residual = self.downsample(xs) if self.downsample is not None else xs
         return conv_bn(self.conv3, self.bn3, out, relu=True, residual=residual)
 
 
@@ -211,6 +218,14 @@ class ResNestDecoder(nn.Module):
 
     def forward(self, x):
         c = self.conv
+        if _FUSE_FANOUT_DEC and self.training and torch.is_grad_enabled() and x.requires_grad:
+            # x feeds the 3x3 AND the 1x1 shortcut conv.  The 1x1 runs first here, so its backward runs last and its data
+            # gradient adds the 3x3's (parked by stash_grad) in its epilogue: no separate gradient-sum kernel
+            h = F_.GradHolder()
+            ds = self.downsample[0](x, h)
+            out = conv_bn(c[0], c[1], F_.stash_grad(x, h), relu=True)
+            out = c[3](out, relu_after=True)
+            return self.downsample[1](ds, relu=True, residual=out)
         out = conv_bn(c[0], c[1], x, relu=True)
         out = c[3](out, relu_after=True)
         # residual branch: BN(1x1(x)) + out, then ReLU -- one fused BatchNorm-apply (training) / folded conv + add (inference)

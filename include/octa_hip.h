@@ -109,6 +109,11 @@ int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed
 /* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
 int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
                       octa_stream_t stream);
+/* Same, with dx = conv^T(dy, w) + addend: `addend` has dx's shape and dtype, per-pixel stride ldadd.  The sum a network's
+ * fan-out needs (a bottleneck's input feeds conv1 AND the shortcut) then costs one extra read in this epilogue instead of a
+ * separate 3-pass add kernel.  Runs on the generic and LDS-DMA kernels (not the 3x3 halo / resident-weight ones). */
+int octa_conv2d_dgrad_add(const octa_conv_desc* d, const void* dy, const void* w_packed_t,
+                          const void* addend, int ldadd, void* dx, octa_stream_t stream);
 /* Strided data gradient as GEMM + col2im: Z[(b,oh,ow)][(ci*KH+kh)*KW+kw] = dy x W^T comes from
  * octa_conv2d_fwd (1x1, operand = the data-grad packed weight); this folds the overlapping taps:
  * dx[b,ih,iw,ci] = sum_{kh,kw : ih+pad-kh = stride*oh, ...} Z[...].  (discriminator/blocks.py:46,97)

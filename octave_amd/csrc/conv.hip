@@ -27,6 +27,8 @@ struct ConvArgs {
     int act, mode;        // mode 0: forward gather, 1: data-gradient gather
     int upshuffle, CoutT;
     int vec_store;
+    const void* addend;   // optional (data gradient): tensor of the OUTPUT's shape added in the epilogue (fan-out gradient sum)
+    int ldadd;
     int vec16;            // 16-byte output stores are aligned: ldy, yoff (and the upshuffle channel count) are multiples of 8
     int NgSt;             // channels stored per group: Ng, or round8(Ng) when the pad channels are zero-filled here
 };
@@ -88,6 +90,52 @@ __device__ __forceinline__ void bias_act_tile(V4 (&acc)[TN][TM], const ConvArgs&
         }
     }
     act_tile(acc, a.act);
+}
+
+// Epilogue pre-pass of the fused data gradient (octa_conv2d_dgrad_add): acc += addend[pixel][channel] for every fragment of
+// the lane.  Runs BEFORE the store loop so that no store sits between the loads (the compiler then issues all of them back to
+// back and waits once); out-of-range fragments read a clamped address and add nothing.
+template <typename T, typename V4, int TN, int TM>
+__device__ __forceinline__ void addend_tile(V4 (&acc)[TN][TM], const ConvArgs& a, int mrow0, int ncol0, int g) {
+    if (!a.addend) return;
+    const T* __restrict__ ad = (const T*)a.addend;
+    const int cbase = g * a.Ng;
+    const bool vec = sizeof(T) == 2 && (a.ldadd & 3) == 0 && (cbase & 3) == 0 && (a.Ng & 3) == 0;
+    if (vec) {
+        uint2 raw[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = min(mrow0 + j * 16, a.M - 1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int nb = ncol0 + i * 16;
+                raw[i][j] = *(const uint2*)(ad + (size_t)m * a.ldadd + cbase + (nb < a.Ng ? nb : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if (mrow0 + j * 16 >= a.M || ncol0 + i * 16 >= a.Ng) continue;
+                float f[8];
+                unpack16<T>(make_uint4(raw[i][j].x, raw[i][j].y, 0u, 0u), f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += f[e];
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mrow0 + j * 16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = ncol0 + i * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nb + e < a.Ng) acc[i][j][e] += DT<T>::ld(ad + (size_t)m * a.ldadd + cbase + nb + e);
+        }
+    }
 }
 
 // PW: pointwise fast path (1x1, stride 1, no padding - three of the four convs of every bottleneck): the gathered pixel IS the
@@ -233,6 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     // epilogue: lane holds, per (tn,tm), 4 consecutive output channels (rows of D) of pixel column r
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
+    addend_tile<T>(acc, a, m0 + wm * TM * 16 + r, n0 + wn * TN * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
@@ -445,6 +494,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
 
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
+    addend_tile<T>(acc, a, m0 + wm * TM * 16 + r, n0 + wn * TN * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
@@ -721,7 +771,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }     // 4-wave 128x128 slab
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
-        if ((want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
+        if (!a.addend && (want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
     }
     // explicit 4-wave tile choices (measured per shape by the training step's autotuner): 4 = 128x128, 5 = 64x64, 6 = 128x64
     if (algo >= 4 && algo <= 6) {
@@ -739,12 +789,12 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         OCTA_CHECK_LAUNCH("conv_igemm");
         return OCTA_OK;
     }
-    if (conv_variant() >= 1) {
+    if (conv_variant() >= 1 && !a.addend) {
         const bool done = a.mode == 0 ? launch_halo<T, 0>(a, groups, st) : launch_halo<T, 1>(a, groups, st);
         if (done) { OCTA_CHECK_LAUNCH("conv3x3_halo"); return OCTA_OK; }
     }
     // LDS-DMA kernel: tap masks are 32 bits and element offsets 32-bit
-    const bool dma = conv_variant() == 2 && a.KH * a.KW <= 32 &&
+    const bool dma = conv_variant() == 2 && !a.addend && a.KH * a.KW <= 32 &&
                      (int64_t)a.B * a.H * a.W * (int64_t)a.ldx * (a.mode == 1 ? a.stride : 1) < (1ll << 31);
     if (a.Ng > 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 128), groups);
@@ -816,6 +866,7 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     a.M = d->B * d->OH * d->OW; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = d->act; a.mode = 0; a.upshuffle = d->upshuffle; a.CoutT = d->upshuffle ? d->Cout / 4 : 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->yoff % 4 == 0) && (d->ldy % 4 == 0) && (!d->upshuffle || a.CoutT % 4 == 0);
+    a.addend = nullptr; a.ldadd = 0;
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     if (d->zero_pad) {
@@ -829,7 +880,7 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
                                  : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
 }
 
-extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
+static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, const void* addend, int ldadd, octa_stream_t stream) {
     int rc = check_desc(d, "octa_conv2d_dgrad");
     if (rc) return rc;
     OCTA_REQUIRE(dy && wt && dx, "octa_conv2d_dgrad: null pointer");
@@ -849,6 +900,7 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     a.M = d->B * d->H * d->W; a.Kc = d->KH * d->KW * (a.Cg / epc);
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
+    a.addend = addend; a.ldadd = ldadd;
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     if (d->zero_pad) {
@@ -858,6 +910,15 @@ extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const 
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
          : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
                                  : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
+}
+extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
+    return conv2d_dgrad_impl(d, dy, wt, dx, nullptr, 0, stream);
+}
+extern "C" int octa_conv2d_dgrad_add(const octa_conv_desc* d, const void* dy, const void* wt, const void* addend, int ldadd, void* dx,
+                                     octa_stream_t stream) {
+    OCTA_REQUIRE(addend != nullptr && ldadd > 0, "octa_conv2d_dgrad_add: addend / ldadd");
+    OCTA_REQUIRE(d && d->Cin % d->groups == 0 && ldadd >= d->Cin, "octa_conv2d_dgrad_add: ldadd %d < Cin", ldadd);
+    return conv2d_dgrad_impl(d, dy, wt, dx, addend, ldadd, stream);
 }
 
 // ------------------------------------------------------------------------------------------

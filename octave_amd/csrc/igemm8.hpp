@@ -195,6 +195,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     // epilogue: lane holds, per (tn, tm), 4 consecutive output channels (rows of D) of pixel column r
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * 4 * 16 + q * 4, g);
+    addend_tile<T>(acc, a, m0 + wm * 4 * 16 + r, n0 + wn * 4 * 16 + q * 4, g);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + (wm * 4 + j) * 16 + r;

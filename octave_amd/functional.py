@@ -418,7 +418,7 @@ def _choose_algo(kind: str, d, launch) -> int:
     cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
     if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
         cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
-    if cg in (32, 64) and d.groups == 1 and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
+    if kind != "dgrad_add" and cg in (32, 64) and d.groups == 1 and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
     best, best_t = 1, None
     if len(cands) > 1:
@@ -444,9 +444,15 @@ def _launch_fwd(d, x, wp, bias, y):
     L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
 
 
-def _launch_dgrad(d, dy, wt, dx):
+def _launch_dgrad(d, dy, wt, dx, addend=None):
     L, st = lib(), _st()
     pdy, pw, pdx = _p(dy), _p(wt), _p(dx)
+    if addend is not None:
+        # dx = conv^T(dy) + addend in the kernel's epilogue (the generic / LDS-DMA kernels; tuned as its own shape class)
+        pa, lda = _p(addend), nhwc_ld(addend)
+        d.algo = _choose_algo("dgrad_add", d, lambda: L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st))
+        L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st)
+        return
     d.algo = _choose_algo("dgrad", d, lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
     L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st)
 
@@ -518,8 +524,18 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
 _COL2IM_TAPS = os.environ.get("OCTA_NO_COL2IM_TAPS") is None
 
 
-def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int) -> Tensor:
+def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int, addend: Optional[Tensor] = None) -> Tensor:
+    """Data gradient of a conv.  `addend` (a tensor of x's shape) is summed into the result: in the kernel's epilogue on
+    the direct path, as a separate add on the GEMM + col2im / densified ones."""
     B, Cin, H, W = xshape
+    if addend is not None:
+        if tuple(addend.shape) != tuple(xshape):
+            raise OctaError(f"raw_conv_dgrad: addend shape {tuple(addend.shape)} != input shape {tuple(xshape)}")
+        direct = not (stride > 1 and groups == 1 and (Cin * w.shape[2] * w.shape[3]) % 8 == 0) and \
+            not _densify(groups, Cin, w.shape[0], w.shape[2], w.shape[3], stride, pad, H, W, dy.dtype)
+        if not direct:
+            return raw_conv_dgrad(dy, w, xshape, stride, pad, groups) + addend.to(dy.dtype)
+        addend = to_nhwc(addend, dtype=dy.dtype)
     Cout, Cin_g, KH, KW = w.shape
     OH, OW = dy.shape[2], dy.shape[3]
     need = round8(Cout // groups) if groups == 1 else Cout
@@ -562,7 +578,7 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
         lib().octa_col2im(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, Cin, KH, KW, stride, pad, _dt(dy), _st())
         return dx
-    _launch_dgrad(d, dy, wt, dx)
+    _launch_dgrad(d, dy, wt, dx, addend)
     _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
     return dx
 
@@ -817,13 +833,47 @@ def _ret(p: Tensor, buf: Tensor) -> Optional[Tensor]:
 
 
 # ============================================================================= autograd Functions
+class GradHolder:
+    """Carries the gradient of one consumer of a tensor to the conv that consumes the same tensor, so that the conv's data
+    gradient can add it in its epilogue (fan-out gradient sum without autograd's separate add kernel)."""
+    __slots__ = ("grad", "consumed")
+
+    def __init__(self):
+        self.grad = None
+        self.consumed = False
+
+
+class StashGradFn(Function):
+    """Identity.  Backward parks the incoming gradient in the holder and reports None; the conv sharing the holder adds it
+    to its own data gradient.  If that conv's backward already ran (unexpected graph order), the gradient flows normally."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        h = ctx.holder
+        if h.consumed:
+            return g, None
+        h.grad = g if h.grad is None else h.grad + g
+        return None, None
+
+
+def stash_grad(x: Tensor, holder: GradHolder) -> Tensor:
+    return StashGradFn.apply(x, holder)
+
+
 class Conv2dFn(Function):
     """nn.Conv2d (+ fused activation).  Weight OIHW-logical fp32 parameter, any strides."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, groups, act):
+    def forward(ctx, x, w, bias, stride, pad, groups, act, holder=None):
         _require_gpu(x)
         y = raw_conv_fwd(x, w, bias, stride, pad, groups, act)
+        ctx.holder = holder
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -837,7 +887,11 @@ class Conv2dFn(Function):
         stride, pad, groups, act, xshape = ctx.cfg
         if act != ACT_NONE:
             dy = raw_act_bwd(y, dy, act)
-        dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups) if ctx.needs_input_grad[0] else None
+        addend = None
+        if ctx.holder is not None:
+            ctx.holder.consumed = True
+            addend, ctx.holder.grad = ctx.holder.grad, None
+        dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         b = ctx.bias_ref
@@ -853,11 +907,11 @@ class Conv2dFn(Function):
             raw_colsum(dy, db)
         if want_b:
             db = _ret(b, db)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE):
-    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act)
+def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE, grad_holder=None):
+    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act, grad_holder)
 
 
 class ConvTranspose2x2Fn(Function):

@@ -48,8 +48,8 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("octave_amd.Conv2d: dilation 1 and zero padding only")
         self.act = act
 
-    def forward(self, x):
-        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act)
+    def forward(self, x, grad_holder=None):
+        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act, grad_holder)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -142,11 +142,12 @@ def _identity_stats(C: int, device):
     return t
 
 
-def conv_bn(conv: "Conv2d", bn: "BatchNorm2d", x, relu: bool = False, residual=None):
+def conv_bn(conv: "Conv2d", bn: "BatchNorm2d", x, relu: bool = False, residual=None, grad_holder=None):
     """bn(conv(x)) [+ residual] [-> relu].  Training: the two fused-statistics layers.  Inference (eval mode, no grad): one conv
-    launch with the BatchNorm folded into its packed weights and bias (+ one add/ReLU pass when there is a residual)."""
+    launch with the BatchNorm folded into its packed weights and bias (+ one add/ReLU pass when there is a residual).
+    `grad_holder` (functional.GradHolder): the conv's data gradient adds the gradient parked there by functional.stash_grad."""
     if bn.training or bn.running_mean is None or torch.is_grad_enabled():
-        return bn(conv(x), relu=relu, residual=residual)
+        return bn(conv(x, grad_holder) if grad_holder is not None else conv(x), relu=relu, residual=residual)
     wf, bf = _fold_entry(conv, bn)
     act = ACT_RELU if (relu and residual is None) else ACT_NONE
     if conv.act != ACT_NONE:

@@ -495,6 +495,72 @@ def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     check(f"igemm8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+ADD_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, groups
+    (2, 256, 13, 11, 64, 1, 1, 0, 1),      # a bottleneck's conv1 (1x1): dx has 256 channels
+    (2, 136, 9, 10, 64, 1, 1, 0, 1),       # N tail
+    (2, 64, 12, 12, 64, 3, 1, 1, 1),       # 3x3 (the halo / resident kernels must step aside)
+    (1, 20, 7, 9, 24, 1, 1, 0, 1),         # odd channel counts: scalar addend reads
+    (2, 64, 16, 16, 128, 3, 2, 1, 1),      # strided: GEMM + col2im path, the sum is a separate add
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("algo", [0, 1, 5, 2, 8, 7])
+@pytest.mark.parametrize("case", ADD_CASES)
+def test_dgrad_with_fused_addend_vs_torch(dev, case, algo, dtype):
+    """octa_conv2d_dgrad_add: dx = conv^T(dy, w) + addend in the kernel's epilogue, on every kernel family the dispatcher may
+    pick (algo 7 must fall back: the resident-weight kernel has no addend path), against torch's CPU gradient + addend."""
+    from octave_amd import functional as F_
+    B, Cin, H, W, Cout, k, s_, p_, g = case
+    gen = torch.Generator().manual_seed(31)
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * 0.1).to(dtype).float()
+    xr = torch.randn(B, Cin, H, W, generator=gen).requires_grad_(True)
+    y = torch.nn.functional.conv2d(xr, w, None, s_, p_, 1, g)
+    dy = torch.randn(tuple(y.shape), generator=gen).to(dtype).float()
+    y.backward(dy)
+    add = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    want = xr.grad + add
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    F_._ALGO_OVERRIDE = algo
+    try:
+        dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), s_, p_, g,
+                               addend=F_.to_nhwc(add.to(dev), dtype=dtype))
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    t = TOL[dtype]
+    check(f"dgrad+addend {case} algo {algo}", dx, want, t["rtol"], t["atol"] * float(want.abs().max()))
+
+
+def test_fanout_gradient_fusion_matches_autograd_sum(dev):
+    """functional.stash_grad + Conv2dFn's grad_holder (Bottleneck.forward): the gradient of a tensor feeding a conv AND a
+    shortcut equals autograd's own sum, including when the tensor has a third consumer and when the holder goes unused."""
+    from octave_amd import functional as F_
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 64, 10, 10, generator=gen)
+    w = torch.nn.Parameter((torch.randn(32, 64, 1, 1, generator=gen) * 0.1).to(dev).contiguous(memory_format=torch.channels_last))
+    gy = torch.randn(2, 32, 10, 10, generator=gen).to(dev)
+
+    def run(fused):
+        x = F_.to_nhwc(x0.to(dev), dtype=torch.bfloat16).requires_grad_(True)
+        t = x * 1.0                                     # non-leaf, like a block input
+        h = F_.GradHolder() if fused else None
+        y = F_.conv2d(t, w, None, 1, 0, 1, 0, h)
+        ts = F_.stash_grad(t, h) if fused else t
+        loss = (y.float() * gy).sum() + (ts.float() * 0.5).sum() + (t.float() * 0.25).sum()    # conv + shortcut + third consumer
+        loss.backward()
+        return x.grad.float().cpu()
+
+    a, b = run(False), run(True)
+    assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()), float((a - b).abs().max())
+    # a holder nobody stashes into: plain data gradient
+    x = F_.to_nhwc(x0.to(dev), dtype=torch.bfloat16).requires_grad_(True)
+    (F_.conv2d(x, w, None, 1, 0, 1, 0, F_.GradHolder()).float() * gy).sum().backward()
+    x2 = F_.to_nhwc(x0.to(dev), dtype=torch.bfloat16).requires_grad_(True)
+    (F_.conv2d(x2, w, None, 1, 0, 1, 0).float() * gy).sum().backward()
+    assert torch.equal(x.grad, x2.grad)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 15, 40, 44, 128, 4, 2, 1), (3, 2, 50, 38, 64, 4, 2, 1), (2, 13, 21, 21, 72, 4, 2, 1)])
 def test_strided_dgrad_tap_major_col2im_vs_torch(dev, case, dtype):
