@@ -201,6 +201,15 @@ int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean, const flo
                   const float* gamma, const float* beta, const void* residual, int ldr, int roff,
                   void* y, int ldy, int yoff, int64_t rows, int C, int dtype, int relu,
                   uint8_t* relu_mask, octa_stream_t stream);
+/* statistics + apply in one call (training forward): same results as octa_bn_stats followed by octa_bn_apply.
+ * Small tensors (<= 16 rows per thread over 32 row slabs) run as TWO launches (the apply merges the
+ * per-slab partials itself: no finalize launch); larger ones as the three launches of the two calls above.  mean / invstd receive the batch
+ * statistics (the backward pass needs them); relu_mask as in octa_bn_apply. */
+int octa_bn_train_fwd(const void* x, int ldx, int xoff, const float* gamma, const float* beta,
+                      const void* residual, int ldr, int roff, void* y, int ldy, int yoff, int64_t rows,
+                      int C, int dtype, float eps, float momentum, int relu, float* mean, float* invstd,
+                      float* running_mean, float* running_var, uint8_t* relu_mask, float* workspace,
+                      octa_stream_t stream);
 /* backward.  With relu != 0 the ReLU mask comes from relu_mask (as written by octa_bn_apply) when it
  * is given, else from the forward output y (y may be NULL when relu_mask is given).
  * dgamma/dbeta are ACCUMULATED (+=).  dres (optional) receives the masked dy. */

@@ -125,6 +125,271 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------
+// Small tensors (up to ~16 rows per thread with 32 row slabs: the 13x13 .. 26x26 stages): the three launches of a BatchNorm pass are latency, not bytes.  Two launches instead:
+//   bn_small_reduce : a workgroup owns TX chunk columns (8 -> 64 channels of a 16-bit tensor: one 128-byte line per row) x a slab
+//                     of rows and writes ONE partial per channel; at most 32 row slabs, so a column block has <= 32 partials;
+//   bn_small_apply / bn_small_bwd_apply : same column-block geometry; the workgroup's prologue merges the <= 32 partials of ITS
+//                     channels (a few KB, 256 threads) into LDS coefficients, then streams its rows.  The workgroups of row
+//                     slab 0 also write what the separate finalize launch used to (mean / invstd / running statistics,
+//                     resp. dgamma / dbeta).
+// No finalize launch, no atomics, no cross-workgroup ordering inside a kernel.  (A single-launch reduce + finalize with a
+// last-arriver ticket was measured first: the device-scope fences it needs cost more than the launch they save.)
+struct BnSmallGeo { int TX, gridx, nby, rpb; };
+static bool bn_small_geometry(int64_t rows, int C, int epc, BnSmallGeo& g) {
+    static int64_t max_bytes = -1;
+    static int max_rpt = -1, max_nby = -1;
+    if (max_nby < 0) { const char* e = getenv("OCTA_BN_SMALL_MAX_NBY"); max_nby = e ? atoi(e) : 32; if (max_nby < 1) max_nby = 1; if (max_nby > 1024) max_nby = 1024; }
+    if (max_bytes < 0) { const char* e = getenv("OCTA_BN_SMALL_MAX_MB"); max_bytes = (int64_t)(e ? atoi(e) : 96) << 20; }
+    if (max_rpt < 0) { const char* e = getenv("OCTA_BN_SMALL_MAX_RPT"); max_rpt = e ? atoi(e) : 16; }
+    const int cpr = C / epc;
+    if (cpr % 4 != 0 || rows * C * (int64_t)(epc == 4 ? 4 : 2) > max_bytes) return false;
+    g.TX = (cpr % 8 == 0 && cpr >= 64) ? 8 : 4;
+    g.gridx = cpr / g.TX;
+    const int RY = 256 / g.TX;
+    int64_t nby = cdiv64(rows, (int64_t)RY * 2);            // at least two rows per thread
+    if (nby > max_nby) nby = max_nby;
+    if (nby < 1) nby = 1;
+    g.rpb = (int)cdiv64(rows, nby);
+    g.nby = (int)cdiv64(rows, g.rpb);
+    // rows per thread; beyond ~16 the many-slab kernels stream better (in-situ sweep: 8 / 12 / 16 / 32 / 48 rows and 32 / 64 /
+    // 128 slabs; 16 x 32 won, 48 rows lost everything again)
+    return cdiv64(g.rpb, RY) <= max_rpt;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_small_reduce_kernel(const T* __restrict__ x, int ldx, int xoff, const T* __restrict__ dy, int lddy,
+                                                              int dyoff, const T* __restrict__ y, int ldy, int yoff,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                              const uint8_t* __restrict__ rmask, int64_t rows, int C, int TX, int rpb,
+                                                              float* __restrict__ partial) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int NS = MODE == 0 ? 3 : 2;
+    __shared__ float red[256 * EPC * NS];              // [RY][CH][NS]
+    const int RY = 256 / TX, CH = TX * EPC;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx;
+    const int cpr = C / EPC;
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    float sa[EPC], sb[EPC], mu[EPC], is[EPC];
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sa[e] = 0.f; sb[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; }
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { mu[e] = mean[col * EPC + e]; is[e] = invstd[col * EPC + e]; }
+    }
+    for (int64_t r = r0 + ry; r < r1; r += RY) {
+        float xv[EPC];
+        unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
+        if (MODE == 0) {
+            if (cnt == 0) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) mu[e] = xv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float d = xv[e] - mu[e]; sa[e] += d; sb[e] += d * d; }
+            ++cnt;
+        } else {
+            float dv[EPC], yv[EPC];
+            unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
+            if (relu && rmask) {
+                const unsigned mb = rmask[r * cpr + col];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
+            } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + col * EPC), yv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
+                sa[e] += d; sb[e] += d * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    float* my = red + ((size_t)ry * CH + cx * EPC) * NS;
+    if (MODE == 0) {
+        const float fn = (float)cnt;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float m1 = cnt ? sa[e] / fn : 0.f;
+            my[e * 3] = mu[e] + m1;                           // thread mean
+            my[e * 3 + 1] = cnt ? sb[e] - sa[e] * m1 : 0.f;   // thread M2
+            my[e * 3 + 2] = fn;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { my[e * 2] = sa[e]; my[e * 2 + 1] = sb[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x >= CH) return;
+    const int ch = threadIdx.x, c = blockIdx.x * CH + ch;
+    if (MODE == 0) {
+        // row lanes re-expressed around row lane 0's mean (it always holds a sample): plain double sums, no divisions
+        const double r = (double)red[ch * 3];
+        double n = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int yy = 0; yy < RY; ++yy) {
+            const float* pr = red + ((size_t)yy * CH + ch) * 3;
+            const double nb = (double)pr[2], d = (double)pr[0] - r;
+            n += nb; s1 += nb * d; s2 += (double)pr[1] + nb * d * d;
+        }
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)(r + s1 / n);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)(s2 - s1 * s1 / n);
+    } else {
+        float a = 0.f, b = 0.f;
+        for (int yy = 0; yy < RY; ++yy) { a += red[((size_t)yy * CH + ch) * 2]; b += red[((size_t)yy * CH + ch) * 2 + 1]; }
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
+    }
+}
+
+// prologue shared by the two apply kernels: S1[ch], S2[ch] (doubles in LDS) of this column block from its nbp partials
+//   MODE 0: S1 = sum n_b (mean_b - r), S2 = sum M2_b + n_b (mean_b - r)^2, r = block 0's mean      MODE 1: plain sums
+template <int MODE>
+__device__ __forceinline__ void bn_small_merge(const float* __restrict__ partial, int nbp, int rpbp, int64_t rows, int C, int CH, int c0,
+                                               double (*fred)[2] /* [256][2] */, double (*S)[2] /* [64][2] */) {
+    const int ch = threadIdx.x % CH, part = threadIdx.x / CH, NP = 256 / CH;
+    const int c = c0 + ch;
+    double s1 = 0.0, s2 = 0.0;
+    if (MODE == 0) {
+        const double r = (double)partial[c];
+        for (int b = part; b < nbp; b += NP) {
+            const int64_t lo = (int64_t)b * rpbp;
+            const double nb = (double)((rows - lo) < rpbp ? (rows - lo) : rpbp);
+            const double d = (double)partial[((size_t)b * 2) * C + c] - r;
+            s1 += nb * d;
+            s2 += (double)partial[((size_t)b * 2 + 1) * C + c] + nb * d * d;
+        }
+    } else {
+        for (int b = part; b < nbp; b += NP) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    }
+    fred[threadIdx.x][0] = s1; fred[threadIdx.x][1] = s2;
+    __syncthreads();
+    if (threadIdx.x < CH) {
+        s1 = 0.0; s2 = 0.0;
+        for (int q = 0; q < NP; ++q) { s1 += fred[q * CH + ch][0]; s2 += fred[q * CH + ch][1]; }
+        S[ch][0] = s1; S[ch][1] = s2;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_apply_kernel(const T* __restrict__ x, int ldx, int xoff, const float* __restrict__ partial, int nbp,
+                                                             int rpbp, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const T* __restrict__ res, int ldr, int roff, T* __restrict__ y, int ldy, int yoff,
+                                                             int64_t rows, int C, int TX, int rpb, int relu, uint8_t* __restrict__ rmask,
+                                                             float eps, float momentum, float* __restrict__ mean_out,
+                                                             float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv) {
+    constexpr int EPC = DT<T>::EPC;
+    __shared__ double fred[256][2];
+    __shared__ double S[64][2];
+    __shared__ float coef[64][3];                      // mean, gamma * invstd, beta
+    const int RY = 256 / TX, CH = TX * EPC;
+    const int c0 = blockIdx.x * CH;
+    bn_small_merge<0>(partial, nbp, rpbp, rows, C, CH, c0, fred, S);
+    if (threadIdx.x < CH) {
+        const int ch = threadIdx.x, c = c0 + ch;
+        const double n = (double)rows, r = (double)partial[c], s1 = S[ch][0], s2 = S[ch][1];
+        const double m = r + s1 / n;
+        double var = (s2 - s1 * s1 / n) / n;
+        if (var < 0.0) var = 0.0;
+        const float isd = (float)(1.0 / sqrt(var + (double)eps));
+        coef[ch][0] = (float)m; coef[ch][1] = gamma[c] * isd; coef[ch][2] = beta[c];
+        if (blockIdx.y == 0) {
+            mean_out[c] = (float)m;
+            invstd_out[c] = isd;
+            if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+            if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+        }
+    }
+    __syncthreads();
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    float mu[EPC], sc[EPC], be[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = coef[cx * EPC + e][0]; sc[e] = coef[cx * EPC + e][1]; be[e] = coef[cx * EPC + e][2]; }
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    // block-uniform trip count (the DPP mask combine below needs every lane of a quad in the loop)
+    for (int64_t rb = r0; rb < r1; rb += RY) {
+        const int64_t r = rb + ry;
+        const bool live = r < r1;
+        const int64_t rr_ = live ? r : r0;
+        float v[EPC], rr[EPC];
+        unsigned mb = 0u;
+        unpack16<T>(*(const uint4*)(x + rr_ * ldx + xoff + col * EPC), v);
+        if (res) unpack16<T>(*(const uint4*)(res + rr_ * ldr + roff + col * EPC), rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float o = (v[e] - mu[e]) * sc[e] + be[e];
+            if (res) o += rr[e];
+            if (relu) { if (o > 0.f) mb |= 1u << e; else o = 0.f; }
+            v[e] = o;
+        }
+        if (live) *(uint4*)(y + rr_ * ldy + yoff + col * EPC) = pack16<T>(v);
+        if (rmask) {
+            // 4 neighbouring lanes = 4 neighbouring chunk columns of one row (TX % 4 == 0, cpr % 4 == 0): one dword store
+            unsigned w = live ? (mb << (8 * (threadIdx.x & 3))) : 0u;
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);
+            if ((threadIdx.x & 3) == 0 && live) *(unsigned*)(rmask + rr_ * cpr + col) = w;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_bwd_apply_kernel(const T* __restrict__ dy, int lddy, int dyoff, const T* __restrict__ x, int ldx,
+                                                                 int xoff, const T* __restrict__ y, int ldy, int yoff,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ partial, int nbp,
+                                                                 const uint8_t* __restrict__ rmask, T* __restrict__ dx, int lddx, int dxoff,
+                                                                 T* __restrict__ dres, int lddr, int droff, int64_t rows, int C, int TX, int rpb,
+                                                                 int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int EPC = DT<T>::EPC;
+    __shared__ double fred[256][2];
+    __shared__ double S[64][2];
+    __shared__ float coef[64][5];                      // mean, invstd, gamma * invstd, sum dy' / N, sum dy' xhat / N
+    const int RY = 256 / TX, CH = TX * EPC;
+    const int c0 = blockIdx.x * CH;
+    bn_small_merge<1>(partial, nbp, 0, rows, C, CH, c0, fred, S);
+    if (threadIdx.x < CH) {
+        const int ch = threadIdx.x, c = c0 + ch;
+        const double n = (double)rows, s = S[ch][0], ss = S[ch][1];
+        const float isd = invstd[c];
+        coef[ch][0] = mean[c]; coef[ch][1] = isd; coef[ch][2] = gamma[c] * isd;
+        coef[ch][3] = (float)(s / n); coef[ch][4] = (float)(ss / n);
+        if (blockIdx.y == 0) {
+            if (dbeta) dbeta[c] += (float)s;
+            if (dgamma) dgamma[c] += (float)ss;
+        }
+    }
+    __syncthreads();
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    float mu[EPC], isd[EPC], gi[EPC], f0[EPC], f1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float* k = coef[cx * EPC + e];
+        mu[e] = k[0]; isd[e] = k[1]; gi[e] = k[2]; f0[e] = k[3]; f1[e] = k[4];
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    for (int64_t r = r0 + ry; r < r1; r += RY) {
+        float dv[EPC], xv[EPC], yv[EPC], o[EPC];
+        unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
+        unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
+        if (relu && rmask) {
+            const unsigned mb = rmask[r * cpr + col];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) yv[e] = (mb >> e) & 1u ? 1.f : 0.f;
+        } else if (relu) unpack16<T>(*(const uint4*)(y + r * ldy + yoff + col * EPC), yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float d = (relu && !(yv[e] > 0.f)) ? 0.f : dv[e];
+            dv[e] = d;
+            const float xh = (xv[e] - mu[e]) * isd[e];
+            o[e] = gi[e] * (d - f0[e] - xh * f1[e]);
+        }
+        *(uint4*)(dx + r * lddx + dxoff + col * EPC) = pack16<T>(o);
+        if (dres) *(uint4*)(dres + r * lddr + droff + col * EPC) = pack16<T>(dv);
+    }
+}
+
 // one workgroup per channel.  The block partials (n_b, mean_b, M2_b) are re-expressed around a common reference r (the first
 // block's mean): S1 = sum n_b (mean_b - r), S2 = sum M2_b + n_b (mean_b - r)^2, after which mean = r + S1/n and
 // M2 = S2 - S1^2/n (parallel-axis form of the Chan merge, evaluated in double: r is within a few sigma/sqrt(n_b) of the mean,
@@ -265,6 +530,41 @@ extern "C" int octa_bn_apply(const void* x, int ldx, int xoff, const float* mean
     return OCTA_OK;
 }
 
+// Training-mode forward in one call: statistics + apply.  Small tensors take the two-launch path above, the rest
+// octa_bn_stats + octa_bn_apply (three launches).
+extern "C" int octa_bn_train_fwd(const void* x, int ldx, int xoff, const float* gamma, const float* beta, const void* residual, int ldr,
+                                 int roff, void* y, int ldy, int yoff, int64_t rows, int C, int dtype, float eps, float momentum, int relu,
+                                 float* mean, float* invstd, float* running_mean, float* running_var, uint8_t* relu_mask, float* ws,
+                                 octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && gamma && beta && mean && invstd && ws, "octa_bn_train_fwd: null pointer");
+    OCTA_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 &&
+                     (!residual || (ldr % 8 == 0 && roff % 8 == 0)),
+                 "octa_bn_train_fwd: C/ld/off must be multiples of 8");
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_bn_train_fwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = dtype == OCTA_F32 ? 4 : 8;
+    BnSmallGeo sg;
+    if (!bn_small_geometry(rows, C, epc, sg)) {
+        const int rc = octa_bn_stats(x, rows, C, ldx, xoff, dtype, eps, momentum, mean, invstd, running_mean, running_var, ws, stream);
+        if (rc != OCTA_OK) return rc;
+        return octa_bn_apply(x, ldx, xoff, mean, invstd, gamma, beta, residual, ldr, roff, y, ldy, yoff, rows, C, dtype, relu, relu_mask, stream);
+    }
+    dim3 g(sg.gridx, sg.nby);
+#define OCTA_BN_SMALL_FWD(TT)                                                                                                                    \
+    bn_small_reduce_kernel<TT, 0><<<g, 256, 0, st>>>((const TT*)x, ldx, xoff, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, \
+                                                     sg.TX, sg.rpb, ws);                                                                          \
+    OCTA_CHECK_LAUNCH("bn_small_reduce(stats)");                                                                                                  \
+    bn_small_apply_kernel<TT><<<g, 256, 0, st>>>((const TT*)x, ldx, xoff, ws, sg.nby, sg.rpb, gamma, beta, (const TT*)residual, ldr, roff, (TT*)y,  \
+                                                 ldy, yoff, rows, C, sg.TX, sg.rpb, relu, relu_mask, eps, momentum, mean, invstd, running_mean,    \
+                                                 running_var)
+    if (dtype == OCTA_F32) { OCTA_BN_SMALL_FWD(float); }
+    else if (dtype == OCTA_BF16) { OCTA_BN_SMALL_FWD(bf16_t); }
+    else { OCTA_BN_SMALL_FWD(f16_t); }
+#undef OCTA_BN_SMALL_FWD
+    OCTA_CHECK_LAUNCH("bn_small_apply");
+    return OCTA_OK;
+}
+
 // ws layout after finalize: fin[0][c] = sum dy' / N ; fin[1][c] = sum dy' xhat / N
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float* __restrict__ fin,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -349,6 +649,24 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     dim3 grid(cm.gridx, nby);
     const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
     float* fin = ws + (size_t)1026 * 2 * C;
+    BnSmallGeo sg;
+    if (bn_small_geometry(rows, C, epc, sg)) {
+        dim3 g(sg.gridx, sg.nby);
+#define OCTA_BN_SMALL_BWD(TT)                                                                                                                   \
+        bn_small_reduce_kernel<TT, 1><<<g, 256, 0, st>>>((const TT*)x, ldx, xoff, (const TT*)dy, lddy, dyoff, (const TT*)y, ldy, yoff, mean, invstd, \
+                                                         relu, relu_mask, rows, C, sg.TX, sg.rpb, ws);                                           \
+        OCTA_CHECK_LAUNCH("bn_small_reduce(bwd)");                                                                                               \
+        bn_small_bwd_apply_kernel<TT><<<g, 256, 0, st>>>((const TT*)dy, lddy, dyoff, (const TT*)x, ldx, xoff, (const TT*)y, ldy, yoff, mean, invstd, \
+                                                         gamma, ws, sg.nby, relu_mask, (TT*)dx, lddx, dxoff, (TT*)dres, lddr, droff, rows, C,    \
+                                                         sg.TX, sg.rpb, relu, dgamma, dbeta)
+        if (dtype == OCTA_F32) { OCTA_BN_SMALL_BWD(float); }
+        else if (dtype == OCTA_BF16) { OCTA_BN_SMALL_BWD(bf16_t); }
+        else { OCTA_BN_SMALL_BWD(f16_t); }
+#undef OCTA_BN_SMALL_BWD
+        OCTA_CHECK_LAUNCH("bn_small_bwd_apply");
+        return OCTA_OK;
+    }
+    {
     if (dtype == OCTA_F32)
         bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
     else if (dtype == OCTA_BF16)
@@ -358,6 +676,7 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");
+    }
     if (dtype == OCTA_F32)
         bn_bwd_apply_kernel<float><<<ew_blocks_aligned(rows * (C / 4), C / 4), 256, 0, st>>>((const float*)dy, lddy, dyoff, (const float*)x, ldx, xoff, (const float*)y, ldy, yoff, mean, invstd, gamma, fin, relu_mask, (float*)dx, lddx, dxoff, (float*)dres, lddr, droff, rows, C, relu);
     else if (dtype == OCTA_BF16)

@@ -760,22 +760,21 @@ def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv:
     B, C, H, W = x.shape
     rows = B * H * W
     L = lib()
+    y = nhwc_empty(B, C, H, W, x.dtype, x.device)
+    res = to_nhwc(residual, dtype=x.dtype) if residual is not None else None
+    # 1 bit per element ReLU mask for the backward pass (read instead of y: 1/16 of the bytes in both backward kernels)
+    mask = torch.empty(((rows * (C // (4 if x.dtype == torch.float32 else 8)) + 3) // 4 * 4,), dtype=torch.uint8, device=x.device) if (relu and training) else None
     if training:
         if rows <= 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        L.octa_bn_stats(_p(x), rows, C, nhwc_ld(x), 0, _dt(x), eps, momentum, _p(mean), _p(invstd), _p(rm), _p(rv),
-                        _p(_bn_ws(rows, C, x.device)), _st())
-    else:
-        mean = rm.float()
-        invstd = torch.rsqrt(rv.float() + eps)
-    y = nhwc_empty(B, C, H, W, x.dtype, x.device)
-    res = None
-    if residual is not None:
-        res = to_nhwc(residual, dtype=x.dtype)
-    # 1 bit per element ReLU mask for the backward pass (read instead of y: 1/16 of the bytes in both backward kernels)
-    mask = torch.empty(((rows * (C // (4 if x.dtype == torch.float32 else 8)) + 3) // 4 * 4,), dtype=torch.uint8, device=x.device) if (relu and training) else None
+        L.octa_bn_train_fwd(_p(x), nhwc_ld(x), 0, _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
+                            _p(y), nhwc_ld(y), 0, rows, C, _dt(x), eps, momentum, int(relu), _p(mean), _p(invstd), _p(rm), _p(rv),
+                            _p(mask), _p(_bn_ws(rows, C, x.device)), _st())
+        return y, mean, invstd, x, mask
+    mean = rm.float()
+    invstd = torch.rsqrt(rv.float() + eps)
     L.octa_bn_apply(_p(x), nhwc_ld(x), 0, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
                     _p(y), nhwc_ld(y), 0, rows, C, _dt(x), int(relu), _p(mask), _st())
     return y, mean, invstd, x, mask

@@ -452,6 +452,40 @@ def test_batch_norm_full_size(dev):
     assert (bet.grad.double() - gd.sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2
 
 
+@pytest.mark.parametrize("shape", [(16, 1024, 25, 25), (16, 256, 50, 50), (16, 2048, 13, 13), (5, 72, 31, 17)])
+def test_batch_norm_fused_finalize_repeated(dev, shape):
+    """The small-tensor path (reduce + finalize in ONE launch, last-arriving workgroup merges) on shapes with
+    many row blocks per column block, called three times in a row (the ticket counters must come back to zero), forward and
+    backward against a float64 evaluation of the same formulas on the same bf16 inputs."""
+    from octave_amd import functional as F_
+    B, C, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    x0 = (torch.randn(B, C, H, W, generator=gen) * 2.0 + 0.7).to(dev).to(torch.bfloat16)
+    g = torch.randn(B, C, H, W, generator=gen).to(dev).to(torch.bfloat16)
+    xd, gd = x0.double(), g.double()
+    mu = xd.mean(dim=(0, 2, 3), keepdim=True)
+    var = xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    isd = 1.0 / torch.sqrt(var + 1e-5)
+    xh = (xd - mu) * isd
+    ref_dx = isd * (gd - gd.mean(dim=(0, 2, 3), keepdim=True) - xh * (gd * xh).mean(dim=(0, 2, 3), keepdim=True))
+    n = B * H * W
+    for it in range(3):
+        x = x0.clone().requires_grad_(True)
+        gam = torch.ones(C, device=dev, requires_grad=True)
+        bet = torch.zeros(C, device=dev, requires_grad=True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y = F_.batch_norm(x, gam, bet, rm, rv, 0.1, 1e-5, True)
+        yf = F_.to_nchw_f32(y.detach()).double()
+        assert (yf - xh).abs().max().item() <= 2.0 ** -8 * xh.abs().max().item() + 1e-6, it
+        assert (rm.double() - 0.1 * mu.flatten()).abs().max().item() < 1e-5, it
+        assert (rv.double() - (0.9 + 0.1 * var.flatten() * n / (n - 1))).abs().max().item() < 1e-4, it
+        (y.float() * g.float()).sum().backward()
+        err = (F_.to_nchw_f32(x.grad).double() - ref_dx).abs()
+        assert bool((err <= 2.0 ** -7 * ref_dx.abs() + 2e-5).all()), (it, err.max().item())
+        assert (gam.grad.double() - (gd * xh).sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2, it
+        assert (bet.grad.double() - gd.sum(dim=(0, 2, 3))).abs().max().item() < 1e-5 * n ** 0.5 + 1e-2, it
+
+
 # ----------------------------------------------------------------------------------------- round 2: 8-wave kernels
 IGEMM8_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, groups
