@@ -394,7 +394,7 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     l64, l32 = float(G["loss_f64"]), float(G["loss"])
     assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l32, l64)
     params, bufs = dict(net.segmentor.named_parameters()), dict(net.segmentor.named_buffers())
-    devs = {}
+    norms = {}
     for k, g in G.items():
         if k.startswith("gradnorm_f64/"):
             name = k[len("gradnorm_f64/"):]
@@ -402,11 +402,18 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
             g64 = float(g)
             if g64 < 1e-9:          # analytically zero (a bias in front of a BatchNorm): rounding noise only
                 continue
-            devs[name] = (abs(params[name].grad.double().norm().item() - g64) / g64, abs(float(G["gradnorm/" + name]) - g64) / g64)
+            norms[name] = (params[name].grad.double().norm().item(), float(G["gradnorm/" + name]), g64)
         if k.startswith("buf/"):
             check(k, bufs[k[4:]], g, 2e-3, 1e-4)
     # the backward is as chaotic as the forward: the reference's own fp32 gradient norms sit up to
-    # worst_ref away from its float64 evaluation; the HIP path must stay within 4x that band
+    # worst_ref away from its float64 evaluation; the HIP path must stay within 4x that band.
+    # Deviations are relative to max(|g64|, 1e-4 * largest norm): a gradient that is 1e-5 of the others (aag_3.conv1.bias at
+    # 64^2: 2.4e-5 against 4.6, a sum of cancelling terms) is pure noise in BOTH implementations -- the reference's own fp32
+    # value is 18 % off, and the HIP value moves between 0.3 and 1.4 from run to run with the order of the float atomics in
+    # the weight gradients (tools/grad_flake.py) -- so its RELATIVE deviation says nothing; the floor turns it into an
+    # absolute bound at the scale of the gradients that matter.
+    floor = 1e-4 * max(n[2] for n in norms.values())
+    devs = {k: (abs(h - g64) / max(g64, floor), abs(r - g64) / max(g64, floor)) for k, (h, r, g64) in norms.items()}
     worst_hip = max(d[0] for d in devs.values())
     worst_ref = max(d[1] for d in devs.values())
     med_hip = float(np.median([d[0] for d in devs.values()]))
