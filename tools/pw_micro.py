@@ -8,7 +8,7 @@ from octave_amd import functional as F_
 from tools.conv8_micro import LAYERS
 
 dev = torch.device("cuda:0")
-ALGOS = (1, 4, 5, 6, 2, 3, 8)
+ALGOS = tuple(int(a) for a in os.environ.get("PW_ALGOS", "1,4,5,6,2,3,8").split(","))
 REPS = 20
 
 
