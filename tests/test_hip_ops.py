@@ -455,7 +455,7 @@ def test_batch_norm_full_size(dev):
 @pytest.mark.parametrize("shape", [(16, 1024, 25, 25), (16, 256, 50, 50), (16, 2048, 13, 13), (5, 72, 31, 17)])
 def test_batch_norm_fused_finalize_repeated(dev, shape):
     """The small-tensor path (two launches: the apply kernels merge the <= 32 slab partials of their own channels; DESIGN.md
-    3.5) on shapes with many row slabs per column block plus one with odd sizes (72 channels: 4-chunk column blocks, a ragged
+    3.5) on shapes with many row slabs per column block, plus one whose 9 channel chunks send it down the three-launch path (ragged
     last slab), called three times in a row, forward and backward against a float64 evaluation of the same formulas on the
     same bf16 inputs; running statistics included."""
     from octave_amd import functional as F_
