@@ -45,6 +45,29 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("OCTA_CPU_THREADS", "16"))))
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs (CPUs have simd_count 0),
+    narrowed by ROCR_/HIP_/CUDA_VISIBLE_DEVICES.  None when sysfs does not say (then --gpus is trusted and a rank that finds no
+    device fails loudly)."""
+    import glob
+    n = 0
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    for path in paths:
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def synth_batch(B, H, rank, device):
     """SURVEY.md 8d: grayscale OCTA-like plane replicated to 3 channels; scribbles ~5 % per class;
     dense real vessel mask, one-hot.  On the GPU the batch is generated ON the device (octa_synth_octa, a counter-based
@@ -230,12 +253,13 @@ def main():
 
     t_begin = time.perf_counter()
     if args.gpus > 1 and "RANK" not in os.environ:
-        # launched without torchrun: start the N ranks ourselves as a CHILD process (never exec: nothing here has touched the
-        # GPU yet, device_count() does not initialise it) and relay its JSON line and exit code.  No fallback to fewer ranks.
+        # launched without torchrun: start the N ranks ourselves as a CHILD process and relay its JSON line and exit code.  The
+        # launcher itself makes NO HIP call (a process that has opened the GPU must not spawn the ranks on this pool): the
+        # devices are counted from the KFD topology in sysfs.  No fallback to fewer ranks.
         import socket
         import subprocess
-        ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        ndev = visible_gpus()
+        if ndev is not None and ndev < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible; refusing to report a smaller run as n_gpus={args.gpus}")
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))

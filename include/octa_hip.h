@@ -36,6 +36,9 @@ enum octa_status { OCTA_OK = 0, OCTA_ERR_BAD_ARG = -1, OCTA_ERR_UNSUPPORTED = -2
 enum octa_dtype { OCTA_F32 = 0, OCTA_BF16 = 1, OCTA_F16 = 2 };
 enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA_ACT_SIGMOID = 3, OCTA_ACT_TANH = 4 };
 
+/* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
+ * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
+#define OCTA_HIP_ABI_VERSION 300
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -84,9 +87,10 @@ int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
  * operand, 1: data-gradient operand, 2: ConvTranspose up-shuffle operand (Cout_g = Cout_t, Cin_g = Cin_t,
  * strides = (s_ci, s_co, s_h, s_w)), 3 / 4: a GROUPED weight laid out as the dense block-diagonal forward
  * operand [Cout][KH][KW][pad_to >= Cin] / data-gradient operand [Cin][KH][KW][pad_to >= Cout] (zeros off the
- * diagonal blocks), for small-channel grouped 3x3 layers that run faster as one dense conv on the halo kernel.
+ * diagonal blocks), for small-channel grouped 3x3 layers that run faster as one dense conv on the halo kernel;
+ * 5: the tap-major data-gradient operand of octa_pack_weight_dgrad_taps ([KH*KW][round8(Cin_g)][pad_to >= Cout_g], groups 1).
  * `prefix` = exclusive prefix sum of the operands' TILE counts (octa_pack_tile_count; `total` = their sum): 2048
- * consecutive elements per tile for kinds 0/3/4, one 32x32 LDS-transposed tile for kinds 1/2. */
+ * consecutive elements per tile for kinds 0/3/4/5, one 32x32 LDS-transposed tile for kinds 1/2. */
 typedef struct octa_pack_desc {
     const float* src;
     void* dst;
@@ -416,11 +420,12 @@ int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx
 /* ------------------------------------------------------------------------------------------
  * Optimiser: fused Adam over a flat fp32 parameter arena (train step a17).
  * ---------------------------------------------------------------------------------------- */
-/* dyn (optional, device): {1 - beta1^t, sqrt(1 - beta2^t)} read at run time instead of being derived
- * from `step` on the host, so a captured hipGraph can be replayed with advancing bias corrections. */
+/* step_dev (optional, device int32): the number of updates APPLIED so far.  The kernel then takes t = *step_dev + 1 for
+ * the bias corrections instead of the host's `step`, so a captured hipGraph advances by itself and an update skipped for
+ * a non-finite gradient does not count (torch.optim.Adam under GradScaler behaves the same); octa_step_end commits it. */
 int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale,
-                   const float* dyn, const float* ls_state /* optional */, int ls_flag, octa_stream_t stream);
+                   const int32_t* step_dev, const float* ls_state /* optional */, int ls_flag, octa_stream_t stream);
 
 /* Dynamic loss scaling for fp16 training, all on the device (capturable, no host sync).  state (8 floats): [0] loss scale,
  * [1] clean steps since the last change, [2..7] found-inf flags, one per optimiser.  octa_nonfinite_flag sets *flag = 1 if
@@ -430,6 +435,11 @@ int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int octa_nonfinite_flag(const float* g, int64_t n, float* flag, octa_stream_t stream);
 int octa_loss_scale_update(float* state, int nflags, float growth, float backoff, int interval,
                            octa_stream_t stream);
+/* The end of an optimiser step as ONE launch: step_dev{0,1} (optional; Adam's applied-update counters of optimiser 0 / 1)
+ * advance unless ls_state[2 + k] flags a skipped update, then octa_loss_scale_update's work on ls_state (optional), then
+ * octa_host_tick's (optional: tick_dev += 1, published to tick_host). */
+int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int interval, int32_t* step_dev0,
+                  int32_t* step_dev1, int32_t* tick_dev, int32_t* tick_host, octa_stream_t stream);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);

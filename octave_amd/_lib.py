@@ -73,6 +73,13 @@ def parse_header(path: str = HEADER):
     return out
 
 
+def header_abi_version(path: str = HEADER) -> int:
+    m = re.search(r"#define\s+OCTA_HIP_ABI_VERSION\s+(\d+)", open(path).read())
+    if not m:
+        raise OctaError("octa_hip.h: OCTA_HIP_ABI_VERSION is not defined")
+    return int(m.group(1))
+
+
 PROFILE = {} if os.environ.get("OCTA_PROFILE") == "1" else None
 
 
@@ -106,6 +113,10 @@ class _Lib:
             fn.restype = res
             fn.argtypes = argtypes
         self._dll.octa_last_error.restype = ctypes.c_char_p
+        # a stale build (or a foreign OCTA_HIP_LIB) would be called with mismatched structs and argument lists
+        want, got = header_abi_version(), int(self._dll.octa_version())
+        if got != want:
+            raise OctaError(f"{LIB_PATH} was built for ABI revision {got}, include/octa_hip.h declares {want}: rebuild it (octave_amd/csrc/build.sh)")
 
     def raw(self, name):
         return getattr(self._dll, name)

@@ -12,5 +12,5 @@ void octa_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int octa_version(void) { return 100; }
+extern "C" int octa_version(void) { return OCTA_HIP_ABI_VERSION; }
 extern "C" const char* octa_last_error(void) { return g_err; }

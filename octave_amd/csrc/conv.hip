@@ -1064,6 +1064,7 @@ __host__ __device__ static inline int64_t pack_tiles(const octa_pack_desc& d) {
     const int64_t kk = (int64_t)d.KH * d.KW;
     if (d.kind == 1) return (int64_t)d.groups * kk * ((d.Cin_g + 31) / 32) * ((d.pad_to + 31) / 32);
     if (d.kind == 2) return 4ll * ((d.Cout_g + 31) / 32) * ((d.pad_to + 31) / 32);
+    if (d.kind == 5) return (kk * ((d.Cin_g + 7) / 8 * 8) * d.pad_to + 2047) / 2048;
     const int64_t rows = d.kind == 4 ? (int64_t)d.groups * d.Cin_g : (int64_t)d.groups * d.Cout_g;
     return (rows * kk * d.pad_to + 2047) / 2048;
 }
@@ -1087,6 +1088,22 @@ template <> __device__ __forceinline__ void pack_store8<bf16_t>(bf16_t* dst, con
 template <typename T>
 __device__ __forceinline__ void pack_tile_linear(const octa_pack_desc& d, unsigned tl) {
     const unsigned kk = (unsigned)(d.KH * d.KW);
+    if (d.kind == 5) {                                       // tap-major data-gradient operand [tap][ci < round8(Cin)][co < pad_to]
+        const unsigned cin_pad = (unsigned)(d.Cin_g + 7) / 8u * 8u;
+        const unsigned total5 = kk * cin_pad * (unsigned)d.pad_to;
+        const unsigned base5 = tl * 2048u + threadIdx.x * 8u;
+        if (base5 >= total5) return;
+        const unsigned co0 = base5 % (unsigned)d.pad_to;     // pad_to % 8 == 0: the 8 elements share (tap, ci)
+        const unsigned t5 = base5 / (unsigned)d.pad_to;
+        const int ci = (int)(t5 % cin_pad);
+        const unsigned tap5 = t5 / cin_pad;
+        const float* src = d.src + (int64_t)ci * d.s_i + (int64_t)(tap5 / (unsigned)d.KW) * d.s_h + (int64_t)(tap5 % (unsigned)d.KW) * d.s_w;
+        float v5[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int co = (int)co0 + e; v5[e] = (ci < d.Cin_g && co < d.Cout_g) ? src[(int64_t)co * d.s_o] : 0.f; }
+        pack_store8<T>((T*)d.dst + base5, v5);
+        return;
+    }
     const unsigned rows = d.kind == 4 ? (unsigned)(d.groups * d.Cin_g) : (unsigned)(d.groups * d.Cout_g);
     const unsigned total = rows * kk * (unsigned)d.pad_to;
     const unsigned base = tl * 2048u + threadIdx.x * 8u;

@@ -344,11 +344,15 @@ extern "C" int octa_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
 // ------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs,
-                                                   const float* __restrict__ dyn, const float* __restrict__ ls_state, int ls_flag) {
-    if (dyn) { bc1 = dyn[0]; bc2s = dyn[1]; }     // bias corrections from device memory (hipGraph replay)
-    if (ls_state) {                               // dynamic loss scaling: the scale lives on the device, a flagged step is skipped
+                                                   const int* __restrict__ step_dev, const float* __restrict__ ls_state, int ls_flag) {
+    if (ls_state) {                               // loss scaling: the scale lives on the device, a flagged step is skipped
         if (ls_state[ls_flag] != 0.f) return;
         gs /= ls_state[0];
+    }
+    if (step_dev) {                               // t = updates applied so far + 1, kept on the device: a captured graph advances by itself
+        const double t = (double)(*step_dev + 1); // and a skipped step does not count (octa_step_end commits the counter)
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2s = (float)sqrt(1.0 - pow((double)b2, t));
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gg = g[i] * gs;
@@ -362,14 +366,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 extern "C" int octa_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, int step, float grad_scale, const float* dyn, const float* ls_state, int ls_flag,
+                              float weight_decay, int step, float grad_scale, const int* step_dev, const float* ls_state, int ls_flag,
                               octa_stream_t stream) {
-    OCTA_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || dyn), "octa_adam_step: bad arguments");
+    OCTA_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "octa_adam_step: bad arguments");
     OCTA_REQUIRE(!ls_state || (ls_flag >= 2 && ls_flag < 8), "octa_adam_step: ls_flag indexes the found-inf slots 2..7 of the loss-scale state");
     if (step < 1) step = 1;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, dyn, ls_state, ls_flag);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev, ls_state, ls_flag);
     OCTA_CHECK_LAUNCH("adam");
     return OCTA_OK;
 }
@@ -409,3 +413,34 @@ extern "C" int octa_loss_scale_update(float* state, int nflags, float growth, fl
     return OCTA_OK;
 }
 
+// End of an optimiser step in ONE single-thread launch (it replaces loss_scale_update + host_tick and keeps Adam's step
+// counters on the device): (1) the applied-update counter of optimiser k advances unless its found-inf flag state[2+k] is
+// set; (2) the loss-scale update above; (3) the step tick (extras.hip: host_tick_kernel).
+__global__ void step_end_kernel(float* state, int nflags, float growth, float backoff, int interval, int* c0, int* c1, int* tick_dev, int* tick_host) {
+    int* const cs[2] = {c0, c1};
+    for (int k = 0; k < 2; ++k)
+        if (cs[k] && !(state && k < nflags && state[2 + k] != 0.f)) *cs[k] += 1;
+    if (state) {
+        bool found = false;
+        for (int k = 0; k < nflags; ++k) { found |= state[2 + k] != 0.f; state[2 + k] = 0.f; }
+        if (found) { state[0] = fmaxf(state[0] * backoff, 1.f); state[1] = 0.f; }
+        else {
+            const float t = state[1] + 1.f;
+            if (t >= (float)interval) { state[0] = fminf(state[0] * growth, 16777216.f); state[1] = 0.f; }
+            else state[1] = t;
+        }
+    }
+    if (tick_dev) {
+        const int v = *tick_dev + 1;
+        *tick_dev = v;
+        if (tick_host) __hip_atomic_store(tick_host, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+extern "C" int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int interval, int* step_dev0, int* step_dev1,
+                             int* tick_dev, int* tick_host, octa_stream_t stream) {
+    OCTA_REQUIRE(!ls_state || (nflags >= 1 && nflags <= 6 && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1), "octa_step_end: bad loss-scale arguments");
+    OCTA_REQUIRE(ls_state || step_dev0 || step_dev1 || tick_dev, "octa_step_end: nothing to do");
+    step_end_kernel<<<1, 1, 0, (hipStream_t)stream>>>(ls_state, nflags, growth, backoff, interval, step_dev0, step_dev1, tick_dev, tick_host);
+    OCTA_CHECK_LAUNCH("step_end");
+    return OCTA_OK;
+}

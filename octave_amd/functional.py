@@ -190,6 +190,7 @@ def _zeroed_f32(shape, device):
 
 # ----------------------------------------------------------------------------- packed weights
 _WEIGHT_EPOCH = 0
+_PARAM_EPOCH = 0          # bumped whenever a kernel writes parameters or BatchNorm running statistics through raw pointers
 _PACK_CACHE = {}          # (id(param), kind, dtype, groups, pad_to) -> _PackEntry  (persistent output buffers)
 _PACK_PLANS = {}          # frozenset of cache keys -> (desc table, prefix, n, total) on the device
 
@@ -203,6 +204,14 @@ def bump_weight_epoch():
     operand becomes stale until it is refreshed (individually on next use, or all at once by repack_all)."""
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
+
+
+def bump_param_epoch():
+    """A kernel moved parameter / running-statistic VALUES behind autograd's version counters (fused Adam, BatchNorm training
+    forward).  Packed operands are refreshed by repack_all; value-derived caches that are not (layers._fold_entry: conv+BN
+    folded for inference) compare this counter."""
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
 
 
 def _pack_tag(w: Tensor):
@@ -224,7 +233,7 @@ def _pack_numel(w: Tensor, kind: str, groups: int, pad_to: int) -> int:
     return 4 * Ig * pad_to      # convT: w is (CinT, CoutT, 2, 2)
 
 
-_PACK_KIND = {"fwd": 0, "dgrad": 1, "convT": 2, "fwd_dense": 3, "dgrad_dense": 4}
+_PACK_KIND = {"fwd": 0, "dgrad": 1, "convT": 2, "fwd_dense": 3, "dgrad_dense": 4, "dgrad_taps": 5}
 
 
 def _pack_desc_fill(d, kind: str, w: Tensor, out: Tensor, dtype, groups: int, pad_to: int):
@@ -315,7 +324,7 @@ def repack_all(params) -> int:
     todo = []
     for key, e in _PACK_CACHE.items():
         w = e.wref()
-        if w is None or key[0] not in ids or e.direct or e.kind not in _PACK_KIND:      # kinds without a multi-pack form refresh lazily on next use
+        if w is None or key[0] not in ids or e.direct:
             if w is not None and key[0] in ids and e.direct:
                 e.tag = _pack_tag(w)          # the parameter storage is the operand: always current
             continue
@@ -334,11 +343,13 @@ def repack_all(params) -> int:
         dev = todo[0][2].device
         tb = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         pf = torch.tensor(prefix, dtype=torch.int64, device=dev)
-        plan = (tb, pf, len(todo), total)
+        plan = (tb, pf, len(todo), total, [e.wref for _, e, _ in todo])
         if len(_PACK_PLANS) > 16:
-            _PACK_PLANS.clear()
+            # drop only plans whose parameters are gone: the device tables of the others may be baked into captured hipGraphs
+            for k in [k for k, pl in _PACK_PLANS.items() if any(r() is None for r in pl[4])]:
+                del _PACK_PLANS[k]
         _PACK_PLANS[sig] = plan
-    tb, pf, n, total = plan
+    tb, pf, n, total = plan[:4]
     lib().octa_pack_many(_p(tb), _p(pf), n, total, _st())
     for key, e, w in todo:
         e.tag = _pack_tag(w)
@@ -772,6 +783,8 @@ def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv:
         L.octa_bn_train_fwd(_p(x), nhwc_ld(x), 0, _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
                             _p(y), nhwc_ld(y), 0, rows, C, _dt(x), eps, momentum, int(relu), _p(mean), _p(invstd), _p(rm), _p(rv),
                             _p(mask), _p(_bn_ws(rows, C, x.device)), _st())
+        if rm is not None:
+            bump_param_epoch()           # running statistics moved behind their version counters
         return y, mean, invstd, x, mask
     mean = rm.float()
     invstd = torch.rsqrt(rv.float() + eps)

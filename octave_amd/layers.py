@@ -117,7 +117,8 @@ _IDENT = {}
 def _fold_entry(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     key = (id(conv.weight), id(bn.running_mean))
     w, cb = conv.weight, conv.bias
-    tag = (w._version, F_._WEIGHT_EPOCH, w.data_ptr(), bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version,
+    # _PARAM_EPOCH: the fused Adam and the BatchNorm training forward write weights / running statistics through raw pointers
+    tag = (w._version, F_._WEIGHT_EPOCH, F_._PARAM_EPOCH, w.data_ptr(), bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version,
            None if cb is None else cb._version, bn.eps)
     e = _FOLD_CACHE.get(key)
     if e is not None and e[0] == tag and e[3]() is w and e[4]() is bn:

@@ -82,7 +82,7 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.g.as_strided(p.shape, p.stride(), o)
-        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # updates APPLIED so far (Adam's t - 1), kept on the device
         # gradient buckets: (tag, lo, hi) contiguous element ranges in arena order; small groups are merged into the NEXT one
         # (a bucket may only be reduced once every group in it is complete, i.e. when its LAST group's mark has fired)
         self.buckets: List[Tuple[str, int, int]] = []
@@ -109,6 +109,16 @@ class FlatArena:
         else:
             self.buckets = [("end", 0, self.numel)]
         self._comm_bufs: Dict[int, Tensor] = {}
+
+    @property
+    def step_count(self) -> int:
+        """Number of optimiser updates applied so far (synchronises: the counter lives on the device, where a step skipped
+        for a non-finite gradient does not advance it)."""
+        return int(self.step_dev.item())
+
+    @step_count.setter
+    def step_count(self, n: int):
+        self.step_dev.fill_(int(n))
 
     # ------------------------------------------------------------------ optimiser state (checkpoint / resume)
     def state_dict(self) -> Dict:
@@ -194,32 +204,30 @@ class FlatArena:
         dist.broadcast(self.p, src)
         F_.bump_weight_epoch()
 
-    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, dyn: Optional[Tensor] = None,
-             ranges: Optional[List[Tuple[int, int]]] = None, ls_state: Optional[Tensor] = None, ls_flag: int = 2):
-        """One fused Adam launch over the arena (or one per element range in `ranges`).  `dyn` (device, 2 floats) carries the
-        bias corrections when the launch is captured in a hipGraph; the caller then advances step_count / dyn itself."""
-        if dyn is None:
-            self.step_count += 1
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+             ranges: Optional[List[Tuple[int, int]]] = None, ls_state: Optional[Tensor] = None, ls_flag: int = 2, commit: bool = True):
+        """One fused Adam launch over the arena (or one per element range in `ranges`).  The bias corrections come from the
+        device-side counter `step_dev`, so the launch is hipGraph-capturable as it stands.  `ls_state` (loss scaling): the arena
+        is checked for inf / nan first and a flagged update is skipped.  commit=False: the caller ends the step itself with
+        octa_step_end (TrainStep does: one launch for both optimisers, the loss scale and the step tick)."""
         st = torch.cuda.current_stream().cuda_stream
         if ls_state is not None:
-            # dynamic loss scaling: flag the arena (after the all-reduce: every rank sees the same infs) before the update
+            # flag the arena (after the all-reduce: every rank sees the same infs) before the update
             lib().octa_nonfinite_flag(self.g.data_ptr(), self.numel, ls_state.data_ptr() + 4 * ls_flag, st)
         for lo, hi in (ranges or [(0, self.numel)]):
             o = lo * 4
             lib().octa_adam_step(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, hi - lo, lr, betas[0],
-                                 betas[1], eps, weight_decay, max(self.step_count, 1), grad_scale, None if dyn is None else dyn.data_ptr(),
+                                 betas[1], eps, weight_decay, 0, grad_scale, self.step_dev.data_ptr(),
                                  None if ls_state is None else ls_state.data_ptr(), ls_flag, st)
+        if commit:
+            if ls_state is not None:
+                raise ValueError("FlatArena.adam(ls_state=..., commit=True): the loss-scale state is updated by octa_step_end, pass commit=False")
+            lib().octa_step_end(None, 0, 1.0, 1.0, 1, self.step_dev.data_ptr(), None, None, None, st)
         # one launch refreshes every cached packed conv operand of THIS network; nothing else went stale, so the global
         # weight epoch is left alone (bumping it here made the other network's operands look stale: ~170 redundant
         # per-weight pack launches were captured into every replayed step)
         F_.repack_all(self.params)
-
-    def advance_dyn(self, ring, betas):
-        self.step_count += 1
-        h = ring.slot()
-        h[0] = 1.0 - betas[0] ** self.step_count
-        h[1] = (1.0 - betas[1] ** self.step_count) ** 0.5
-        ring.push()
+        F_.bump_param_epoch()         # caches keyed on parameter values that are NOT refreshed above (folded conv+BN of the eval path)
 
 
 def mask_pyramid(mask: Tensor, levels: int = 5) -> List[Tensor]:
@@ -341,15 +349,18 @@ class TrainStep:
         # loss_scale: a float (static), or "dynamic" (fp16): the scale lives in device memory (8 floats, octa_hip.h), starts at
         # 65536, is halved when an optimiser finds a non-finite gradient (that optimiser skips its update) and doubled after
         # `loss_scale_interval` clean steps - all by kernels inside the step, so it survives hipGraph capture with no host sync
+        # A STATIC scale in fp16 uses the same device-side state with growth = backoff = 1: the scale never moves, but an
+        # update whose gradients hold an inf / nan is still skipped instead of writing NaN into the weights.
         self.dynamic_scale = isinstance(loss_scale, str)
         if self.dynamic_scale and loss_scale != "dynamic":
             raise ValueError(f"loss_scale must be a number or 'dynamic', got {loss_scale!r}")
-        self.loss_scale = 1.0 if self.dynamic_scale else float(loss_scale)
-        self.ls_cfg = (float(loss_scale_growth), float(loss_scale_backoff), int(loss_scale_interval))
+        self.device_scale = self.dynamic_scale or compute_dtype == torch.float16
+        self.loss_scale = 1.0 if self.device_scale else float(loss_scale)
+        self.ls_cfg = (float(loss_scale_growth), float(loss_scale_backoff), int(loss_scale_interval)) if self.dynamic_scale else (1.0, 1.0, 1)
         self.ls_state = None
-        if self.dynamic_scale:
+        if self.device_scale:
             self.ls_state = torch.zeros(8, dtype=torch.float32, device=next(net.parameters()).device)
-            self.ls_state[0] = 65536.0
+            self.ls_state[0] = 65536.0 if self.dynamic_scale else float(loss_scale)
         self.grad_comm_dtype = grad_comm_dtype
         self.seg.compute_dtype = compute_dtype
         self.discs: Dict[Optional[int], nn.Module] = {}
@@ -383,7 +394,6 @@ class TrainStep:
         defer_bn_counters(True)
         self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
-        self._dyn = None
         # eager launches with more than one rank: start each gradient bucket's all-reduce from the stage mark that completes it,
         # i.e. overlapped with the REST of the backward pass (BASELINE config 4).  Captured graphs hold no collective: there the
         # buckets are issued, in the same order, right after the segmentor graph and overlap the discriminator step instead.
@@ -496,25 +506,25 @@ class TrainStep:
             out["loss_disc"] = l_d.detach()
 
     def _scaled(self, loss: Tensor) -> Tensor:
-        if self.dynamic_scale:
+        if self.device_scale:
             return loss * self.ls_state[0:1].reshape(())        # device scalar: the captured graph follows the scale
         return loss * self.loss_scale if self.loss_scale != 1.0 else loss
 
     def _grad_scale(self) -> float:
         return 1.0 / (self.world * self.loss_scale)
 
-    def _phase_seg_update(self, dyn=None):
-        self.seg_arena.adam(self.lr, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ls_state=self.ls_state, ls_flag=2)
+    def _phase_seg_update(self):
+        self.seg_arena.adam(self.lr, self.betas, grad_scale=self._grad_scale(), ls_state=self.ls_state, ls_flag=2, commit=False)
 
-    def _phase_finish(self, disc, dyn=None):
+    def _phase_finish(self, disc):
         if self.adversarial:
-            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), dyn=dyn, ranges=self._disc_ranges[id(disc)],
-                                 ls_state=self.ls_state, ls_flag=3)
-        if self.dynamic_scale:
-            g, b, n = self.ls_cfg
-            lib().octa_loss_scale_update(F_._p(self.ls_state), 2 if self.adversarial else 1, g, b, n, F_._st())
-        # last kernel of the step: publish "step n done" to pinned host memory (paces the replayed path, see __call__)
-        lib().octa_host_tick(F_._p(self._tick.dev), F_._p(self._tick.host), F_._st())
+            self.disc_arena.adam(self.lr_disc, self.betas, grad_scale=self._grad_scale(), ranges=self._disc_ranges[id(disc)],
+                                 ls_state=self.ls_state, ls_flag=3, commit=False)
+        # last kernel of the step: commit Adam's step counters (a flagged optimiser did not step), update the loss scale and
+        # publish "step n done" to pinned host memory (paces the replayed path, see __call__)
+        g, b, n = self.ls_cfg
+        lib().octa_step_end(F_._p(self.ls_state), 2 if self.adversarial else 1, g, b, n, F_._p(self.seg_arena.step_dev),
+                            F_._p(self.disc_arena.step_dev) if self.adversarial else None, F_._p(self._tick.dev), F_._p(self._tick.host), F_._st())
         if not torch.cuda.is_current_stream_capturing():
             self._tick.launched += 1           # an eagerly launched step (training or capture warm-up); replays count in __call__
 
@@ -563,7 +573,7 @@ class TrainStep:
         """Capture the step for inputs of x's size into four hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm: segmentor
         fwd/bwd | discriminator step | segmentor Adam + operand repack | discriminator Adam) around the two all-reduces.
         Inputs are copied into static buffers on every call; the CPU random draws of the discriminator are staged through
-        _RngFeed; Adam's bias corrections come from device memory.  Call once per input resolution."""
+        _RngFeed; Adam's step counters live on the device.  Call once per input resolution."""
         dev = x.device
         cap = _Capture()
         cap.sx, cap.sys = x.clone(), ys.clone()
@@ -573,9 +583,6 @@ class TrainStep:
         if self.adversarial:
             cap.feed = _RngFeed(cap.disc, dev, self._tick)
             cap.disc.rng_feed = cap.feed
-        if self._dyn is None:
-            self._dyn = [_PinnedRing((2,), dev, self._tick) for _ in range(2)]
-            self._dyn_dev = [r.dev for r in self._dyn]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -605,10 +612,10 @@ class TrainStep:
             self._phase_discriminator(cap.att, cap.sreal, cap.out, cap.disc)
         g2b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=mode):
-            self._phase_seg_update(dyn=self._dyn_dev[0])
+            self._phase_seg_update()
         g3 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
-            self._phase_finish(cap.disc, dyn=self._dyn_dev[1])
+            self._phase_finish(cap.disc)
         cap.graphs = (g1, g2, g2b, g3)
         self._caps[int(x.shape[-1])] = cap
         return self
@@ -625,16 +632,14 @@ class TrainStep:
         out: Dict[str, Tensor] = {}
         if self.adversarial:
             cap.feed.refill()
-        self.seg_arena.advance_dyn(self._dyn[0], self.betas)
         att = self._phase_segmentor(cap.sx, cap.sys, out, cap.disc)
         self.seg_arena.all_reduce_begin(self.world, self._comm(), self.grad_comm_dtype)
         self._phase_discriminator(att, cap.sreal, out, cap.disc)
         self.seg_arena.all_reduce_end(self.world, self._comm())
-        self._phase_seg_update(dyn=self._dyn_dev[0])
+        self._phase_seg_update()
         if self.adversarial:
-            self.disc_arena.advance_dyn(self._dyn[1], self.betas)
             self.disc_arena.all_reduce(self.world)
-        self._phase_finish(cap.disc, dyn=self._dyn_dev[1])
+        self._phase_finish(cap.disc)
         return out
 
     def _load_static(self, cap: _Capture, x, ys, real_pyramid):
@@ -717,9 +722,6 @@ class TrainStep:
         if self.adversarial:
             cap.feed.refill()
         g1, g2, g2b, g3 = cap.graphs
-        self.seg_arena.advance_dyn(self._dyn[0], self.betas)
-        if self.adversarial:
-            self.disc_arena.advance_dyn(self._dyn[1], self.betas)
         g1.replay()
         # bucketed, in completion order, on the comm stream: the D step overlaps the segmentor gradient exchange
         comm = self._comm()
@@ -739,6 +741,7 @@ class TrainStep:
             self.disc_arena.all_reduce_end(self.world, comm)
         g3.replay()
         F_.bump_weight_epoch()      # the weights moved behind the pack cache's back
+        F_.bump_param_epoch()
         return cap.out
 
     def close(self):

@@ -537,53 +537,224 @@ def test_baseline_size_bf16_vs_fp32_hip(H):
         assert (d32.mean() - d16.mean()).abs().item() <= 1e-3 + 0.02 * (1 - agree)
 
 
+def test_loss_scale_mechanism_with_injected_nonfinite_gradient():
+    """The device-side loss-scale machinery on its own, with an inf / nan INJECTED into one gradient slot (no network, nothing
+    chaotic): octa_nonfinite_flag -> octa_adam_step (skips a flagged update, divides by the device scale, takes its bias
+    corrections from the device-side applied-update counter) -> octa_step_end (commits the counter only for an applied update,
+    halves / doubles the scale, clears the flags).  The applied updates must equal torch.optim.Adam stepped only on the clean
+    gradients -- what torch.cuda.amp.GradScaler does -- i.e. a skipped step does not advance the bias correction."""
+    from octave_amd._lib import lib
+    from octave_amd.train import FlatArena
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(37,), (16, 8, 3, 3), (5, 7)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    twin = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = torch.optim.Adam(twin, lr=1e-2)
+    ar = FlatArena(list(ps))
+    ls = torch.zeros(8, device=dev)
+    ls[0] = 256.0
+    L, stm = lib(), torch.cuda.current_stream().cuda_stream
+    growth, backoff, interval = 2.0, 0.5, 2
+
+    def run(poison=None, static=False):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for p, gr in zip(ps, grads):
+            p.grad.copy_(gr.to(dev) * float(ls[0]))                 # what a backward pass of the scaled loss leaves in the arena
+        if poison is not None:
+            ar.g[ar.offsets[ar.names[1]] + 11] = poison              # one slot of the conv weight's gradient
+        before = ar.p.clone()
+        ar.adam(1e-2, ls_state=ls, ls_flag=2, commit=False)
+        cfg = (1.0, 1.0, 1) if static else (growth, backoff, interval)
+        L.octa_step_end(ls.data_ptr(), 1, *cfg, ar.step_dev.data_ptr(), None, None, None, stm)
+        torch.cuda.synchronize()
+        if poison is None:
+            for t, gr in zip(twin, grads):
+                t.grad = gr.to(dev)
+            opt.step()
+        return before
+
+    run()                                                             # clean: applied
+    assert ar.step_count == 1 and ls.tolist()[:3] == [256.0, 1.0, 0.0]
+    b = run(float("inf"))                                            # injected inf: skipped, scale halved, tracker reset
+    assert torch.equal(b, ar.p) and ar.step_count == 1 and ls.tolist()[:4] == [128.0, 0.0, 0.0, 0.0]
+    b = run(float("nan"))
+    assert torch.equal(b, ar.p) and ar.step_count == 1 and float(ls[0]) == 64.0
+    run(); run()                                                      # two clean steps = the interval: the scale doubles
+    assert ar.step_count == 3 and ls.tolist()[:2] == [128.0, 0.0]
+    b = run(float("-inf"), static=True)                              # static scale: the update is still skipped, the scale stays
+    assert torch.equal(b, ar.p) and ar.step_count == 3 and float(ls[0]) == 128.0
+    run(static=True)
+    assert ar.step_count == 4 and float(ls[0]) == 128.0
+    for p, t in zip(ps, twin):                                        # four applied updates == four torch.optim.Adam steps
+        assert torch.allclose(p.detach(), t.detach(), rtol=2e-5, atol=2e-6), (p.detach() - t.detach()).abs().max().item()
+    # commit=True (no loss scaling): the arena advances its own counter
+    ar2 = FlatArena([torch.nn.Parameter(torch.ones(8, device=dev))])
+    ar2.params[0].grad.fill_(1.0)
+    ar2.adam(1e-2)
+    assert ar2.step_count == 1
+
+
 def test_dynamic_loss_scale_fp16_skips_and_backs_off():
     """TrainStep(loss_scale="dynamic") in fp16: the scale lives on the device; a step whose gradients overflow is skipped by both
-    optimisers (parameters bit-identical) and halves the scale, clean steps count up and double it after the interval; the
-    state survives a captured-graph replay and a state_dict round trip."""
-    from architectures.models.octa import OctaScribbleNet
+    optimisers (parameters bit-identical, Adam counters unchanged) and halves the scale, clean steps count up and double it after
+    the interval; the state survives a captured-graph replay and a state_dict round trip.
+    Deterministic inputs and weights.  The overflow is FORCED (a scale of 2^30 makes every fp16 gradient inf); the clean steps
+    run at a scale of 8: tools/fp16_overflow_probe.py (profiles/r03_fp16_overflow_probe.txt) measured unscaled activation
+    gradients of up to ~130 at the stem for tiny-batch inputs (B=2, 64^2: the 2-sample split-attention bn1 and the 8-sample
+    encoder_4 BatchNorms amplify the gradient ~100x on the way back), so "scale 1024 is clean" does not hold at this size,
+    while at B=16, 400^2 nothing overflows up to 2^16."""
     from octave_amd.train import TrainStep, mask_pyramid
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    B, H = 2, 64
-    net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
+    B, H = 4, 64
+    net = _net(B, H, dev, seed_fill=False)
+    x, ys, real = _inputs(B, H, dev)
+    pyr = mask_pyramid(real)
     st = TrainStep(net, lr=1e-4, compute_dtype=torch.float16, loss_scale="dynamic", loss_scale_interval=3)
-    x = torch.rand(B, 3, H, H, device=dev)
-    ys = (torch.rand(B, 2, H, H, device=dev) > 0.7).float()
-    pyr = mask_pyramid((torch.rand(B, 2, H, H, device=dev) > 0.5).float())
-    assert float(st.ls_state[0]) == 65536.0
-    # 1) force an overflow: with a scale of 2^24 * 64 the fp16 gradients are inf
-    st.ls_state[0] = 2.0 ** 30
-    before = [p.detach().clone() for p in net.parameters()]
-    out = st(x, ys, pyr)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out["loss_seg"]).all()
-    assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters())), "an overflowed step must not move the weights"
-    assert float(st.ls_state[0]) == 2.0 ** 29 and float(st.ls_state[1]) == 0.0 and float(st.ls_state[2:4].abs().sum()) == 0.0
-    # 2) clean steps at a sane scale: weights move, the tracker counts, the third clean step doubles the scale
-    st.ls_state[0] = 1024.0
-    out = st(x, ys, pyr)
-    torch.cuda.synchronize()
-    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
-    assert float(st.ls_state[0]) == 1024.0 and float(st.ls_state[1]) == 1.0
-    st(x, ys, pyr); st(x, ys, pyr)
-    torch.cuda.synchronize()
-    assert float(st.ls_state[0]) == 2048.0 and float(st.ls_state[1]) == 0.0
-    for p in net.parameters():
-        assert torch.isfinite(p).all()
-    # 3) captured graphs follow the device-side scale; the checkpoint carries it
-    st.capture(x, ys, pyr)
-    st.launch = "graph"
-    st.ls_state[0] = 2.0 ** 30
-    snap = [p.detach().clone() for p in net.parameters()]
-    st(x, ys, pyr)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
-    assert float(st.ls_state[0]) == 2.0 ** 29
-    sd = st.state_dict()
-    assert float(sd["loss_scale_state"][0]) == 2.0 ** 29
-    st.ls_state[0] = 1.0
-    st.load_state_dict(sd)
-    assert float(st.ls_state[0]) == 2.0 ** 29
-    st.close()
+    try:
+        assert float(st.ls_state[0]) == 65536.0
+        # 1) force an overflow
+        st.ls_state[0] = 2.0 ** 30
+        before = [p.detach().clone() for p in net.parameters()]
+        out = st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["loss_seg"]).all()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters())), "an overflowed step must not move the weights"
+        assert float(st.ls_state[0]) == 2.0 ** 29 and float(st.ls_state[1]) == 0.0 and float(st.ls_state[2:4].abs().sum()) == 0.0
+        assert st.seg_arena.step_count == 0 and st.disc_arena.step_count == 0, "a skipped update must not advance Adam's bias correction"
+        # 2) clean steps at a safe scale: weights move, the tracker counts, the third clean step doubles the scale
+        st.ls_state[0] = 8.0
+        out = st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+        assert float(st.ls_state[0]) == 8.0 and float(st.ls_state[1]) == 1.0
+        st(x, ys, pyr); st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert float(st.ls_state[0]) == 16.0 and float(st.ls_state[1]) == 0.0
+        assert st.seg_arena.step_count == 3 and st.disc_arena.step_count == 3
+        for p in net.parameters():
+            assert torch.isfinite(p).all()
+        # 3) captured graphs follow the device-side scale; the checkpoint carries it
+        st.capture(x, ys, pyr)
+        n0 = st.seg_arena.step_count
+        st.launch = "graph"
+        st.ls_state[0] = 2.0 ** 30
+        snap = [p.detach().clone() for p in net.parameters()]
+        st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
+        assert float(st.ls_state[0]) == 2.0 ** 29 and st.seg_arena.step_count == n0
+        st.ls_state[0] = 8.0
+        st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert st.seg_arena.step_count == n0 + 1 and any(not torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
+        sd = st.state_dict()
+        assert float(sd["loss_scale_state"][0]) == 8.0
+        st.ls_state[0] = 1.0
+        st.load_state_dict(sd)
+        assert float(st.ls_state[0]) == 8.0
+    finally:
+        st.close()
 
+
+def test_static_loss_scale_fp16_skips_nonfinite_update():
+    """A STATIC loss scale in fp16 goes through the same device-side check: an overflowed step leaves the weights alone (it used
+    to write NaN into them) and the scale does not move."""
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, H = 4, 64
+    net = _net(B, H, dev, seed_fill=False)
+    x, ys, real = _inputs(B, H, dev)
+    pyr = mask_pyramid(real)
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.float16, loss_scale=2.0 ** 30)
+    try:
+        before = [p.detach().clone() for p in net.parameters()]
+        st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+        assert float(st.ls_state[0]) == 2.0 ** 30 and st.seg_arena.step_count == 0
+        st.ls_state[0] = 8.0
+        st(x, ys, pyr)
+        torch.cuda.synchronize()
+        assert st.seg_arena.step_count == 1 and float(st.ls_state[0]) == 8.0
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    finally:
+        st.close()
+
+
+def test_packed_operands_follow_the_optimiser_eager_and_graph():
+    """Every cached packed conv operand -- including the tap-major data-gradient operand of the discriminator's 2-channel k4 s2
+    conv_0 (kind dgrad_taps), which had no multi-pack form and stayed at its initial values -- equals a fresh pack of the current
+    weights after eager steps AND after replayed steps (the refresh is part of the captured Adam graph)."""
+    from octave_amd import functional as F_
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, H = 4, 64
+    net = _net(B, H, dev, seed_fill=False)
+    x, ys, real = _inputs(B, H, dev)
+    pyr = mask_pyramid(real)
+    st = TrainStep(net, lr=1e-3, compute_dtype=torch.bfloat16)
+
+    def check(tag):
+        kinds, bad = set(), []
+        for key, e in list(F_._PACK_CACHE.items()):
+            w = e.wref()
+            if w is None or e.direct:
+                continue
+            kinds.add(e.kind)
+            cached = e.out.clone()
+            F_.bump_weight_epoch()                       # force a fresh pack into the entry's buffer
+            fresh = F_._packed(w, e.kind, e.dtype, e.groups, e.pad_to)
+            if not torch.equal(cached.view(torch.int16), fresh.view(torch.int16)):
+                bad.append((tag, e.kind, tuple(w.shape)))
+        return kinds, bad
+    try:
+        st(x, ys, pyr); st(x, ys, pyr)
+        torch.cuda.synchronize()
+        kinds, bad = check("eager")
+        assert "dgrad_taps" in kinds and {"fwd", "dgrad", "convT"} <= kinds, kinds
+        assert not bad, bad
+        st.capture(x, ys, pyr)
+        st.launch = "graph"
+        for _ in range(3):
+            st(x, ys, pyr)
+        torch.cuda.synchronize()
+        kinds, bad = check("graph")
+        assert not bad, bad
+    finally:
+        st.close()
+
+
+def test_eval_fold_cache_follows_eager_training():
+    """train -> eval(no_grad) -> train (eager) -> eval: the inference path's folded conv+BatchNorm operands must follow the
+    weights and running statistics the fused kernels moved through raw pointers.  Reference for each eval: the same network's
+    UNFOLDED eval forward (grad enabled: conv and BatchNorm-apply as separate launches on the live tensors)."""
+    from octave_amd.train import TrainStep, mask_pyramid
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, H = 4, 64
+    net = _net(B, H, dev, seed_fill=False)
+    x, ys, real = _inputs(B, H, dev)
+    pyr = mask_pyramid(real)
+    st = TrainStep(net, lr=1e-2, compute_dtype=torch.float32)
+
+    def evals():
+        net.eval()
+        with torch.no_grad():
+            folded = net.segmentor(x)[1].float().clone()
+        unfolded = net.segmentor(x)[1].detach().float().clone()
+        net.train()
+        return folded, unfolded
+    try:
+        st(x, ys, pyr)
+        f0, u0 = evals()
+        assert (f0 - u0).abs().max().item() <= 2e-4 * u0.abs().max().item() + 1e-5
+        st(x, ys, pyr); st(x, ys, pyr)
+        f1, u1 = evals()
+        assert (u1 - u0).abs().max().item() > 1e-3 * u0.abs().max().item(), "the training steps must have changed the network"
+        assert (f1 - u1).abs().max().item() <= 2e-4 * u1.abs().max().item() + 1e-5, ((f1 - u1).abs().max().item(), (f1 - f0).abs().max().item())
+    finally:
+        st.close()
