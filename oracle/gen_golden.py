@@ -487,6 +487,97 @@ def gen_unet304():
     _save("unet_304.npz", d)
 
 
+
+def _adversarial_step_fixture(B, H, d, noise_seed=2024):
+    """One full adversarial step on the reference modules at (B, H): the four loss parts, both losses and every
+    gradient norm, in fp32 and (same modules, .double()) in float64."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    u = hash_input((B, 1, H, H), 4321)
+    ys = torch.zeros(B, 2, H, H)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    dense = (hash_input((B, H, H), 999) > 0.8).long()
+    real = F.one_hot(dense, 2).permute(0, 3, 1, 2).float()
+    torch.manual_seed(noise_seed)
+    for c in range(3):
+        d[f"noise{c}"] = _np(torch.normal(mean=0.0, std=0.2, size=(H, H)))
+        d[f"uniform{c}"] = _np(torch.FloatTensor(1).uniform_(0, 1))
+    for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
+        fill_state_dict(net.state_dict())
+        net = net.to(dt).train()
+        xx, yy = x.to(dt), ys.to(dt)
+        real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous().to(dt) for i in range(5)]
+        torch.manual_seed(noise_seed)
+        att, agg, _ = net.segmentor(xx)
+        p = F.softmax(agg, dim=1)
+        parts = [net.supervised_loss(p, yy), DiceLoss()(p, yy), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
+        l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
+        net.zero_grad()
+        l_seg.backward()
+        d["l_seg" + tag] = _np(l_seg)
+        d["parts" + tag] = np.array([float(v) for v in parts])
+        for k, pr in net.segmentor.named_parameters():
+            if pr.grad is not None:
+                d[f"seg_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+        net.zero_grad()
+        l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
+        l_d.backward()
+        d["l_d" + tag] = _np(l_d)
+        for k, pr in net.discriminator.named_parameters():
+            d[f"disc_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+
+
+def gen_trainstep304():
+    """BASELINE configs[0] end to end: the full adversarial step at B = 2, 304 x 304 on the reference modules (fp32 + float64
+    twin): loss parts, both losses, every gradient norm and the consumed CPU random draws."""
+    d = {}
+    _adversarial_step_fixture(2, 304, d)
+    _save("trainstep_304.npz", d)
+
+
+def gen_round3():
+    """(1) the stand-alone ResNet checkpoint layout of resnest50() (extra/resnest.py:451-459: what resnest50-528c19ca.pth
+    holds and what load_state_dict(torch.load(model_path)) expects), dumped from the reference; (2) BACKWARD fixtures for the two
+    dual-head U-Nets (segmentor/compose.py:233-362, 365-527) at B = 3, 48 x 48, train mode: cotangents are closed-form
+    (hash_input, seeds 7100 + output index), every parameter's gradient norm is stored in fp32 and float64, a few gradients
+    in full."""
+    from architectures.extra.resnest import resnest50
+    from architectures.segmentor.compose import ResnestUnetParallelHead, ResnestUnetParallelHeadAttentionGate
+    d = {}
+    sd = resnest50().state_dict()
+    d["layout/resnest50/keys"] = np.array(list(sd.keys()))
+    d["layout/resnest50/shapes"] = np.array([",".join(str(v) for v in t.shape) for t in sd.values()])
+    B, H = 3, 48
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    full = ("decoder_4_c.conv.0.weight", "decoder_0_c.conv.3.conv.bias", "upsampling_4_c.up.weight", "upsampling_0_c.up.bias", "fc_c.weight", "fc_c.bias",
+            "fc.weight", "aag_3_c.conv1.weight", "aag_0_c.conv1.bias", "aag_3.conv1.weight", "encoder_4.2.bn3.bias", "encoder_1.0.conv1.weight",
+            "encoder_0_1_2.0.0.weight", "decoder_1_c.conv.0.weight", "upsampling_1_c.up.weight", "aag_1_c.conv1.weight")
+    for tag, cls, kw in (("ph", ResnestUnetParallelHead, {}), ("phag", ResnestUnetParallelHeadAttentionGate, {"gating_leveL": 3})):
+        for suffix, dt in (("", torch.float32), ("_f64", torch.float64)):
+            m = cls(2, False, **kw)
+            fill_state_dict(m.state_dict())
+            m = m.to(dt).train()
+            out = m(x.to(dt))
+            outs = [out] if tag == "ph" else [out[1], *out[0][0], *out[0][1]]
+            loss = 0
+            for i, o in enumerate(outs):
+                loss = loss + (o * hash_input(tuple(o.shape), 7100 + i, -1.0, 1.0).to(dt)).sum()
+            loss.backward()
+            d[f"{tag}/loss{suffix}"] = _np(loss)
+            d[f"{tag}/n_out"] = np.array([len(outs)])
+            for k, pr in m.named_parameters():
+                if pr.grad is not None:
+                    d[f"{tag}/gradnorm{suffix}/{k}"] = _np(pr.grad.double().norm())
+                    if suffix == "" and k in full:
+                        d[f"{tag}/grad/{k}"] = _np(pr.grad)
+            if suffix == "":
+                d[f"{tag}/nograd_keys"] = np.array([k for k, pr in m.named_parameters() if pr.grad is None])
+    _save("round3.npz", d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}")
@@ -494,7 +585,7 @@ if __name__ == "__main__":
     _install_standins()
     torch.set_num_threads(8)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304"]
+    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304", "trainstep304", "round3"]
     if "blocks" in which:
         gen_blocks()
     if "losses" in which:
@@ -509,3 +600,7 @@ if __name__ == "__main__":
         gen_extras()
     if "unet304" in which:
         gen_unet304()
+    if "trainstep304" in which:
+        gen_trainstep304()
+    if "round3" in which:
+        gen_round3()
