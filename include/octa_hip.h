@@ -157,7 +157,8 @@ typedef struct octa_wgrad_job {
 } octa_wgrad_job;
 int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, octa_stream_t stream);
 /* Which kernel family octa_conv2d_wgrad_batch runs this job on: 1 = batched 256(N)x128(K) slabs, 2 = batched 128x256
- * slabs, 0 = the single-problem kernels (host-side query; lets the caller group a queue so that one call = one family).
+ * slabs, 3 = batched 256x256 tiles (wgrad9), 0 = the single-problem kernels (host-side query; lets the caller group a queue so
+ * that one call = one family).
  * Not a status code. */
 size_t octa_wgrad_job_class(const octa_wgrad_job* job_host);
 /* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
@@ -440,6 +441,10 @@ int octa_loss_scale_update(float* state, int nflags, float growth, float backoff
  * octa_host_tick's (optional: tick_dev += 1, published to tick_host). */
 int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int interval, int32_t* step_dev0,
                   int32_t* step_dev1, int32_t* tick_dev, int32_t* tick_host, octa_stream_t stream);
+
+/* Tuning switches (process-wide; benchmarks and A/B tests).  key 1: which tile families octa_conv2d_wgrad_batch may use,
+ * bit 0 = 256x128 / 128x256 (wgrad8), bit 1 = 256x256 (wgrad9); default 3. */
+int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);

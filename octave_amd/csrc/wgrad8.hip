@@ -317,6 +317,296 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgBatch batch) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad9: 256(N) x 256(K) output tile per workgroup (round 3).  Same batch interface, DMA roles, zero page and epilogue as
+// wgrad8; what changed, and why:
+//   * the tile is twice as big and a stage is 32 pixel rows (4 ring slots of 32 KB): per FLOP a wave issues 25 % fewer
+//     transposed LDS reads and 33 % fewer LDS-DMA instructions -- wgrad8 was bound by instruction ISSUE (two waves share a
+//     SIMD's vector issue port with their own MFMAs), not by the matrix pipe;
+//   * v_mfma_f32_32x32x16: half as many MFMA instructions for the same tile, i.e. half the issue slots they hold, and the
+//     natural software-pipelining unit becomes a k16 half-stage of 8 MFMAs whose 24 fragment registers are double-buffered
+//     ACROSS the stage barrier (the first fragments of stage s+1 are fetched under the last MFMAs of stage s), so no LDS
+//     latency is exposed after the barrier; accumulators 128 + fragments 48 registers per lane;
+//   * a 3x3 layer now has 18 (not 36) K-tiles per pixel range, which fit the 32 CUs of one XCD: the tiles that stream the same
+//     dy rows and the same (tap-shifted) x rows run side by side behind one L2.
+// LDS image: rows of 512 B (256 channels); the 32-byte pair index of row m is XOR-ed with f(m) = (m & 3) << 1, which sends the
+// 4 rows x 2 pairs that one 32-lane half of a 32x32x16 transposed read touches to 8 distinct 32-byte slots of the 256-byte
+// bank row (conflict-free); the same involution is applied to the per-lane SOURCE chunk of the lane-linear LDS-DMA image.
+typedef __attribute__((ext_vector_type(16))) float wg_f32x16_t;
+template <int F16> struct WgMma32;
+template <> struct WgMma32<0> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, wg_f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8_t, a), __builtin_bit_cast(wg_bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct WgMma32<1> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, wg_f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8_t, a), __builtin_bit_cast(wg_f16x8_t, b), c, 0, 0, 0);
+    }
+};
+// fragments of one k16 half-stage: 4 A blocks (32 output channels each) + 2 B blocks (32 taps x channels each), two transposed
+// 8-byte reads per block (pixel rows 8h .. 8h+3 and 8h+4 .. 8h+7 of the half-stage, h = lane >> 5)
+template <int HS>
+__device__ __forceinline__ void wg9_load_half(const unsigned (&aa)[4], const unsigned (&ba)[2], wg_u32x2_t (&af)[4][2], wg_u32x2_t (&bf)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i][0] = wg_tr<HS * 8192>(aa[i]); af[i][1] = wg_tr<HS * 8192 + 2048>(aa[i]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { bf[j][0] = wg_tr<HS * 8192>(ba[j]); bf[j][1] = wg_tr<HS * 8192 + 2048>(ba[j]); }
+}
+__device__ __forceinline__ void wg9_wait_frags(wg_u32x2_t (&af)[4][2], wg_u32x2_t (&bf)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]),
+                   "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[1][0]), "+v"(bf[1][1])
+                 :: "memory");
+}
+template <int F16>
+__device__ __forceinline__ void wg9_mma_half(const wg_u32x2_t (&af)[4][2], const wg_u32x2_t (&bf)[2][2], wg_f32x16_t (&acc)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            WgMma32<F16>::run(make_uint4(af[i][0].x, af[i][0].y, af[i][1].x, af[i][1].y), make_uint4(bf[j][0].x, bf[j][0].y, bf[j][1].x, bf[j][1].y), acc[i][j]);
+}
+
+// ABL: timing-only ablation builds (tools/wgrad_micro.py "ablate"; results are wrong by construction): 1 = no epilogue atomics,
+// 2 = no LDS-DMA after the prologue, 4 = no MFMAs, 8 = no transposed LDS reads
+template <int F16, int STAGGER, int ABL = 0>
+__global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
+    constexpr int BN = 256, BK = 256, MT = 32, SLOTS = 4;
+    constexpr int RB = 512, IMG = MT * RB, SBYTES = 2 * IMG;       // LDS row bytes, bytes of one stage image (dy or x), bytes of a ring slot
+    constexpr int LPR = 32, RPI = 2, IPW = 2;                      // lanes per row, rows per DMA instruction, instructions per wave and image
+    constexpr int LPT = 2 * IPW;                                   // DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SLOTS * SBYTES + BN * 4];
+    float* const sBias = (float*)(smem + SLOTS * SBYTES);
+
+    // ---- which problem / tile is this workgroup (XCD-contiguous order over the whole launch; within a problem the K-tiles of
+    // one pixel range are consecutive, so the tiles that share dy / x rows sit on one XCD)
+    const int total = gridDim.x, Lb = blockIdx.x;
+    const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
+    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jq;
+    int pi = 0;
+    for (int i = 1; i < batch.n; ++i) if (batch.p[i].blockStart <= Lp) pi = i;
+    const WgProb& Pk = batch.p[pi];
+    const int tilesN = Pk.tilesN, tilesK = Pk.tilesK, groups = Pk.groups, mPerSplit = Pk.mPerSplit, Mtot = Pk.M;
+    const int Ng = Pk.Ng, Kpad = Pk.Kpad, Cg = Pk.Cg, CgReal = Pk.CgReal, KW = Pk.KW;
+    const int H = Pk.H, W = Pk.W, OH = Pk.OH, OW = Pk.OW, stride = Pk.stride, pad = Pk.pad;
+    const int ldx = Pk.ldx, ldy = Pk.ldy;
+    const unsigned short* const xbase = Pk.x;
+    const unsigned short* const dybase = Pk.dy;
+    int bid = Lp - Pk.blockStart;
+    const int nt = bid % tilesN; bid /= tilesN;
+    const int kt = bid % tilesK; bid /= tilesK;
+    const int g = bid % groups;
+    const int sp = bid / groups;
+    const int n0 = nt * BN, k0 = kt * BK;
+    const int mbeg = (ABL & 16) ? 0 : sp * mPerSplit;              // ABL 16: every workgroup streams pixel range 0 (all L2 hits)
+    const int mend = min(Mtot, mbeg + mPerSplit);
+    const int nsteps = (mend - mbeg + MT - 1) / MT;
+    if (nsteps <= 0) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave >> 2, wk = wave & 3;                       // 2 x 4 waves of 128(N) x 64(K)
+    const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
+
+    // ---- DMA roles (both images have the same geometry): instruction i of this wave fills LDS rows (i*8 + wave)*2 + lane/32
+    const int drow = wave * RPI + lane / LPR;
+    const int dpos = lane % LPR;
+    const int df_ = (drow & 3) << 1;
+    const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
+    const bool pvalid = (n0 + dchunk * 8) < Ng;
+    const unsigned long pstep = pvalid ? (unsigned long)((long)MT * ldy * 2) : 0ul;
+    unsigned long pptr[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+        pptr[i] = pvalid ? (unsigned long)(dybase + ((long)(mbeg + drow + i * 8 * RPI) * ldy + Pk.yoff + g * Ng + n0 + dchunk * 8)) : zaddr;
+    const int kel = k0 + dchunk * 8;
+    const bool kvalid = kel < Kpad;
+    const int qtap = kel / Cg, qcc = kel - qtap * Cg;
+    const int qkh = qtap / KW, qkw = qtap - qkh * KW;
+    const int qdh = qkh - pad, qdw = qkw - pad;
+    const unsigned long qbase = (unsigned long)(xbase + (Pk.xoff + g * CgReal + qcc));
+    const bool plain = (Pk.KH == 1 && KW == 1 && pad == 0 && stride == 1);   // 1x1: input pixel == output pixel
+    const int ldx2 = ldx * 2;
+    const int dq = MT / OW, dr = MT - dq * OW;               // a stage advances the output pixel by dq rows + dr columns
+    const int sdr = stride * dr, sdq = stride * dq, OWs = OW * stride, OHs = OH * stride;
+    const int thrW = OWs + qdw, thrH = OHs + qdh;
+    const int dpix = sdq * W + sdr, cW = stride * W - OWs, cH = H * W - OHs * W;
+    int qih[IPW], qiw[IPW], qpix[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int m = mbeg + drow + i * 8 * RPI;
+        const int ow = m % OW, tq = m / OW, oh = tq % OH, b = tq / OH;
+        qih[i] = oh * stride + qdh; qiw[i] = ow * stride + qdw;
+        qpix[i] = plain ? m : (b * H + qih[i]) * W + qiw[i];
+    }
+
+    const unsigned sbase = wg_lds_addr(smem);
+    // one LDS-DMA instruction each, branch-free (invalid rows / taps / channels read the zero page): P = dy rows, Q = x rows of this lane's tap
+    auto issueP = [&](int i, int slot, int mcur) {
+        const bool ok = (mcur + drow + i * 8 * RPI) < mend;
+        const unsigned long src = ok ? pptr[i] : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + (i * 8 + wave) * 1024)));
+        pptr[i] += pstep;
+    };
+    auto issueQ = [&](int i, int slot, int mcur) {
+        const bool ok = kvalid & ((mcur + drow + i * 8 * RPI) < mend) & ((unsigned)qih[i] < (unsigned)H) & ((unsigned)qiw[i] < (unsigned)W);
+        const unsigned off = (unsigned)__mul24(qpix[i], ldx2);              // pixel index < 2^23, ldx2 < 2^17: exact in 24 x 24 bits
+        const unsigned long a = qbase + (unsigned long)off;
+        const unsigned long src = ok ? a : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + IMG + (i * 8 + wave) * 1024)));
+        qiw[i] += sdr;
+        const bool c1 = qiw[i] >= thrW;
+        qiw[i] -= c1 ? OWs : 0;
+        qih[i] += sdq + (c1 ? stride : 0);
+        const bool c2 = qih[i] >= thrH;
+        qih[i] -= c2 ? OHs : 0;
+        qpix[i] += dpix + (c1 ? cW : 0) + (c2 ? cH : 0);
+    };
+    auto issue = [&](int slot, int mcur) { issueP(0, slot, mcur); issueP(1, slot, mcur); issueQ(0, slot, mcur); issueQ(1, slot, mcur); };
+
+    wg_f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- transposed fragment addressing (slot 0, half-stage 0): 16-lane group gq = lane >> 4 reads pixel rows 8 (gq >> 1) + (r >> 2)
+    // (+ 4 for the second read) of channel pair 2 * block + (gq & 1); f(row) = ((r >> 2) & 3) << 1 is a lane constant
+    const int r = lane & 15, gq = lane >> 4;
+    const int frow = 8 * (gq >> 1) + (r >> 2);
+    const int fr = ((r >> 2) & 3) << 1;
+    const int cb = (r & 3) * 8;
+    unsigned abase[4], bbase[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = sbase + (unsigned)(frow * RB + ((((wn * 4 + i) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = sbase + (unsigned)(IMG + frow * RB + ((((wk * 2 + j) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+
+    // ---- fused bias gradient (k-tile 0 only): thread = (16-byte chunk position, rows brow and brow + 16) of the dy stage image
+    float* const dbias = Pk.dbias;
+    const bool do_bias = (dbias != nullptr) && (kt == 0);
+    const int brow = t / LPR, bpos = t % LPR;
+    const int bf_ = (brow & 3) << 1;
+    const int bchunk = (((bpos >> 1) ^ bf_) << 1) | (bpos & 1);
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    if (do_bias && t < BN) sBias[t] = 0.f;
+
+    issue(0, mbeg);
+    if (nsteps > 1) issue(1, mbeg + MT);
+    if (nsteps > 2) issue(2, mbeg + 2 * MT);
+    if (nsteps > 2) wg_wait_vmcnt<2 * LPT>(); else if (nsteps > 1) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    wg_u32x2_t afX[4][2], bfX[2][2], afY[4][2], bfY[2][2];
+    if (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { afY[i][0] = (wg_u32x2_t){0x3f803f80u, 0x3f803f80u}; afY[i][1] = afY[i][0]; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { bfY[j][0] = (wg_u32x2_t){0x3f803f80u, 0x3f803f80u}; bfY[j][1] = bfY[j][0]; }
+    }
+    {
+        unsigned aa[4], ba[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aa[i] = abase[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ba[j] = bbase[j];
+        wg9_load_half<0>(aa, ba, afX, bfX);
+        wg9_wait_frags(afX, bfX);
+    }
+    // One MFMA, then the instructions that ride in its shadow (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles and holds the
+    // vector issue port for 8 of them): two transposed reads of the NEXT half-stage's fragments, or one LDS-DMA instruction of
+    // stage it + 3 with its address arithmetic.  The order is pinned (sched_barrier): issuing all 12 reads in front of the 8
+    // MFMAs, as the first version did, left the matrix pipe idle for ~150 cycles per half-stage.
+#define WG9_MMA(AF, BF, i, j)                                                                                                              \
+    if (!(ABL & 4)) WgMma32<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[i][j])
+#define WG9_TR(F, i, HS, ad)                                                                                                               \
+    if (!(ABL & 8)) { F[i][0] = wg_tr<HS * 8192>(ad); F[i][1] = wg_tr<HS * 8192 + 2048>(ad); }
+#define WG9_SB __builtin_amdgcn_sched_barrier(0)
+    for (int it = 0; it < nsteps; ++it) {
+        const int rem = nsteps - 1 - it;                            // stages after this one
+        const bool more = !(ABL & 2) && rem >= 3;                   // stage it + 3 goes into the slot of stage it - 1 (its reads ended before the last barrier)
+        const int s3 = (it + 3) & (SLOTS - 1), m3 = mbeg + (it + 3) * MT;
+        const unsigned so = (unsigned)((it & (SLOTS - 1)) * SBYTES);
+        const unsigned sn = (unsigned)(((it + 1) & (SLOTS - 1)) * SBYTES);
+        if (do_bias) {
+            const unsigned char* sP = smem + so;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const uint4 v = *(const uint4*)(sP + (brow + jj * 16) * RB + bpos * 16);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += WgMma<F16>::cvt((unsigned short)(w4[e] & 0xffffu));
+                    bsum[2 * e + 1] += WgMma<F16>::cvt((unsigned short)(w4[e] >> 16));
+                }
+            }
+        }
+        WG9_SB;
+        // ---- half-stage 0 of stage it (fragments X); fetch half-stage 1 (Y); first half of the DMA
+        WG9_MMA(afX, bfX, 0, 0); WG9_TR(afY, 0, 1, abase[0] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 1, 0); WG9_TR(afY, 1, 1, abase[1] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 2, 0); WG9_TR(afY, 2, 1, abase[2] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 3, 0); WG9_TR(afY, 3, 1, abase[3] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 0, 1); WG9_TR(bfY, 0, 1, bbase[0] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 1, 1); WG9_TR(bfY, 1, 1, bbase[1] + so); WG9_SB;
+        WG9_MMA(afX, bfX, 2, 1); if (more) issueP(0, s3, m3); WG9_SB;
+        WG9_MMA(afX, bfX, 3, 1); if (more) issueP(1, s3, m3); WG9_SB;
+        if (ABL & 2) wg_wait_vmcnt<0>();
+        else if (rem >= 3) wg_wait_vmcnt<LPT + 2>(); else if (rem == 2) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();   // stage it + 1 has landed (this wave's part)
+        wg9_wait_frags(afY, bfY);                                   // ... and every LDS read of stage it has returned
+        __builtin_amdgcn_s_barrier();
+        WG9_SB;
+        // ---- half-stage 1 (fragments Y); fetch half-stage 0 of stage it + 1 (X); second half of the DMA
+        WG9_MMA(afY, bfY, 0, 0); WG9_TR(afX, 0, 0, abase[0] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 1, 0); WG9_TR(afX, 1, 0, abase[1] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 2, 0); WG9_TR(afX, 2, 0, abase[2] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 3, 0); WG9_TR(afX, 3, 0, abase[3] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 0, 1); WG9_TR(bfX, 0, 0, bbase[0] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 1, 1); WG9_TR(bfX, 1, 0, bbase[1] + sn); WG9_SB;
+        WG9_MMA(afY, bfY, 2, 1); if (more) issueQ(0, s3, m3); WG9_SB;
+        WG9_MMA(afY, bfY, 3, 1); if (more) issueQ(1, s3, m3); WG9_SB;
+        wg9_wait_frags(afX, bfX);
+        WG9_SB;
+    }
+#undef WG9_MMA
+#undef WG9_TR
+#undef WG9_SB
+
+    if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
+        __syncthreads();
+        if (t < BN && n0 + t < Ng) atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+    }
+    // ---- epilogue: 32x32 accumulator block (i, j): column c = lane & 31, row n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5); one register
+    // of all lanes = two 128-byte runs along Cin of the channels-last gradient tensor (full-rate float atomics)
+    float* const dw = Pk.dw;
+    const long s_o = Pk.s_o, s_i = Pk.s_i, s_h = Pk.s_h, s_w = Pk.s_w;
+    const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wk * 64 + j * 32 + lc;
+        if (k >= Kpad) continue;
+        const int tap = k / Cg, ci = k - tap * Cg;
+        if (ci >= CgReal) continue;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const long koff = (long)ci * s_i + (long)kh * s_h + (long)kw * s_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (ABL & 1) { asm volatile("" :: "v"(acc[i][j][e])); continue; }
+                if (n < Ng) atomicAdd(dw + (long)(g * Ng + n) * s_o + koff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static unsigned wg_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
@@ -393,9 +683,80 @@ static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
     return OCTA_OK;
 }
 
+static int g_wg9_ablate = 0;           // octa_tuning_set(2, mask): timing-only ablation build of wgrad9 (tools/wgrad_micro.py)
+// 256 x 256 tiles (wgrad9): one launch per batch, 32-pixel stages
+template <int F16>
+static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
+    size_t i0 = 0;
+    while (i0 < plans.size()) {
+        const size_t i1 = std::min(plans.size(), i0 + (size_t)WG_MAXP);
+        int64_t maxsteps = 1;
+        for (size_t i = i0; i < i1; ++i) maxsteps = std::max(maxsteps, plans[i].steps);
+        // stages per workgroup S: minimise rounds(S) * (S + E), rounds = ceil(workgroups / 256 CUs), E ~ prologue + 256 KB of float
+        // atomics per workgroup in units of a 32-pixel stage
+        static const int E = getenv("OCTA_WG9_EPI") ? atoi(getenv("OCTA_WG9_EPI")) : 16;
+        static const int minsteps = getenv("OCTA_WG9_MINSTEPS") ? atoi(getenv("OCTA_WG9_MINSTEPS")) : 8;
+        auto blocks_at = [&](int64_t s) { int64_t b = 0; for (size_t i = i0; i < i1; ++i) b += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups * ((plans[i].steps + s - 1) / s); return b; };
+        int64_t S = maxsteps, best = -1;
+        for (int64_t s = maxsteps; s >= minsteps; s = (s > 64 ? s - s / 32 : s - 1)) {
+            const int64_t rounds = (blocks_at(s) + 255) / 256;
+            const int64_t cost = rounds * (s + E);
+            if (best < 0 || cost < best) { best = cost; S = s; }
+        }
+        std::stable_sort(plans.begin() + i0, plans.begin() + i1, [&](const WgPlan& a, const WgPlan& b) { return std::min(a.steps, S) > std::min(b.steps, S); });
+        WgBatch batch;
+        batch.n = (int)(i1 - i0);
+        int64_t nblk = 0;
+        for (size_t i = i0; i < i1; ++i) {
+            WgProb& p = plans[i].p;
+            const int64_t split = (plans[i].steps + S - 1) / S;
+            const int64_t sps = (plans[i].steps + split - 1) / split;      // balanced stages per split
+            p.mPerSplit = (int)(sps * 32);
+            p.splitM = (int)((p.M + p.mPerSplit - 1) / p.mPerSplit);
+            p.blockStart = (int)nblk;
+            nblk += (int64_t)p.tilesN * p.tilesK * p.groups * p.splitM;
+            batch.p[i - i0] = p;
+        }
+        if (nblk <= 0 || nblk >= (1ll << 30)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_conv2d_wgrad_batch: bad grid %lld", (long long)nblk);
+        static const bool stagger = getenv("OCTA_WG8_NOSTAGGER") == nullptr;
+        if (g_wg9_ablate && !F16) {
+            switch (g_wg9_ablate) {
+                case 1: wgrad9_kernel<0, 1, 1><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 2: wgrad9_kernel<0, 1, 2><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 4: wgrad9_kernel<0, 1, 4><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 8: wgrad9_kernel<0, 1, 8><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 3: wgrad9_kernel<0, 1, 3><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 11: wgrad9_kernel<0, 1, 11><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 7: wgrad9_kernel<0, 1, 7><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 16: wgrad9_kernel<0, 1, 16><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 21: wgrad9_kernel<0, 1, 21><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 13: wgrad9_kernel<0, 1, 13><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                case 29: wgrad9_kernel<0, 1, 29><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
+                default: OCTA_FAIL(OCTA_ERR_BAD_ARG, "wgrad9 ablation %d is not built", g_wg9_ablate);
+            }
+        } else if (stagger) wgrad9_kernel<F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        else wgrad9_kernel<F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        OCTA_CHECK_LAUNCH("wgrad9");
+        octa_note_conv_kernel(F16 ? "wgrad9_kernel<f16,256x256>" : "wgrad9_kernel<bf16,256x256>");
+        i0 = i1;
+    }
+    return OCTA_OK;
+}
+
+static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
+extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
+    OCTA_REQUIRE(key == 1 && value >= 1 && value <= 3, "octa_tuning_set: key 1 = batched weight-gradient tile families (mask 1..3)");
+    g_wgrad_families = value;
+    return OCTA_OK;
+}
+
 static int wg8_variant(const octa_wgrad_job& j) {
-    // slab orientation: the one that wastes less padded MFMA work; ties go to 256(N) x 128(K)
     const int Ng = j.d.Cout / j.d.groups, Kpad = j.d.KH * j.d.KW * j.d.cin_g_pad;
+    // 256 x 256 tiles when they waste at most 15 % of their MFMA work on padding (variant 2)
+    const int64_t w2 = (int64_t)cdiv(Ng, 256) * 256 * cdiv(Kpad, 256) * 256;
+    if ((g_wgrad_families & 2) && (w2 * 100 <= (int64_t)Ng * Kpad * 115 || !(g_wgrad_families & 1))) return 2;
+    // slab orientation: the one that wastes less padded MFMA work; ties go to 256(N) x 128(K)
     const int64_t w0 = (int64_t)cdiv(Ng, 256) * 256 * cdiv(Kpad, 128) * 128, w1 = (int64_t)cdiv(Ng, 128) * 128 * cdiv(Kpad, 256) * 256;
     return (w1 < w0) ? 1 : 0;
 }
@@ -409,7 +770,7 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
     OCTA_REQUIRE(jobs != nullptr && n >= 0, "octa_conv2d_wgrad_batch: bad arguments");
     static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    std::vector<WgPlan> plans[2][2];   // [f16][variant]
+    std::vector<WgPlan> plans[2][3];   // [f16][variant]
     for (int i = 0; i < n; ++i) {
         const octa_wgrad_job& j = jobs[i];
         if (off || !wg8_eligible(j)) {
@@ -430,9 +791,9 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
         p.magicOW = wg_magic(d.OW); p.magicOH = wg_magic(d.OH);
         p.groups = d.groups;
         pl.variant = wg8_variant(j);
-        p.tilesN = cdiv(p.Ng, pl.variant ? 128 : 256);
-        p.tilesK = cdiv(p.Kpad, pl.variant ? 256 : 128);
-        pl.steps = (p.M + 63) / 64;
+        p.tilesN = cdiv(p.Ng, pl.variant == 1 ? 128 : 256);
+        p.tilesK = cdiv(p.Kpad, pl.variant == 0 ? 128 : 256);
+        pl.steps = pl.variant == 2 ? (p.M + 31) / 32 : (p.M + 63) / 64;
         p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0;
         plans[d.dtype == OCTA_F16 ? 1 : 0][pl.variant].push_back(pl);
     }
@@ -440,5 +801,7 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
         if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
         if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }
     }
+    if (!plans[0][2].empty()) { const int rc = wg9_launch<0>(plans[0][2], st); if (rc) return rc; }
+    if (!plans[1][2].empty()) { const int rc = wg9_launch<1>(plans[1][2], st); if (rc) return rc; }
     return OCTA_OK;
 }

@@ -142,11 +142,11 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
                 F_.raw_conv_wgrad(xn, dyn, wq, s, p, g, dw=dw, defer=True)
                 assert F_.pending_wgrads() == 1
                 job = F_._WGRAD_Q[0][0]
-                assert int(L.octa_wgrad_job_class(ctypes.byref(job))) in (1, 2), "this layer must run on the batched 8-wave kernel"
+                assert int(L.octa_wgrad_job_class(ctypes.byref(job))) in (1, 2, 3), "this layer must run on the batched 8-wave kernels"
                 F_.flush_wgrads()
             finally:
                 F_.defer_wgrads(False)
-            assert "wgrad8" in L.octa_last_conv_kernel().decode(), L.octa_last_conv_kernel().decode()
+            assert any(k in L.octa_last_conv_kernel().decode() for k in ("wgrad8", "wgrad9")), L.octa_last_conv_kernel().decode()
         else:
             F_.raw_conv_wgrad(xn, dyn, wq, s, p, g, dw=dw)
         for (kh, kw), ref in refs.items():
@@ -201,11 +201,15 @@ STAGES = [
 
 @pytest.mark.parametrize("stage", STAGES)
 def test_deferred_batched_wgrads_equal_immediate_at_baseline_geometry(dev, stage):
-    """A whole stage at B = 16: backward with the weight gradients DEFERRED and flushed as batched 8-wave launches (what a
-    TrainStep does: multi-job batches, M-split chosen over all jobs) against backward with every weight gradient launched
-    immediately on the per-layer kernels.  Same forward, same incoming gradients; only the weight-gradient kernels differ."""
+    """A whole stage at B = 16: the backward pass queues its weight-gradient jobs (what a TrainStep does); the SAME jobs -- same
+    activation and gradient buffers -- are then run twice: flushed as batched 8-wave launches (multi-job batches, M-split chosen
+    over all jobs) and one by one on the per-layer kernels.  (Two separate backward passes are not comparable this tightly: the
+    split-attention and BatchNorm reductions use float atomics and the 16-sample bn1 amplifies their rounding noise, so the
+    incoming gradients differ from run to run.)"""
     from architectures.segmentor.compose import ResnestUNet
     from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    L = lib()
     name, shape = stage
     torch.manual_seed(0)
     unet = ResnestUNet(2, False).to(dev).train()
@@ -213,44 +217,49 @@ def test_deferred_batched_wgrads_equal_immediate_at_baseline_geometry(dev, stage
     params = [(n, p) for n, p in mod.named_parameters()]
     gen = torch.Generator(device="cpu").manual_seed(5)
     x = F_.to_nhwc(torch.randn(*shape, generator=gen).to(dev).to(torch.bfloat16))
-    state = {k: v.clone() for k, v in mod.state_dict().items()}
-    res = {}
-    for mode in ("deferred", "immediate"):
-        mod.load_state_dict(state)
-        for _, p in params:
-            p.grad = torch.zeros_like(p.data)              # same strides as the (channels-last) parameter: the gradient sink
-        F_.set_grad_sink(True)
-        F_.defer_wgrads(mode == "deferred")
-        try:
-            xin = x.detach().clone().requires_grad_(True)
-            y = mod(xin)
-            y = y[0] if isinstance(y, tuple) else y
-            g = torch.randn(tuple(y.shape), generator=torch.Generator(device="cpu").manual_seed(9)).to(dev).to(torch.bfloat16)
-            y.backward(F_.to_nhwc(g))
-            njobs = F_.pending_wgrads()
-            F_.flush_wgrads()
-        finally:
-            F_.defer_wgrads(False)
-            F_.set_grad_sink(False)
+    for _, p in params:
+        p.grad = torch.zeros_like(p.data)                  # same strides as the (channels-last) parameter: the gradient sink
+    F_.set_grad_sink(True)
+    F_.defer_wgrads(True)
+    try:
+        xin = x.detach().clone().requires_grad_(True)
+        y = mod(xin)
+        y = y[0] if isinstance(y, tuple) else y
+        g = torch.randn(tuple(y.shape), generator=torch.Generator(device="cpu").manual_seed(9)).to(dev).to(torch.bfloat16)
+        y.backward(F_.to_nhwc(g))
+        jobs = list(F_._WGRAD_Q)
+        classes = [int(L.octa_wgrad_job_class(ctypes.byref(j))) for j, _ in jobs]
+        assert len(jobs) >= 1 and any(c > 0 for c in classes), classes
+        targets = {}
+        for j, keep in jobs:
+            targets[j.dw] = keep[4]
+            if keep[5] is not None:
+                targets[j.dbias] = keep[5]
+        before = {k: t.detach().clone() for k, t in targets.items()}        # what the non-deferred part of backward already added
+        F_.flush_wgrads()
         torch.cuda.synchronize()
-        res[mode] = ({n: p.grad.detach().clone() for n, p in params}, njobs, F_.to_nchw_f32(xin.grad).clone())
-    (ga, ja, dxa), (gb, jb, dxb) = res["deferred"], res["immediate"]
-    assert ja >= 1 and jb == 0, (ja, jb)
-    # the data path does not depend on when the weight gradients run; it is not bit-reproducible either (the split-attention
-    # and BatchNorm reductions use float atomics), so two runs differ by a bf16 ulp on a few elements
-    assert (dxa - dxb).abs().max().item() <= 2.0 ** -6 * dxb.abs().max().item(), ((dxa - dxb).abs().max().item(), dxb.abs().max().item())
-    worst = ("", 0.0)
-    for n in ga:
-        a, b = ga[n].double(), gb[n].double()
-        assert torch.isfinite(a).all() and torch.isfinite(b).all(), n
+        batched = {k: t.detach().clone() for k, t in targets.items()}
+        for k, t in targets.items():
+            t.copy_(before[k])
+        st = torch.cuda.current_stream().cuda_stream
+        for j, keep in jobs:
+            L.octa_conv2d_wgrad(ctypes.byref(j.d), j.x, j.dy, j.dw, j.dw_strides, j.dbias, st)
+        torch.cuda.synchronize()
+    finally:
+        F_.defer_wgrads(False)
+        F_.set_grad_sink(False)
+    worst = 0.0
+    for k, t in targets.items():
+        a, b = (batched[k] - before[k]).double(), (t.detach() - before[k]).double()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
         den = b.norm().item()
-        rel = (a - b).norm().item() / den if den > 0 else (a - b).abs().max().item()
-        if rel > worst[1]:
-            worst = (n, rel)
-        # both are fp32 accumulations of bf16 products; the summation order differs and so do a few bf16 ulps of the incoming
-        # gradients (see above): measured 1e-5 .. 3e-4
-        assert rel <= 2e-3, (name, n, rel, den)
-    print(f"[stage {name}] {ja} deferred jobs; worst relative L2 difference batched vs immediate: {worst[1]:.2e} ({worst[0]})")
+        assert den > 0
+        rel = (a - b).norm().item() / den
+        worst = max(worst, rel)
+        # both are fp32 accumulations of the same bf16 products; only the summation order differs.  A bias gradient is a plain
+        # column sum over 10^4 .. 10^5 pixels whose terms cancel (|sum| << sum |terms|), hence the wider band for 1-D targets
+        assert rel <= (2e-3 if t.dim() == 1 else 2e-4), (name, tuple(t.shape), rel, den)
+    print(f"[stage {name}] {len(jobs)} queued jobs, classes {sorted(set(classes))}; worst relative L2 difference batched vs per-layer: {worst:.2e}")
 
 
 @pytest.mark.parametrize("cfg", [(400, True), (304, False)])

@@ -699,15 +699,19 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_wgrad_batch_vs_torch(dev, dtype):
-    """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations, a grouped conv, a strided one, a small-N job that falls
-    through to the single-problem kernel, fused bias gradients) in ONE call against torch's CPU gradients."""
+    """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations of wgrad8, the 256 x 256 tiles of wgrad9, grouped convs,
+    strided ones, a small-N job that falls through to the single-problem kernel, fused bias gradients) in ONE call against
+    torch's CPU gradients."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import WgradJob, lib
     L = lib()
     cases = [(3, 24, 9, 11, 136, 1, 1, 0, 1, True), (2, 40, 13, 10, 130, 3, 1, 1, 1, True), (2, 16, 15, 17, 256, 3, 2, 1, 1, False),
              (2, 32, 12, 12, 256, 3, 1, 1, 2, True), (2, 15, 20, 20, 128, 4, 2, 1, 1, True), (2, 320, 9, 9, 384, 3, 1, 1, 1, False),
-             (2, 32, 10, 10, 48, 3, 1, 1, 1, True)]
+             (2, 32, 10, 10, 48, 3, 1, 1, 1, True),
+             # 256 x 256 tiles (wgrad9): exact fit, N tail, grouped, strided, 1x1 with a 5-stage pixel axis and a ragged tail
+             (2, 256, 10, 12, 256, 3, 1, 1, 1, True), (3, 512, 7, 9, 500, 1, 1, 0, 1, True), (2, 512, 8, 8, 512, 3, 1, 1, 2, True),
+             (2, 256, 15, 17, 256, 3, 2, 1, 1, False), (1, 1024, 13, 11, 768, 1, 1, 0, 1, False)]
     gen = torch.Generator().manual_seed(3)
     jobs = (WgradJob * len(cases))()
     keep, want = [], []
@@ -728,7 +732,7 @@ def test_wgrad_batch_vs_torch(dev, dtype):
         keep.append((xd, dyd, dw, db))
         want.append((wr.grad, dy.sum((0, 2, 3))))
     classes = [int(L.octa_wgrad_job_class(ctypes.byref(jobs[j]))) for j in range(len(cases))]
-    assert set(classes) == {0, 1, 2}, classes
+    assert set(classes) == {0, 1, 2, 3}, classes
     L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
     for j, ((xd, dyd, dw, db), (gw, gb)) in enumerate(zip(keep, want)):
         check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))

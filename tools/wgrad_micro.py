@@ -1,6 +1,8 @@
 """Correctness + timing of the batched 8-wave weight-gradient kernel (octa_conv2d_wgrad_batch) against the single-problem
 kernels (octa_conv2d_wgrad) on real layer shapes, one job per launch and whole stages per launch.
-Usage: python tools/wgrad_micro.py [check] [time] [batch]"""
+"ab": interleaved A/B of the two batched tile families (octa_tuning_set(1, mask): 1 = 256x128 / 128x256 wgrad8, 3 = 256x256 wgrad9
+where it wastes < 15 % padding), 5 rounds each, behind a cache-evicting sweep, median and minimum.
+Usage: python tools/wgrad_micro.py [check] [time] [batch] [ab]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -168,6 +170,62 @@ def main():
             t_old = timeit(old)
             t_new = timeit(lambda: L.octa_conv2d_wgrad_batch(arr, len(items), st()))
             print(f"stage {sname:10s} {len(items):2d} jobs: old {t_old:8.1f} us {fl / t_old / 1e6:7.1f} TF/s | batched {t_new:8.1f} us {fl / t_new / 1e6:7.1f} TF/s", flush=True)
+    if "ab" in args:
+        evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        sets = {n: [n] for n in names if n in ("dec2_3x3", "dec3_3x3", "dec4_3x3", "dec2_splat", "dec3_splat", "dec4_1x1", "dec2_1x1", "enc3_c3", "enc4_c3", "up4_adj")}
+        sets["enc3 x6"] = ["enc3_c1", "enc3_splat", "enc3_c3"] * 6
+        sets["enc4 x3"] = ["enc4_c1", "enc4_splat", "enc4_c3"] * 3
+        sets["dec4 stage"] = ["dec4_3x3", "dec4_splat", "dec4_1x1", "up4_adj"]
+        sets["dec2+3"] = ["dec2_3x3", "dec2_splat", "dec2_1x1", "dec3_3x3", "dec3_splat"]
+        for sname, lst in sets.items():
+            items = [make(n) for n in lst]
+            dws = [torch.zeros_like(it["w"]) for it in items]
+            dbs = [torch.zeros(it["cfg"][4], device=dev) if it["bias"] else None for it in items]
+            arr = job_array(items, dws, dbs)
+            fl = sum(it["flops"] for it in items)
+            res = {1: [], 3: []}
+            names_k = {}
+            for rnd in range(5):
+                for mask in (1, 3):
+                    L.octa_tuning_set(1, mask)
+                    for cold in (True,):
+                        evict.zero_()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        L.octa_conv2d_wgrad_batch(arr, len(items), st())
+                        e1.record(); e1.synchronize()
+                        res[mask].append(e0.elapsed_time(e1) * 1e3)
+                        names_k[mask] = L.octa_last_conv_kernel().decode()
+            L.octa_tuning_set(1, 3)
+            out = []
+            for mask in (1, 3):
+                v = sorted(res[mask])
+                out.append(f"{names_k[mask]:28s} median {v[len(v) // 2]:8.1f} us ({fl / v[len(v) // 2] / 1e6:7.1f} TF/s) min {v[0]:8.1f}")
+            print(f"A/B {sname:12s} | " + " | ".join(out), flush=True)
+    if "ablate" in args:
+        evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        for n in [x for x in names if x in ("dec2_3x3", "dec3_3x3", "dec4_3x3")] or ["dec2_3x3"]:
+            it = make(n)
+            dw = torch.zeros_like(it["w"])
+            arr = job_array([it], [dw], [None])
+            L.octa_tuning_set(1, 3)
+            for abl, what in ((0, "full kernel"), (1, "no epilogue atomics"), (2, "no LDS-DMA in the loop"), (4, "no MFMA"), (8, "no transposed reads"),
+                              (3, "no atomics, no DMA"), (11, "MFMA only (no atomics / DMA / reads)"), (7, "reads only (no atomics / DMA / MFMA)"),
+                              (13, "DMA only (no atomics / MFMA / reads)"), (16, "full, every WG on pixel range 0"),
+                              (21, "no atomics / MFMA, pixel range 0"), (29, "DMA only, pixel range 0")):
+                L.octa_tuning_set(2, abl)
+                ts = []
+                for cold in (True, False):
+                    for _ in range(4):
+                        if cold:
+                            evict.zero_()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        L.octa_conv2d_wgrad_batch(arr, 1, st())
+                        e1.record(); e1.synchronize()
+                        ts.append(e0.elapsed_time(e1) * 1e3)
+                print(f"ablate {n} {what:40s} cold {sorted(ts[:4])[1]:8.1f} us  warm {sorted(ts[4:])[1]:8.1f} us", flush=True)
+            L.octa_tuning_set(2, 0)
     print("ALL OK" if ok else "FAILURES", flush=True)
     sys.exit(0 if ok else 1)
 
