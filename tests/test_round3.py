@@ -29,8 +29,15 @@ def _cotangent_loss(outs, dev="cpu"):
     return loss
 
 
-def _band_check(tag, got, G, pre32, pre64, floor=1e-3):
-    """relative deviation of `got` norms from the float64 reference vs the reference's own fp32 deviation (4x band rule)."""
+def _band_check(tag, got, G, pre32, pre64, floor=1e-3, chaotic=False):
+    """relative deviation of `got` norms from the float64 reference vs the reference's own fp32 deviation (4x band rule).
+    chaotic=True (the dual-head U-Nets at B = 3: every split-attention bn1 normalises over THREE samples): any fp32 evaluation
+    is one draw of a heavy-tailed, partly discrete noise -- a ReLU or a 3-sample BatchNorm channel on the edge flips and the
+    encoder's gradient norms move by several per cent.  profiles/r03_heads_bwd_diag.txt (tools/heads_bwd_diag.py) shows it per
+    module for three HIP runs and the CPU oracle: relative L2 errors of 3-7 % in the encoder for EVERY fp32 evaluation (oracle
+    fp32: 2.7-3.5 %), bimodal between HIP runs, 1e-5 .. 1e-3 in the second decoder branch and the heads, and no module with an
+    O(1) error.  The bulk statistics then get an absolute floor of 1.5 % / 5 % next to the 4x band; a structural error (a
+    missing or doubled gradient path) shows as tens of per cent and is also pinned by the per-module checks of the callers."""
     dh, dr = [], []
     top = max(float(g) for k, g in G.items() if k.startswith(pre64))
     for k, g64 in G.items():
@@ -44,11 +51,9 @@ def _band_check(tag, got, G, pre32, pre64, floor=1e-3):
     p95h, p95r = np.percentile(dh, 95), np.percentile(dr, 95)
     print(f"[{tag}] grad-norm deviation from ref64: HIP median {np.median(dh):.2e} p95 {p95h:.2e} max {np.max(dh):.2e}; "
           f"ref32 median {np.median(dr):.2e} p95 {p95r:.2e} max {np.max(dr):.2e}")
-    # both are ONE draw of a heavy-tailed noise (train-mode BatchNorm over a handful of samples amplifies rounding chaotically):
-    # the bulk (median, 95th percentile) is held to 4x the reference's own band, the single worst parameter to 8x
-    assert np.median(dh) <= 4 * np.median(dr) + floor and p95h <= 4 * p95r + 2 * floor and np.max(dh) <= 8 * np.max(dr) + 2 * floor, \
+    f_med, f_tail = (1.5e-2, 5e-2) if chaotic else (floor, 2 * floor)
+    assert np.median(dh) <= 4 * np.median(dr) + f_med and p95h <= 4 * p95r + f_tail and np.max(dh) <= 8 * np.max(dr) + f_tail, \
         (tag, np.median(dh), p95h, np.max(dh), np.median(dr), p95r, np.max(dr))
-
 
 
 # ----------------------------------------------------------------------------------------- CPU
@@ -121,7 +126,7 @@ def test_oracle_parallel_heads_backward(golden, tag):
     assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-5 * abs(l64), (loss.item(), l32, l64)
     got = {k: v.grad.double().norm().item() for k, v in P.items() if v.requires_grad and v.grad is not None}
     assert len(got) > 300
-    _band_check(f"oracle {tag}", got, G, f"{tag}/gradnorm/", f"{tag}/gradnorm_f64/")
+    _band_check(f"oracle {tag}", got, G, f"{tag}/gradnorm/", f"{tag}/gradnorm_f64/", chaotic=True)
     for k, g in G.items():                                          # full gradients next to the outputs (little amplification there)
         if k.startswith(f"{tag}/grad/") and k.rsplit("/", 1)[1].split(".")[0] in ("fc", "fc_c", "aag_0_c", "upsampling_0_c"):
             w = P[k[len(tag) + 6:]].grad
@@ -195,12 +200,19 @@ def test_hip_parallel_heads_backward_vs_reference(dev, golden, tag):
     params = dict(m.named_parameters())
     got = {k: p.grad.double().norm().item() for k, p in params.items() if p.grad is not None}
     assert sorted(k for k, p in params.items() if p.grad is None) == sorted(G[f"{tag}/nograd_keys"].tolist())
-    _band_check(tag, got, G, f"{tag}/gradnorm/", f"{tag}/gradnorm_f64/")
-    # the second branch in particular
+    _band_check(tag, got, G, f"{tag}/gradnorm/", f"{tag}/gradnorm_f64/", chaotic=True)
+    # structure: no parameter anywhere may be off by tens of per cent (a lost or doubled branch of the fan-out would be) ...
+    top = max(float(g) for k, g in G.items() if k.startswith(f"{tag}/gradnorm_f64/"))
+    for k, v in got.items():
+        g64 = float(G[f"{tag}/gradnorm_f64/{k}"])
+        if g64 > 1e-6 * top:
+            assert abs(v - g64) <= 0.25 * g64, (k, v, g64)
+    # ... and the well-conditioned part -- the second decoder branch and both heads, which sit next to the outputs -- is tight
     for k in got:
-        if "_c." in k:
+        if "_c." in k or k.startswith(("fc.", "fc_c.")):
             g64, g32 = float(G[f"{tag}/gradnorm_f64/{k}"]), float(G[f"{tag}/gradnorm/{k}"])
-            assert abs(got[k] - g64) <= 4 * abs(g32 - g64) + 2e-3 * g64 + 1e-7, (k, got[k], g32, g64)
+            if g64 > 1e-6 * top:
+                assert abs(got[k] - g64) <= 4 * abs(g32 - g64) + 2e-3 * g64 + 1e-7, (k, got[k], g32, g64)
 
 
 @pytest.mark.gpu
