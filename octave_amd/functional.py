@@ -649,9 +649,11 @@ def flush_wgrads(min_jobs: int = 1) -> int:
     return n
 
 
-def add_mark_hook(fn):
-    """fn(tag) is called (after the weight-gradient flush) whenever the backward pass crosses a stage mark."""
-    _MARK_HOOKS.append(fn)
+def add_mark_hook(fn, tags=None):
+    """fn(tag) is called (after the weight-gradient flush) whenever the backward pass crosses a stage mark; `tags` (optional):
+    only at these marks -- the queue of deferred weight gradients is then flushed completely there (a gradient bucket must be
+    whole before it travels) and by the usual batch-size rule at the other marks."""
+    _MARK_HOOKS.append((fn, None if tags is None else frozenset(tags)))
 
 
 def clear_mark_hooks():
@@ -671,8 +673,9 @@ class StageMarkFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        flush_wgrads(1 if _MARK_HOOKS else _WGRAD_FLUSH_MIN)
-        for fn in _MARK_HOOKS:
+        hooks = [fn for fn, tags in _MARK_HOOKS if tags is None or ctx.tag in tags]
+        flush_wgrads(1 if hooks else _WGRAD_FLUSH_MIN)
+        for fn in hooks:
             fn(ctx.tag)
         return g, None
 

@@ -323,7 +323,7 @@ class _RngFeed:
 
 class _Capture:
     """Static buffers and the four hipGraphs of one input resolution."""
-    __slots__ = ("sx", "sys", "sreal", "feed", "out", "att", "graphs", "disc")
+    __slots__ = ("sx", "sys", "sreal", "feed", "out", "att", "graphs", "disc", "seg_graphs")
 
 
 class TrainStep:
@@ -376,7 +376,7 @@ class TrainStep:
         rank = {m: i for i, (_, mods) in enumerate(SEG_GRAD_ORDER) for m in mods}
         named.sort(key=lambda np_: rank.get(np_[0].split(".", 1)[0], len(rank)))       # stable: registration order inside a module
         groups = [(tag, [n for n, _ in named if n.split(".", 1)[0] in mods]) for tag, mods in SEG_GRAD_ORDER]
-        self.seg_arena = FlatArena(named, groups)
+        self.seg_arena = FlatArena(named, groups, min_bucket=int(os.environ.get("OCTA_MIN_BUCKET", str(4 << 20))))
         self.disc_arena = None
         if self.adversarial:
             seen, dn = set(), []
@@ -397,7 +397,10 @@ class TrainStep:
         # eager launches with more than one rank: start each gradient bucket's all-reduce from the stage mark that completes it,
         # i.e. overlapped with the REST of the backward pass (BASELINE config 4).  Captured graphs hold no collective: there the
         # buckets are issued, in the same order, right after the segmentor graph and overlap the discriminator step instead.
-        self.overlap_backward = _dist_on(self.world) if overlap_backward is None else bool(overlap_backward)
+        self.overlap_backward = (_dist_on(self.world) or os.environ.get("OCTA_SPLIT_BACKWARD") == "1") if overlap_backward is None else bool(overlap_backward)
+        # ... and with overlap_backward the SEGMENTOR graph is captured in pieces, cut at the stage marks that complete a gradient
+        # bucket (capture()): a replay then starts each bucket's all-reduce right behind the piece that produced it, overlapped
+        # with the rest of the backward pass exactly like the eager path
         self._started: List[int] = []
         self._tag_to_bucket = {tag: i for i, (tag, _, _) in enumerate(self.seg_arena.buckets)}
         self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
@@ -459,7 +462,7 @@ class TrainStep:
             self.seg_arena.all_reduce_bucket_async(self.world, self._comm(), i, self.grad_comm_dtype)
             self._started.append(i)
 
-    def _phase_segmentor(self, x, ys, out, disc, hooks: bool = False):
+    def _phase_segmentor(self, x, ys, out, disc, hooks=False):
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         self._started = []
@@ -477,8 +480,10 @@ class TrainStep:
             g_adv = F_.lsgan_generator(disc(att))
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
-        if hooks:
-            F_.add_mark_hook(self._on_mark)
+        if callable(hooks):
+            F_.add_mark_hook(hooks, self._tag_to_bucket.keys())         # capture(): cuts the graph at the bucket-completing marks
+        elif hooks:
+            F_.add_mark_hook(self._on_mark, self._tag_to_bucket.keys())
         try:
             self._scaled(loss).backward()
             F_.flush_wgrads()
@@ -604,9 +609,13 @@ class TrainStep:
         # thread captures; under the default global mode that query is an error and the watchdog aborts the process
         mode = "thread_local"
         pool = next(iter(self._caps.values())).graphs[0].pool() if self._caps else None
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=pool, capture_error_mode=mode):
-            cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc)
+        cap.seg_graphs = None
+        if self.overlap_backward:
+            g1 = self._capture_segmentor_in_pieces(cap, pool)
+        else:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=pool, capture_error_mode=mode):
+                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
             self._phase_discriminator(cap.att, cap.sreal, cap.out, cap.disc)
@@ -619,6 +628,45 @@ class TrainStep:
         cap.graphs = (g1, g2, g2b, g3)
         self._caps[int(x.shape[-1])] = cap
         return self
+
+    def _capture_segmentor_in_pieces(self, cap: "_Capture", pool):
+        """The segmentor phase as a CHAIN of hipGraphs cut at the stage marks that complete a gradient bucket (SEG_GRAD_ORDER):
+        piece k ends when bucket k's gradients are final, so a replay can hand bucket k to RCCL (side stream) while piece k + 1
+        -- the rest of the backward pass -- runs.  The cuts happen inside autograd's backward pass, i.e. on the autograd worker
+        thread: capture mode "relaxed" (stream capture may be ended / begun from any thread, and RCCL's watchdog may query its
+        events meanwhile).  All pieces allocate from one private pool and are replayed in capture order."""
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        pieces: List[Tuple[torch.cuda.CUDAGraph, Optional[int]]] = []
+        state = {"g": torch.cuda.CUDAGraph()}
+        kw = {"capture_error_mode": "relaxed"}
+
+        def cut(tag):
+            i = self._tag_to_bucket.get(tag)
+            if i is None or any(b == i for _, b in pieces):
+                return
+            state["g"].capture_end()
+            pieces.append((state["g"], i))
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=pieces[0][0].pool(), **kw)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if pool is not None:
+                state["g"].capture_begin(pool=pool, **kw)
+            else:
+                state["g"].capture_begin(**kw)
+            try:
+                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc, hooks=cut)
+            finally:
+                state["g"].capture_end()
+        pieces.append((state["g"], None))
+        cur.wait_stream(side)
+        cap.seg_graphs = pieces
+        return pieces[0][0]
 
     @property
     def _graphs(self):          # bench.py's roofline leg swaps this to record an eager step
@@ -722,10 +770,20 @@ class TrainStep:
         if self.adversarial:
             cap.feed.refill()
         g1, g2, g2b, g3 = cap.graphs
-        g1.replay()
-        # bucketed, in completion order, on the comm stream: the D step overlaps the segmentor gradient exchange
         comm = self._comm()
-        self.seg_arena.all_reduce_begin(self.world, comm, self.grad_comm_dtype)
+        started: List[int] = []
+        if cap.seg_graphs is not None:
+            # the segmentor phase in pieces: bucket k leaves for RCCL as soon as piece k has been enqueued, the next piece
+            # (the rest of the backward pass) runs meanwhile
+            for g, bucket in cap.seg_graphs:
+                g.replay()
+                if bucket is not None:
+                    self.seg_arena.all_reduce_bucket_async(self.world, comm, bucket, self.grad_comm_dtype)
+                    started.append(bucket)
+        else:
+            g1.replay()
+        # what has not left yet (everything, without the pieces), in completion order on the comm stream: the D step overlaps it
+        self.seg_arena.all_reduce_begin(self.world, comm, self.grad_comm_dtype, skip=started)
         seg_done = None
         if _dist_on(self.world):
             seg_done = torch.cuda.Event()

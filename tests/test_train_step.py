@@ -397,7 +397,14 @@ def test_train_step_single_rank_rccl_buckets_and_capture():
             nb = len(st.seg_arena.buckets)
             started = list(st._started)
             st.capture(x, ys, pyr)
+            pieces = st._caps[H].seg_graphs
+            if distributed:
+                # replay mode overlaps too: the segmentor graph is a chain of pieces cut at the bucket-completing stage marks
+                assert pieces is not None and len(pieces) == nb and [b for _, b in pieces] == list(range(nb - 1)) + [None], pieces
+            else:
+                assert pieces is None
             st.launch = "graph"
+            o = st(x, ys, pyr)
             o = st(x, ys, pyr)
             torch.cuda.synchronize()
             res2 = {k: float(v) for k, v in o.items()}
@@ -423,7 +430,7 @@ def test_train_step_single_rank_rccl_buckets_and_capture():
     for k in ref[0]:
         assert abs(ref[0][k] - got[0][k]) <= 1e-4 * abs(ref[0][k]) + 1e-5, (k, ref[0][k], got[0][k])
         assert np.isfinite(got[1][k]) and np.isfinite(got2[k]), (k, got[1][k], got2[k])
-    assert (p_ref - p_got).abs().max().item() <= 5 * 2 * 1e-4 + 1e-6        # 2 eager + 2 capture warm-up + 1 replayed step
+    assert (p_ref - p_got).abs().max().item() <= 6 * 2 * 1e-4 + 1e-6        # 2 eager + 2 capture warm-up + 2 replayed steps
 
 
 def test_optimizer_state_roundtrip_and_autotune_has_no_side_effect():
