@@ -164,6 +164,12 @@ class FlatArena:
         if buf is None or buf.numel() != hi - lo or buf.dtype != comm_dtype:
             buf = torch.empty(hi - lo, dtype=comm_dtype, device=sl.device)
             self._comm_bufs[lo] = buf
+        if not sl.is_cuda:
+            # host tensors (the gloo tests of the bucket schedule): plain tensor casts, no kernel of the library involved
+            buf.copy_(sl)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            sl.copy_(buf)
+            return
         st = torch.cuda.current_stream().cuda_stream
         L = lib()
         L.octa_cast(sl.data_ptr(), 0, buf.data_ptr(), F_._dt(comm_dtype), hi - lo, st)
@@ -181,6 +187,9 @@ class FlatArena:
         if not _dist_on(world):
             return
         _, lo, hi = self.buckets[idx]
+        if comm_stream is None:                 # host tensors: no streams
+            self._reduce_range(lo, hi, comm_dtype)
+            return
         comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(comm_stream):
             self._reduce_range(lo, hi, comm_dtype)
@@ -190,6 +199,11 @@ class FlatArena:
         work and calls all_reduce_end() before consuming the gradients."""
         if not _dist_on(world):
             return
+        if comm_stream is None:                 # host tensors: no streams
+            for i, (_, lo, hi) in enumerate(self.buckets):
+                if i not in skip:
+                    self._reduce_range(lo, hi, comm_dtype)
+            return
         comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(comm_stream):
             for i, (_, lo, hi) in enumerate(self.buckets):
@@ -197,7 +211,7 @@ class FlatArena:
                     self._reduce_range(lo, hi, comm_dtype)
 
     def all_reduce_end(self, world: int, comm_stream):
-        if _dist_on(world):
+        if _dist_on(world) and comm_stream is not None:
             torch.cuda.current_stream().wait_stream(comm_stream)
 
     def broadcast(self, src: int = 0):

@@ -132,6 +132,84 @@ def test_flat_arena_all_reduce_world2_gloo():
     assert numel >= 1 and nparams == 20
 
 
+def _worker_buckets_bf16(rank, world, port, q):
+    """Two TrainStep-shaped ranks: the segmentor-style arena (groups in gradient-completion order), the bucket schedule a step
+    walks -- buckets handed over from the stage marks in completion order while `backward` is still producing the later ones,
+    the stragglers afterwards with skip=started -- and the reduced-precision exchange (grad_comm_dtype=bfloat16)."""
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    ok = False
+    try:
+        from octave_amd import train as T
+        P = _make_state()
+        named = [(k, p) for k, p in P.items() if isinstance(p, torch.nn.Parameter)]
+        quarter = (len(named) + 3) // 4
+        tags = ["decoder_3", "decoder_4", "encoder_4", "end"]
+        groups = [(tags[i], [k for k, _ in named[i * quarter:(i + 1) * quarter]]) for i in range(4)]
+        arena = T.FlatArena(named, groups, min_bucket=1)
+        assert [b[0] for b in arena.buckets] == tags
+        arena.zero_grad()
+        g_local = _local_grads(P, rank, reset=False)           # "backward": every rank's own shard, written into the arena views
+        tag_to_bucket = {t: i for i, (t, _, _) in enumerate(arena.buckets)}
+        started = []
+        for tag in ("decoder_3", "decoder_4", "encoder_4"):     # the marks fire in completion order; "end" has no mark
+            i = tag_to_bucket[tag]
+            arena.all_reduce_bucket_async(world, None, i, torch.bfloat16)
+            started.append(i)
+        arena.all_reduce_begin(world, None, torch.bfloat16, skip=started)
+        arena.all_reduce_end(world, None)
+        # every bucket was reduced exactly once: sum over ranks of the bf16-rounded local gradients, rounded to bf16 again
+        P2 = _make_state()
+        want = None
+        for r in range(world):
+            g = {k: v.bfloat16().float() for k, v in _local_grads(P2, r).items()}
+            want = g if want is None else {k: want[k] + g[k] for k in g}
+        err, scale = 0.0, 0.0
+        for k, p in named:
+            w = want[k].bfloat16().float()
+            err = max(err, (p.grad - w).abs().max().item())
+            scale = max(scale, w.abs().max().item())
+            # and against the exact fp32 average: one rounding per rank + one for the sum
+            exact = sum(_local_grads(P2, r)[k] for r in range(world))
+            assert (p.grad - exact).abs().max().item() <= 3 * 2.0 ** -8 * exact.abs().max().item() + 1e-12, k
+        chk = arena.g.clone()
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        assert torch.equal(chk, world * arena.g), "ranks disagree after the exchange"
+        if rank == 0:
+            q.put(("ok", err, scale, len(started)))
+        ok = True
+    except Exception:
+        import traceback
+        q.put(("fail", traceback.format_exc(), 0, 0))
+        raise
+    finally:
+        if ok:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_bucket_schedule_bf16_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buckets_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        status, err, scale, nstarted = q.get(timeout=200)
+    finally:
+        for p in procs:
+            p.join(timeout=100)
+            if p.is_alive():
+                p.kill()
+    assert status == "ok", err
+    assert err <= 2.0 ** -8 * scale and nstarted == 3, (err, scale, nstarted)
+
+
 def test_bench_shards_data_by_rank():
     import importlib.util
     import sys
