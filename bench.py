@@ -171,7 +171,7 @@ def roofline_leg(step, batch, dtype_name):
     # their own runs, gfx950 correction applied by tools/pmc_traffic.py); null when the kernel was not profiled
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
         if name in pm and batch[0].shape[0] == 16 and batch[0].shape[-1] == 400:
             traffic = round(pm[name]["hbm_bytes_per_launch"])
     except Exception:

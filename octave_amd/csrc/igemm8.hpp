@@ -101,27 +101,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
         const long roff = ((long)(b * a.H + rh) * Wimg + rw) * ldx + a.xoff + g * a.CgStride;
         abase[j] = (unsigned long)((const T*)a.x + roff);
     }
-    // B: the B_IPW weight rows this lane fetches, chunk `chunk` of the current K step (zero page with a zero step when out of range)
+    // B: the B_IPW weight rows this lane fetches (zero page when out of range); the K offset of a stage is added per stage
     const size_t Kelem = (size_t)Kc * EPC;
     unsigned long wptr[B_IPW];
-    unsigned long wstep[B_IPW];
+    bool wvalid[B_IPW];
 #pragma unroll
     for (int j = 0; j < B_IPW; ++j) {
         const int n = n0 + rowc + RPR * j;
-        const bool wvalid = n < a.Ng;
-        wptr[j] = wvalid ? (unsigned long)((const T*)a.w + ((size_t)g * a.Ng + n) * Kelem + (size_t)chunk * EPC) : zaddr;
-        wstep[j] = wvalid ? 128ul : 0ul;
+        wvalid[j] = n < a.Ng;
+        wptr[j] = wvalid[j] ? (unsigned long)((const T*)a.w + ((size_t)g * a.Ng + n) * Kelem + (size_t)chunk * EPC) : zaddr;
     }
-    // per-lane K state of the stage to be issued next: chunk index kc, channel chunk cc inside the tap, tap (kh, kw)
-    int kc = chunk, cc = chunk % CgC, tap = chunk / CgC;
-    int kh = tap / KW, kw = tap - kh * KW;
+    // K order: a stage is ONE tap x 64 channels (Cg % 64 == 0).  The stages walk the taps of one 64-channel slice before moving
+    // to the next slice (slice-major), not the slices of one tap: the nine taps of a 3x3 layer re-read the same activation
+    // lines (shifted by a pixel / an image row), and with the taps 8 .. 32 stages apart those lines had left the XCD's 4 MB
+    // L2 in between -- rocprofv3 FETCH_SIZE showed 3-4x the algorithmic bytes for this kernel (profiles/r03_a_pmc_traffic.json).
+    // Per-lane state of the stage to be issued next: tap (kh, kw), channel chunk cc = 8 * slice + chunk inside the tap.
+    const int ntaps = a.KH * KW;
+    int cc = chunk, tap = 0, kh = 0, kw = 0;
 
     const unsigned sbase = lds_addr(smem);
+    auto advanceK = [&]() {                               // next tap of the slice; after the last tap, the next slice
+        tap += 1; kw += 1;
+        const bool wrap2 = kw >= KW;
+        kw = wrap2 ? 0 : kw;
+        kh += wrap2 ? 1 : 0;
+        const bool wrap = tap >= ntaps;
+        tap = wrap ? 0 : tap; kh = wrap ? 0 : kh; kw = wrap ? 0 : kw;
+        cc += wrap ? KP : 0;
+    };
     auto issue = [&](int stage) {
         const unsigned ab = sbase + (unsigned)(stage * SBYTES), bb = ab + A_BYTES;
         const int tpix = kh * Wimg + kw;
         const long soff = (long)(((MODE == 0 ? tpix : -tpix) * ldx + cc * EPC) * 2);      // byte offset of (tap, channel chunk)
-        const bool kin = kc < Kc;
+        const unsigned long woff = (unsigned long)((tap * CgC + (cc - chunk)) * (EPC * 2));    // (tap, slice) inside the packed weight row
+        const bool kin = cc < CgC;
         const unsigned tbit = kin ? (1u << tap) : 0u;
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
@@ -131,19 +144,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
         }
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
-            const unsigned long src = kin ? wptr[j] : zaddr;
+            const unsigned long src = (kin && wvalid[j]) ? (wptr[j] + woff) : zaddr;
             glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(bb + (unsigned)((wave + NW * j) * 1024)));
-            wptr[j] += wstep[j];
         }
-        // advance by one K step (8 chunks); CgC >= 8 (checked by the launcher): at most one tap wrap
-        kc += KP; cc += KP;
-        const bool wrap = cc >= CgC;
-        cc -= wrap ? CgC : 0;
-        tap += wrap ? 1 : 0;
-        kw += wrap ? 1 : 0;
-        const bool wrap2 = kw >= KW;
-        kw = wrap2 ? 0 : kw;
-        kh += wrap2 ? 1 : 0;
+        advanceK();
     };
 
     f32x4_t acc[4][4];
@@ -209,20 +213,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
         const unsigned long src = ok ? (abase[j] + soff) : zaddr;
         glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(stage * SBYTES + (wave + NW * j) * 1024)));
     };
-    auto issueB = [&](int j, int stage, bool kin) {
-        const unsigned long src = kin ? wptr[j] : zaddr;
+    auto issueB = [&](int j, int stage, bool kin, unsigned long woff) {
+        const unsigned long src = (kin && wvalid[j]) ? (wptr[j] + woff) : zaddr;
         glds16_fast((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(stage * SBYTES + A_BYTES + (wave + NW * j) * 1024)));
-        wptr[j] += wstep[j];
-    };
-    auto advanceK = [&]() {
-        kc += KP; cc += KP;
-        const bool wrap = cc >= CgC;
-        cc -= wrap ? CgC : 0;
-        tap += wrap ? 1 : 0;
-        kw += wrap ? 1 : 0;
-        const bool wrap2 = kw >= KW;
-        kw = wrap2 ? 0 : kw;
-        kh += wrap2 ? 1 : 0;
     };
     issue(0);
     if (nk > 1) issue(1);
@@ -243,9 +236,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
         // (tap, channel chunk) state of stage kt + 2, frozen for this iteration's DMA instructions
         const int tpix = kh * Wimg + kw;
         const long soff = (long)(((MODE == 0 ? tpix : -tpix) * ldx + cc * EPC) * 2);
-        const bool kin = kc < Kc;
+        const unsigned long woff = (unsigned long)((tap * CgC + (cc - chunk)) * (EPC * 2));
+        const bool kin = cc < CgC;
         const unsigned tbit = kin ? (1u << tap) : 0u;
-        auto dma = [&](int d) { if (d < A_IPW) issueA(d, s2, soff, tbit); else issueB(d - A_IPW, s2, kin); };
+        auto dma = [&](int d) { if (d < A_IPW) issueA(d, s2, soff, tbit); else issueB(d - A_IPW, s2, kin, woff); };
         IG8_SB;
         // ---- sub-step 0 of stage kt (X); fetch sub-step 1 (Y)
 #pragma unroll

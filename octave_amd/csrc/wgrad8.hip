@@ -610,13 +610,14 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 // ------------------------------------------------------------------------------------------ host side
 static unsigned wg_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
+static int g_wg8_min_ng = 128;        // octa_tuning_set(3, n): smallest Cout / groups the batched kernels accept
 // can the batched kernel take this job?  (everything else goes to the single-problem kernels of conv.hip)
 static bool wg8_eligible(const octa_wgrad_job& j) {
     const octa_conv_desc& d = j.d;
     if (d.dtype != OCTA_BF16 && d.dtype != OCTA_F16) return false;
     if (d.upshuffle || !j.x || !j.dy || !j.dw) return false;
     const int Ng = d.Cout / d.groups;
-    if (Ng < 128) return false;                              // tall-skinny problems stay on the slab kernels
+    if (Ng < g_wg8_min_ng) return false;                     // tall-skinny problems stay on the slab kernels
     if (d.OW < 2 || d.OH < 2 || d.OW > 511 || d.OH > 511 || 64 / d.OW + 1 > d.OH) return false;   // single-wrap pixel updates
     if ((int64_t)d.B * d.H * d.W >= (1 << 23) || d.ldx * 2 >= (1 << 23)) return false;              // 24-bit multiply operands
     const int64_t M = (int64_t)d.B * d.OH * d.OW;
@@ -746,6 +747,7 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
 extern "C" int octa_tuning_set(int key, int value) {
     if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
+    if (key == 3) { OCTA_REQUIRE(value >= 8 && value <= 4096, "octa_tuning_set: key 3 = minimum Cout / groups of the batched weight-gradient kernels"); g_wg8_min_ng = value; return OCTA_OK; }
     OCTA_REQUIRE(key == 1 && value >= 1 && value <= 3, "octa_tuning_set: key 1 = batched weight-gradient tile families (mask 1..3)");
     g_wgrad_families = value;
     return OCTA_OK;

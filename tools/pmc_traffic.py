@@ -25,6 +25,9 @@ def short(name):
     if mr:      # <T, TAPS, NCH, TN, MODE> -> the name launch_res() reports (256 pixels x TN*16 channels)
         fam = "conv_res3x3_kernel" if int(mr.group(2)) == 9 else "conv_res1x1_kernel"
         return f"{fam}<{'bf16' if mr.group(1) == 'unsigned short' else 'f16'},256x{int(mr.group(4)) * 16}>"
+    m9 = re.match(r"void wgrad9_kernel<(\d+), (\d+), (\d+)>", name)
+    if m9:
+        return f"wgrad9_kernel<{'f16' if int(m9.group(1)) else 'bf16'},256x256>"
     mw = re.match(r"void wgrad8_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if mw:
         return f"wgrad8_kernel<{'f16' if int(mw.group(3)) else 'bf16'},{int(mw.group(1)) * 64}x{int(mw.group(2)) * 64}>"

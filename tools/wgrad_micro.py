@@ -33,6 +33,15 @@ LAYERS = {
     "enc4_c3": (16, 512, 13, 13, 2048, 1, 1, 0, 1, 0),
     "disc3": (16, 15, 50, 50, 512, 4, 2, 1, 1, 1),
     "up4_adj": (16, 1024, 26, 26, 2048, 2, 2, 0, 1, 0),
+    # tall-skinny layers (fewer than 128 output channels per group): single-problem kernels by default
+    "disc0": (16, 2, 400, 400, 64, 4, 2, 1, 1, 1),
+    "enc1_splat": (16, 64, 100, 100, 128, 3, 1, 1, 2, 0),
+    "dec1_splat": (16, 64, 200, 200, 128, 3, 1, 1, 4, 1),
+    "dec0_1x1": (16, 64, 400, 400, 32, 1, 1, 0, 1, 0),
+    "stem0": (16, 3, 400, 400, 32, 3, 2, 1, 1, 0),
+    "stem2": (16, 32, 200, 200, 64, 3, 1, 1, 1, 0),
+    "up0_adj": (16, 64, 400, 400, 64, 2, 2, 0, 1, 0),
+    "sq1": (16, 64, 200, 200, 13, 1, 1, 0, 1, 1),
 }
 
 
@@ -202,6 +211,35 @@ def main():
                 v = sorted(res[mask])
                 out.append(f"{names_k[mask]:28s} median {v[len(v) // 2]:8.1f} us ({fl / v[len(v) // 2] / 1e6:7.1f} TF/s) min {v[0]:8.1f}")
             print(f"A/B {sname:12s} | " + " | ".join(out), flush=True)
+    if "skinny" in args:
+        evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        for n in ("disc0", "enc1_splat", "dec1_splat", "dec0_1x1", "stem0", "stem2", "up0_adj", "sq1"):
+            it = make(n)
+            Cout = it["cfg"][4]
+            res = {}
+            for mode, minng in (("single-problem kernel", 128), ("batched 8-wave kernel", 8)):
+                L.octa_tuning_set(3, minng)
+                dw = torch.zeros_like(it["w"])
+                db = torch.zeros(Cout, device=dev) if it["bias"] else None
+                arr = job_array([it], [dw], [db])
+                ts = []
+                for _ in range(5):
+                    evict.zero_()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    L.octa_conv2d_wgrad_batch(arr, 1, st())
+                    e1.record(); e1.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+                dw.zero_()
+                if db is not None:
+                    db.zero_()
+                L.octa_conv2d_wgrad_batch(arr, 1, st())
+                torch.cuda.synchronize()
+                res[mode] = (sorted(ts)[2], dw.clone(), L.octa_last_conv_kernel().decode())
+            L.octa_tuning_set(3, 128)
+            a, b = res["single-problem kernel"], res["batched 8-wave kernel"]
+            err = (a[1] - b[1]).abs().max().item() / max(a[1].abs().max().item(), 1e-30)
+            print(f"skinny {n:11s} {a[2]:32s} {a[0]:8.1f} us | {b[2]:30s} {b[0]:8.1f} us | max rel diff {err:.1e}", flush=True)
     if "ablate" in args:
         evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         for n in [x for x in names if x in ("dec2_3x3", "dec3_3x3", "dec4_3x3")] or ["dec2_3x3"]:
