@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 300
+#define OCTA_HIP_ABI_VERSION 301
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -110,6 +110,14 @@ int octa_pack_weight_convT(const float* w, int64_t s_ci, int64_t s_co, int64_t s
 /* y = act(conv(x, w) + bias).  bias: fp32 [Cout] or NULL. */
 int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                     void* y, octa_stream_t stream);
+/* The same conv, and in its epilogue the BatchNorm statistics of y (extra/resnest.py:25,34,86,90,182,224: every conv of the
+ * path is followed by a train-mode BatchNorm): stats[r][0][c] += sum (y - shift[c]), stats[r][1][c] += sum (y - shift[c])^2 over
+ * the pixels, r = one of `replicas` accumulators (float atomics; the caller zero-fills stats[replicas][2][Cout] and merges the
+ * replicas: octa_bn_train_fwd_sums).  shift (optional, [Cout]): the BatchNorm's running mean.  16-bit dtypes, act NONE only.
+ * *fused_host = 1 when the kernel that ran supports it, 0 when the conv ran on a kernel that does not (3x3 halo / resident
+ * weights): y is complete either way, stats untouched in the latter case and the caller runs the ordinary statistics pass. */
+int octa_conv2d_fwd_stats(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                          float* stats, const float* shift, int replicas, int* fused_host, octa_stream_t stream);
 /* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
 int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
                       octa_stream_t stream);
@@ -215,6 +223,12 @@ int octa_bn_train_fwd(const void* x, int ldx, int xoff, const float* gamma, cons
                       int C, int dtype, float eps, float momentum, int relu, float* mean, float* invstd,
                       float* running_mean, float* running_var, uint8_t* relu_mask, float* workspace,
                       octa_stream_t stream);
+/* Training forward from the sums octa_conv2d_fwd_stats left (shift = running_mean before this call's update, NULL = 0): a
+ * one-thread-per-channel merge of the replicas (double) + the apply launch; same outputs as octa_bn_train_fwd. */
+int octa_bn_train_fwd_sums(const void* x, int ldx, int xoff, const float* sums, int replicas, const float* gamma,
+                           const float* beta, const void* residual, int ldr, int roff, void* y, int ldy, int yoff,
+                           int64_t rows, int C, int dtype, float eps, float momentum, int relu, float* mean, float* invstd,
+                           float* running_mean, float* running_var, uint8_t* relu_mask, octa_stream_t stream);
 /* backward.  With relu != 0 the ReLU mask comes from relu_mask (as written by octa_bn_apply) when it
  * is given, else from the forward output y (y may be NULL when relu_mask is given).
  * dgamma/dbeta are ACCUMULATED (+=).  dres (optional) receives the masked dy. */

@@ -31,6 +31,10 @@ struct ConvArgs {
     int ldadd;
     int vec16;            // 16-byte output stores are aligned: ldy, yoff (and the upshuffle channel count) are multiples of 8
     int NgSt;             // channels stored per group: Ng, or round8(Ng) when the pad channels are zero-filled here
+    // BatchNorm statistics of the output, taken in the epilogue (octa_conv2d_fwd_stats; kernels that support it only):
+    float* stats;         // [stats_rep][2][stats_ctot] fp32 sums of d = y - shift and d*d, accumulated with float atomics; NULL = off
+    const float* stats_shift;   // per output channel (all groups), or NULL = 0
+    int stats_rep, stats_ctot;
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -135,6 +139,50 @@ __device__ __forceinline__ void addend_tile(V4 (&acc)[TN][TM], const ConvArgs& a
             for (int e = 0; e < 4; ++e)
                 if (nb + e < a.Ng) acc[i][j][e] += DT<T>::ld(ad + (size_t)m * a.ldadd + cbase + nb + e);
         }
+    }
+}
+
+// BatchNorm statistics in the conv epilogue (16-bit training path, layers.conv_bn): per output channel the sums of d = y - shift[c]
+// and d * d over the pixels of this workgroup's tile.  registers (the lane's TM pixel fragments) -> DPP row sums (the 16 pixel
+// lanes of a fragment column) -> LDS float atomics (the waves of the workgroup that hold the same channels) -> ONE pair of global
+// float atomics per channel and workgroup, into replica (workgroup id % stats_rep) of stats[rep][2][ctot] so that the ~10^3
+// workgroups of a big layer do not queue on one address.  The shift (the BatchNorm's running mean) keeps sum d*d - (sum d)^2 / n
+// free of the E[x^2] - E[x]^2 cancellation; octa_bn_train_fwd_sums merges the replicas in double.
+// nbase: first channel (inside the group) of this lane's fragment 0; mrow0: pixel row of this lane's fragment column 0;
+// lds: >= 2 * BN floats that no wave reads any more (the callers put a barrier in front).
+template <int BN, typename V4, int TN, int TM>
+__device__ __forceinline__ void stats_tile(const V4 (&acc)[TN][TM], const ConvArgs& a, int nbase, int n0, int mrow0, int g, float* lds, int wg_linear) {
+    for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    const bool lead = (threadIdx.x & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = nbase + i * 16 + e;
+            const float sh = (a.stats_shift && ch < a.Ng) ? a.stats_shift[g * a.Ng + ch] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const float d = (mrow0 + j * 16 < a.M) ? acc[i][j][e] - sh : 0.f;
+                s1 += d; s2 += d * d;
+            }
+            // sum over the 16 lanes of the row (= the 16 pixels of a fragment column)
+            s1 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s2), 0xB1, 0xF, 0xF, true));
+            s1 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s2), 0x4E, 0xF, 0xF, true));
+            s1 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x124, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s2), 0x124, 0xF, 0xF, true));
+            s1 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x128, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s2), 0x128, 0xF, 0xF, true));
+            if (lead && ch < a.Ng) { atomicAdd(&lds[2 * (ch - n0)], s1); atomicAdd(&lds[2 * (ch - n0) + 1], s2); }
+        }
+    }
+    __syncthreads();
+    float* const dst = a.stats + (size_t)(wg_linear % a.stats_rep) * 2 * a.stats_ctot + g * a.Ng + n0;
+    for (int c = threadIdx.x; c < BN; c += blockDim.x) {
+        if (n0 + c < a.Ng) { atomicAdd(dst + c, lds[2 * c]); atomicAdd(dst + a.stats_ctot + c, lds[2 * c + 1]); }
     }
 }
 
@@ -282,6 +330,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
     addend_tile<T>(acc, a, m0 + wm * TM * 16 + r, n0 + wn * TN * 16 + q * 4, g);
+    if constexpr (sizeof(T) == 2) {
+        if (a.stats) stats_tile<BN>(acc, a, n0 + wn * TN * 16 + q * 4, n0, m0 + wm * TM * 16 + r, g, (float*)&sA[0][0], blockIdx.x + blockIdx.y * gridDim.x);
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
@@ -752,9 +803,12 @@ static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // algo (octa_conv_desc.algo): 0 = heuristic, 1 = 4-wave kernels (halo / generic), 2 / 3 = 8-wave kernel with 256x128 / 128x256 slabs
+// *fused (optional): set to 1 when the kernel that ran accumulates a.stats in its epilogue (the generic 4-wave tiles and the
+// 8-wave kernel do; the 3x3 halo, resident-weight and LDS-DMA kernels do not and ignore a.stats)
 template <typename T>
-static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo = 0) {
+static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo = 0, int* fused = nullptr) {
     dim3 block(256);
+    if (fused) *fused = 0;
     const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW;
     if constexpr (sizeof(T) == 2) {
         static const int force8 = getenv("OCTA_IGEMM8") ? atoi(getenv("OCTA_IGEMM8")) : 0;
@@ -767,8 +821,8 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
             const double gf = 2.0 * (double)a.M * a.Ng * a.Kc * 8.0 * groups * 1e-9;
             if (gf >= thr && a.Cg % 64 == 0) want = (a.Ng >= 256) ? 3 : 2;
         }
-        if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }
-        if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); return OCTA_OK; }     // 4-wave 128x128 slab
+        if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); if (fused) *fused = 1; return OCTA_OK; }
+        if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); if (fused) *fused = 1; return OCTA_OK; }     // 4-wave 128x128 slab
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
         if (!a.addend && (want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
@@ -787,6 +841,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         }
         else { { if (pw) conv_igemm_kernel<T, 4, 1, 2, 4, true, (sizeof(T) == 2 ? 8 : 4)><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); else conv_igemm_kernel<T, 4, 1, 2, 4><<<dim3(cdiv(a.M, 128), cdiv(a.Ng, 64), groups), block, 0, st>>>(a); } note_kernel<T>("conv_igemm_kernel", 128, 64); }
         OCTA_CHECK_LAUNCH("conv_igemm");
+        if (fused) *fused = sizeof(T) == 2;
         return OCTA_OK;
     }
     if (conv_variant() >= 1 && !a.addend) {
@@ -828,6 +883,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         }
     }
     OCTA_CHECK_LAUNCH("conv_igemm");
+    if (fused) *fused = (sizeof(T) == 2 && !dma) ? 1 : 0;
     return OCTA_OK;
 }
 
@@ -852,7 +908,19 @@ static int check_desc(const octa_conv_desc* d, const char* who) {
     return OCTA_OK;
 }
 
+static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats, const float* shift,
+                           int replicas, int* fused, octa_stream_t stream);
 extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, octa_stream_t stream) {
+    return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, 0, nullptr, stream);
+}
+extern "C" int octa_conv2d_fwd_stats(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
+                                     const float* shift, int replicas, int* fused_host, octa_stream_t stream) {
+    OCTA_REQUIRE(stats && fused_host && replicas >= 1 && replicas <= 64, "octa_conv2d_fwd_stats: stats buffer, fused flag and 1..64 replicas");
+    OCTA_REQUIRE(d && d->dtype != OCTA_F32 && d->act == OCTA_ACT_NONE && !d->upshuffle, "octa_conv2d_fwd_stats: 16-bit, no fused activation, no upshuffle");
+    return conv2d_fwd_impl(d, x, w, bias, y, stats, shift, replicas, fused_host, stream);
+}
+static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats, const float* shift,
+                           int replicas, int* fused, octa_stream_t stream) {
     int rc = check_desc(d, "octa_conv2d_fwd");
     if (rc) return rc;
     OCTA_REQUIRE(x && w && y, "octa_conv2d_fwd: null pointer");
@@ -869,15 +937,16 @@ extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const voi
     a.addend = nullptr; a.ldadd = 0;
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
+    a.stats = stats; a.stats_shift = shift; a.stats_rep = replicas; a.stats_ctot = d->Cout;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
         a.NgSt = (a.Ng + 7) / 8 * 8;
     }
     if (d->upshuffle) OCTA_REQUIRE(d->ldy >= a.CoutT + d->yoff, "octa_conv2d_fwd: ldy too small for upshuffle");
     else OCTA_REQUIRE(d->ldy >= d->Cout + d->yoff, "octa_conv2d_fwd: ldy %d < yoff+Cout", d->ldy);
-    return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
-         : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
-                                 : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
+    return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream, 0, fused)
+         : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo, fused)
+                                 : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo, fused);
 }
 
 static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, const void* addend, int ldadd, octa_stream_t stream) {
@@ -903,6 +972,7 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
     a.addend = addend; a.ldadd = ldadd;
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
+    a.stats = nullptr; a.stats_shift = nullptr; a.stats_rep = 0; a.stats_ctot = 0;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
         a.NgSt = (a.Ng + 7) / 8 * 8;

@@ -282,6 +282,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * 4 * 16 + q * 4, g);
     addend_tile<T>(acc, a, m0 + wm * 4 * 16 + r, n0 + wn * 4 * 16 + q * 4, g);
+    if (a.stats) {
+        __syncthreads();                                   // every wave has left the K loop: the ring may be overwritten
+        stats_tile<BN>(acc, a, n0 + wn * 4 * 16 + q * 4, n0, m0 + wm * 4 * 16 + r, g, (float*)smem, blockIdx.x + blockIdx.y * gridDim.x);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + (wm * 4 + j) * 16 + r;

@@ -565,6 +565,36 @@ extern "C" int octa_bn_train_fwd(const void* x, int ldx, int xoff, const float* 
     return OCTA_OK;
 }
 
+// Training-mode forward when the producing conv already summed its output (octa_conv2d_fwd_stats): sums[r][0][c] = sum (x - shift),
+// sums[r][1][c] = sum (x - shift)^2 over replica r's share of the rows, shift = the running mean BEFORE this update (NULL: 0).
+// One thread per channel merges the replicas in double; then the ordinary apply launch.  Two launches instead of three (two for
+// the small tensors either way), and the statistics pass over the activation is gone.
+__global__ __launch_bounds__(256) void bn_sums_finalize_kernel(const float* __restrict__ sums, int R, int C, int64_t rows, float eps, float momentum,
+                                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm,
+                                                              float* __restrict__ rv) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < R; ++r) { s1 += (double)sums[((size_t)r * 2) * C + c]; s2 += (double)sums[((size_t)r * 2 + 1) * C + c]; }
+    const double n = (double)rows, sh = rm ? (double)rm[c] : 0.0;
+    const double m = sh + s1 / n;
+    double var = (s2 - s1 * s1 / n) / n;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+    if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+}
+extern "C" int octa_bn_train_fwd_sums(const void* x, int ldx, int xoff, const float* sums, int replicas, const float* gamma, const float* beta,
+                                      const void* residual, int ldr, int roff, void* y, int ldy, int yoff, int64_t rows, int C, int dtype,
+                                      float eps, float momentum, int relu, float* mean, float* invstd, float* running_mean, float* running_var,
+                                      uint8_t* relu_mask, octa_stream_t stream) {
+    OCTA_REQUIRE(x && y && sums && gamma && beta && mean && invstd && replicas >= 1, "octa_bn_train_fwd_sums: null pointer");
+    bn_sums_finalize_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(sums, replicas, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
+    OCTA_CHECK_LAUNCH("bn_sums_finalize");
+    return octa_bn_apply(x, ldx, xoff, mean, invstd, gamma, beta, residual, ldr, roff, y, ldy, yoff, rows, C, dtype, relu, relu_mask, stream);
+}
+
 // ws layout after finalize: fin[0][c] = sum dy' / N ; fin[1][c] = sum dy' xhat / N
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nby, int C, int64_t rows, float* __restrict__ fin,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {

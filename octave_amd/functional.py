@@ -448,10 +448,27 @@ def _choose_algo(kind: str, d, launch) -> int:
     return best
 
 
-def _launch_fwd(d, x, wp, bias, y):
+class ConvStats:
+    """BatchNorm statistics taken in the producing conv's epilogue (octa_conv2d_fwd_stats): `sums` is a zero-filled fp32
+    (replicas, 2, Cout) buffer, `shift` the BatchNorm's running mean (or None).  `fused` is set by the conv launch: False when
+    the kernel chosen for this shape cannot do it (3x3 halo / resident-weight kernels) -- BatchNorm then runs its own pass."""
+    __slots__ = ("sums", "shift", "replicas", "fused")
+
+    def __init__(self, cout: int, shift: Optional[Tensor], device, replicas: int = 16):
+        t = ZERO_SLAB.take((replicas, 2, cout))
+        self.sums = t if (t is not None and t.device == device) else torch.zeros((replicas, 2, cout), dtype=torch.float32, device=device)
+        self.shift, self.replicas, self.fused = shift, replicas, False
+
+
+def _launch_fwd(d, x, wp, bias, y, stats: Optional["ConvStats"] = None):
     L, st = lib(), _st()
     px, pw, pb, py = _p(x), _p(wp), _p(bias), _p(y)
     d.algo = _choose_algo("fwd", d, lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
+    if stats is not None:
+        flag = ctypes.c_int(0)
+        L.octa_conv2d_fwd_stats(ctypes.byref(d), px, pw, pb, py, _p(stats.sums), _p(stats.shift), stats.replicas, ctypes.byref(flag), st)
+        stats.fused = bool(flag.value)
+        return
     L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
 
 
@@ -511,7 +528,7 @@ def _densify(groups: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pa
 
 
 def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, groups: int, act: int = ACT_NONE,
-                 out: Optional[Tensor] = None) -> Tensor:
+                 out: Optional[Tensor] = None, stats: Optional["ConvStats"] = None) -> Tensor:
     B, Cin, H, W, Cout, Cin_g, KH, KW, OH, OW = _conv_geometry(x, w, stride, pad)
     if Cin != Cin_g * groups:
         raise OctaError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
@@ -527,7 +544,9 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
         d.zero_pad = int(zp)
         wp = _packed(w, "fwd", x.dtype, groups, d.cin_g_pad)
-    _launch_fwd(d, x, wp, bias, y)
+    if stats is not None and (x.dtype == torch.float32 or act != ACT_NONE):
+        stats = None
+    _launch_fwd(d, x, wp, bias, y, stats)
     _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
     return y
 
@@ -769,7 +788,7 @@ def _bn_ws(rows: int, C: int, device) -> Tensor:
 
 
 def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv: Optional[Tensor], momentum: float, eps: float,
-               training: bool, relu: bool, residual: Optional[Tensor] = None):
+               training: bool, relu: bool, residual: Optional[Tensor] = None, pre_sums: Optional["ConvStats"] = None):
     x = to_nhwc(x)
     B, C, H, W = x.shape
     rows = B * H * W
@@ -783,6 +802,14 @@ def raw_bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, rm: Optional[Tensor], rv:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
+        if pre_sums is not None and pre_sums.fused and pre_sums.shift is rm:
+            # the producing conv summed its own output: replica merge + apply, no statistics pass over x
+            L.octa_bn_train_fwd_sums(_p(x), nhwc_ld(x), 0, _p(pre_sums.sums), pre_sums.replicas, _p(gamma), _p(beta), _p(res),
+                                     nhwc_ld(res) if res is not None else 0, 0, _p(y), nhwc_ld(y), 0, rows, C, _dt(x), eps, momentum, int(relu),
+                                     _p(mean), _p(invstd), _p(rm), _p(rv), _p(mask), _st())
+            if rm is not None:
+                bump_param_epoch()
+            return y, mean, invstd, x, mask
         L.octa_bn_train_fwd(_p(x), nhwc_ld(x), 0, _p(gamma), _p(beta), _p(res), nhwc_ld(res) if res is not None else 0, 0,
                             _p(y), nhwc_ld(y), 0, rows, C, _dt(x), eps, momentum, int(relu), _p(mean), _p(invstd), _p(rm), _p(rv),
                             _p(mask), _p(_bn_ws(rows, C, x.device)), _st())
@@ -885,9 +912,9 @@ class Conv2dFn(Function):
     """nn.Conv2d (+ fused activation).  Weight OIHW-logical fp32 parameter, any strides."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, groups, act, holder=None):
+    def forward(ctx, x, w, bias, stride, pad, groups, act, holder=None, stats=None):
         _require_gpu(x)
-        y = raw_conv_fwd(x, w, bias, stride, pad, groups, act)
+        y = raw_conv_fwd(x, w, bias, stride, pad, groups, act, stats=stats)
         ctx.holder = holder
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
@@ -922,11 +949,11 @@ class Conv2dFn(Function):
             raw_colsum(dy, db)
         if want_b:
             db = _ret(b, db)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE, grad_holder=None):
-    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act, grad_holder)
+def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE, grad_holder=None, stats=None):
+    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act, grad_holder, stats)
 
 
 class ConvTranspose2x2Fn(Function):
@@ -974,9 +1001,9 @@ class BatchNormFn(Function):
     """Training/eval BatchNorm2d with fused ReLU and residual add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, momentum, eps, training, relu, residual):
+    def forward(ctx, x, gamma, beta, rm, rv, momentum, eps, training, relu, residual, pre_sums=None):
         _require_gpu(x)
-        y, mean, invstd, xn, mask = raw_bn_fwd(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual)
+        y, mean, invstd, xn, mask = raw_bn_fwd(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual, pre_sums)
         ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
         ctx.beta_ref = beta
         ctx.save_for_backward(xn, y if (relu and mask is None) else None, mean, invstd, gamma, mask)
@@ -994,11 +1021,11 @@ class BatchNormFn(Function):
         if dgamma is None or dbeta is None:
             dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
         dx, dres = raw_bn_bwd(dy, x, y, mean, invstd, gamma, ctx.relu, ctx.has_res and ctx.needs_input_grad[9], dgamma, dbeta, mask)
-        return dx, _ret(gamma, dgamma), _ret(beta, dbeta), None, None, None, None, None, None, dres
+        return dx, _ret(gamma, dgamma), _ret(beta, dbeta), None, None, None, None, None, None, dres, None
 
 
-def batch_norm(x, gamma, beta, rm, rv, momentum=0.1, eps=1e-5, training=True, relu=False, residual=None):
-    return BatchNormFn.apply(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual)
+def batch_norm(x, gamma, beta, rm, rv, momentum=0.1, eps=1e-5, training=True, relu=False, residual=None, pre_sums=None):
+    return BatchNormFn.apply(x, gamma, beta, rm, rv, momentum, eps, training, relu, residual, pre_sums)
 
 
 class MaxPool3s2Fn(Function):

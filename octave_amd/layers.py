@@ -1,6 +1,7 @@
 """nn.Module leaves whose forward runs on libocta_hip.so.  They subclass the torch modules only to
 inherit parameter registration, initialisation and state_dict layout (identical keys/shapes to the
 reference); no ATen compute kernel is called in their forward."""
+import os
 import weakref
 
 import torch
@@ -48,8 +49,8 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("octave_amd.Conv2d: dilation 1 and zero padding only")
         self.act = act
 
-    def forward(self, x, grad_holder=None):
-        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act, grad_holder)
+    def forward(self, x, grad_holder=None, stats=None):
+        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act, grad_holder, stats)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -68,7 +69,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d (batch statistics in training, running-stat update) with optional fused
     ReLU / residual add, selected per call."""
 
-    def forward(self, x, relu: bool = False, residual=None):
+    def forward(self, x, relu: bool = False, residual=None, pre_sums=None):
         training = self.training or (self.running_mean is None)
         mom = 0.0 if self.momentum is None else self.momentum
         if training and self.track_running_stats and self.num_batches_tracked is not None:
@@ -78,7 +79,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 bump_counter(self.num_batches_tracked)
         return F_.batch_norm(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                             self.running_var if self.track_running_stats else None, mom, self.eps, training, relu, residual)
+                             self.running_var if self.track_running_stats else None, mom, self.eps, training, relu, residual, pre_sums)
 
 
 class ReLU(nn.Module):
@@ -110,6 +111,10 @@ def use_channels_last_weights(module: nn.Module) -> nn.Module:
 # (w' = w * gamma / sqrt(var + eps) per output channel) and into a bias (b' = (b - mean) * gamma / sqrt(var + eps) + beta)
 # when the operand is packed; the folded parameters are rebuilt only when a weight, an affine parameter or a running
 # statistic changes (version counters).  Training mode and grad-enabled eval go through the unfused layers.
+# BatchNorm statistics in the producing conv's epilogue: built, parity-tested, measured at break-even in the step (DESIGN.md 9.3:
+# the epilogue costs the 25-40 us pointwise kernels what the separate statistics pass cost) -> off unless OCTA_FUSE_BN_STATS=1
+_FUSE_BN_STATS = os.environ.get("OCTA_FUSE_BN_STATS", "0") == "1"
+_FUSE_BN_MIN_BYTES = int(float(os.environ.get("OCTA_FUSE_BN_STATS_MIN_MB", "16")) * (1 << 20))   # output tensors below this keep the two-launch small-tensor BatchNorm
 _FOLD_CACHE = {}
 _IDENT = {}
 
@@ -143,11 +148,24 @@ def _identity_stats(C: int, device):
     return t
 
 
+def _conv_out_bytes(conv, x) -> int:
+    k, s_, p_ = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    oh, ow = (x.shape[2] + 2 * p_ - k) // s_ + 1, (x.shape[3] + 2 * p_ - k) // s_ + 1
+    return x.shape[0] * conv.out_channels * oh * ow * x.element_size()
+
+
 def conv_bn(conv: "Conv2d", bn: "BatchNorm2d", x, relu: bool = False, residual=None, grad_holder=None):
     """bn(conv(x)) [+ residual] [-> relu].  Training: the two fused-statistics layers.  Inference (eval mode, no grad): one conv
     launch with the BatchNorm folded into its packed weights and bias (+ one add/ReLU pass when there is a residual).
     `grad_holder` (functional.GradHolder): the conv's data gradient adds the gradient parked there by functional.stash_grad."""
     if bn.training or bn.running_mean is None or torch.is_grad_enabled():
+        if (_FUSE_BN_STATS and bn.training and bn.track_running_stats and bn.running_mean is not None and conv.act == ACT_NONE
+                and x.dtype in (torch.bfloat16, torch.float16) and x.is_cuda and _conv_out_bytes(conv, x) >= _FUSE_BN_MIN_BYTES):
+            # 16-bit training: the conv sums its own output for the BatchNorm (per-channel sum / sum of squares around the
+            # running mean, in its epilogue); BatchNorm is then a replica merge + the apply launch
+            st = F_.ConvStats(conv.out_channels, bn.running_mean, x.device)
+            y = conv(x, grad_holder, st)
+            return bn(y, relu=relu, residual=residual, pre_sums=st)
         return bn(conv(x, grad_holder) if grad_holder is not None else conv(x), relu=relu, residual=residual)
     wf, bf = _fold_entry(conv, bn)
     act = ACT_RELU if (relu and residual is None) else ACT_NONE

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(L):
     dll = ctypes.CDLL(os.path.join(ROOT, "octave_amd", "libocta_hip.so"))
     for name in L.signatures:
         assert hasattr(dll, name), f"{name} declared in octa_hip.h but not exported"
-    assert L.octa_version() >= 300
+    assert L.octa_version() >= 301
 
 
 def test_bad_arguments_return_error_codes_not_crashes(L):

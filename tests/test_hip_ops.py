@@ -738,3 +738,66 @@ def test_wgrad_batch_vs_torch(dev, dtype):
         check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))
         if db is not None:
             check(f"wgrad batch bias {j}", db, gb, 0, 1e-3 * float(gb.abs().max()) + 1e-3)
+
+
+# ----------------------------------------------------------------------------------------- round 3: BatchNorm statistics in the conv epilogue
+STATS_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, groups, bias, algo            kernel that takes the statistics
+    (4, 64, 25, 25, 256, 1, 1, 0, 1, False, 0),       # pointwise, 64x64 tiles (generic 4-wave kernel)
+    (3, 256, 13, 13, 72, 1, 1, 0, 1, False, 6),       # N tail (72 channels), 128x64 tiles
+    (2, 128, 20, 20, 256, 3, 1, 1, 2, True, 2),       # grouped 3x3 with bias on the 8-wave kernel (256x128 slab)
+    (2, 128, 17, 19, 320, 1, 1, 0, 1, False, 3),      # 8-wave 128x256 slab, N tail, odd image (M tail)
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, False, 1),        # 3x3 halo kernel: NOT fused, the BatchNorm runs its own pass
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_bn_fused_statistics_vs_separate_pass(dev, case, dtype):
+    """layers.conv_bn in 16-bit training mode: the conv sums its own output for the BatchNorm (octa_conv2d_fwd_stats ->
+    octa_bn_train_fwd_sums) -- output, batch statistics, running statistics and every gradient against the separate
+    statistics pass on the same operands, with a NON-zero running mean as the shift and twice in a row (momentum update)."""
+    from octave_amd import functional as F_
+    from octave_amd import layers as Ly
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, k, s, p, g, bias, algo = case
+    gen = torch.Generator().manual_seed(31)
+    x = (torch.randn(B, Cin, H, W, generator=gen) + 0.3).to(dev)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(5)
+        conv = Ly.Conv2d(Cin, Cout, k, s, p, groups=g, bias=bias).to(dev)
+        bn = Ly.BatchNorm2d(Cout).to(dev).train()
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.linspace(-0.5, 0.5, Cout))
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cout))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, Cout))
+        Ly.use_channels_last_weights(conv)
+        old, Ly._FUSE_BN_STATS = Ly._FUSE_BN_STATS, fused
+        old_min, Ly._FUSE_BN_MIN_BYTES = Ly._FUSE_BN_MIN_BYTES, 0
+        F_._ALGO_OVERRIDE = algo
+        try:
+            xin = F_.to_nhwc(x, dtype=dtype).detach().requires_grad_(True)
+            kinds = []
+            for _ in range(2):
+                y = Ly.conv_bn(conv, bn, xin, relu=True)
+                kinds.append(lib().octa_last_conv_kernel().decode())
+            gy = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(6)).to(dev).to(dtype)
+            y.backward(F_.to_nhwc(gy))
+        finally:
+            Ly._FUSE_BN_STATS = old
+            Ly._FUSE_BN_MIN_BYTES = old_min
+            F_._ALGO_OVERRIDE = 0
+        res[fused] = (F_.to_nchw_f32(y.detach()), bn.running_mean.clone(), bn.running_var.clone(), F_.to_nchw_f32(xin.grad), conv.weight.grad.clone(),
+                      bn.weight.grad.clone(), bn.bias.grad.clone(), kinds)
+    a, b = res[True], res[False]
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (a[0] - b[0]).abs().max().item() <= 2 * ulp * b[0].abs().max().item() + 1e-6, (case, a[7], (a[0] - b[0]).abs().max().item())
+    assert (a[1] - b[1]).abs().max().item() <= 2e-5 * (1.0 + b[1].abs().max().item()), (a[1] - b[1]).abs().max().item()
+    assert (a[2] - b[2]).abs().max().item() <= 2e-4 * b[2].abs().max().item(), (a[2] - b[2]).abs().max().item()
+    # gradients in relative L2: an output within an ulp of the ReLU threshold may land on the other side (its whole gradient flips
+    # on / off), which is a handful of elements, not a statistics error
+    for i, nm in ((3, "dx"), (4, "dw"), (5, "dgamma"), (6, "dbeta")):
+        rel = (a[i].double() - b[i].double()).norm().item() / max(b[i].double().norm().item(), 1e-30)
+        assert rel <= 1e-2, (nm, rel)
+    print(f"[conv+bn stats {case}] kernel {a[7][0]}")
