@@ -695,8 +695,8 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
         for (size_t i = i0; i < i1; ++i) maxsteps = std::max(maxsteps, plans[i].steps);
         // stages per workgroup S: minimise rounds(S) * (S + E), rounds = ceil(workgroups / 256 CUs), E ~ prologue + 256 KB of float
         // atomics per workgroup in units of a 32-pixel stage
-        static const int E = getenv("OCTA_WG9_EPI") ? atoi(getenv("OCTA_WG9_EPI")) : 16;
-        static const int minsteps = getenv("OCTA_WG9_MINSTEPS") ? atoi(getenv("OCTA_WG9_MINSTEPS")) : 8;
+        static const int E = getenv("OCTA_WG9_EPI") ? atoi(getenv("OCTA_WG9_EPI")) : 40;
+        static const int minsteps = getenv("OCTA_WG9_MINSTEPS") ? atoi(getenv("OCTA_WG9_MINSTEPS")) : 24;
         auto blocks_at = [&](int64_t s) { int64_t b = 0; for (size_t i = i0; i < i1; ++i) b += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups * ((plans[i].steps + s - 1) / s); return b; };
         int64_t S = maxsteps, best = -1;
         for (int64_t s = maxsteps; s >= minsteps; s = (s > 64 ? s - s / 32 : s - 1)) {

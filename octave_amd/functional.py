@@ -620,7 +620,7 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
 # ~60 launches per step disappear.  Only jobs that accumulate into a pre-assigned gradient buffer (gradient sink)
 # are queued: autograd never sees their result, so nobody can read it before the flush.
 _WGRAD_Q = None
-_WGRAD_FLUSH_MIN = int(os.environ.get("OCTA_WGRAD_FLUSH_MIN", "8"))      # swept in situ (4 / 8 / 16 / 30 / all at the end): 16 is 0.1 ms faster but its bigger batches miss L2 more (PMC: 6.6 -> 8.4 GB of fetches per step)
+_WGRAD_FLUSH_MIN = int(os.environ.get("OCTA_WGRAD_FLUSH_MIN", "16"))      # swept in situ (4 / 8 / 16 / 30 / all at the end): 16 is 0.1 ms faster but its bigger batches miss L2 more (PMC: 6.6 -> 8.4 GB of fetches per step)
 _MARK_HOOKS = []
 
 
