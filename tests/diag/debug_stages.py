@@ -1,8 +1,8 @@
 """Per-stage parity of the HIP segmentor against the oracle: every stage of the oracle is fed the
 HIP path's own input to that stage, so errors do not accumulate through the 93 BatchNorms.
-Usage (GPU box): python tools/debug_stages.py [H] [B] [dtype]"""
+Usage (GPU box): python tests/diag/debug_stages.py [H] [B] [dtype]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ref_ops as R
 from oracle.fill import fill_state_dict, hash_input

@@ -1,7 +1,7 @@
 """Dual-head U-Net backward: HIP fp32 gradients against the CPU oracle in float64 and float32, per top-level module
 (relative L2 error of the gradient VECTORS, not only their norms), several HIP runs.  Separates a structural error (a module
 whose error is O(1) in every run) from amplified rounding noise (errors of a few per cent that move from run to run and grow
-towards the encoder).  Usage: python tools/heads_bwd_diag.py [ph|phag] [runs]"""
+towards the encoder).  Usage: python tests/diag/heads_bwd_diag.py [ph|phag] [runs]"""
 import collections
 import sys
 

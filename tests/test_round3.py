@@ -33,7 +33,7 @@ def _band_check(tag, got, G, pre32, pre64, floor=1e-3, chaotic=False):
     """relative deviation of `got` norms from the float64 reference vs the reference's own fp32 deviation (4x band rule).
     chaotic=True (the dual-head U-Nets at B = 3: every split-attention bn1 normalises over THREE samples): any fp32 evaluation
     is one draw of a heavy-tailed, partly discrete noise -- a ReLU or a 3-sample BatchNorm channel on the edge flips and the
-    encoder's gradient norms move by several per cent.  profiles/r03_heads_bwd_diag.txt (tools/heads_bwd_diag.py) shows it per
+    encoder's gradient norms move by several per cent.  profiles/r03_heads_bwd_diag.txt (tests/diag/heads_bwd_diag.py) shows it per
     module for three HIP runs and the CPU oracle: relative L2 errors of 3-7 % in the encoder for EVERY fp32 evaluation (oracle
     fp32: 2.7-3.5 %), bimodal between HIP runs, 1e-5 .. 1e-3 in the second decoder branch and the heads, and no module with an
     O(1) error.  The bulk statistics then get an absolute floor of 1.5 % / 5 % next to the 4x band; a structural error (a
