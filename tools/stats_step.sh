@@ -8,5 +8,6 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 $R/bench.py --steps 5 --warmup 2 --launch graph --no-cpu-baseline --no-roofline "$@" > $OUT/run.log 2>&1
 cd $R
+python3 tools/trace_last_step.py $OUT/k_kernel_trace.csv > $OUT/last_step.txt 2>&1
 rm -f $OUT/*kernel_trace.csv
 python3 tools/stats_summary.py $OUT/k_kernel_stats.csv 9
