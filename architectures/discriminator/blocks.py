@@ -167,7 +167,7 @@ class DiscriminatorBlock(nn.Module):
         for i in range(self.depth):
             try:
                 s = self.squeeze_dict[f'squeeze_{i}'][0](s)
-                s = F_.DiscCatFn.apply(s, y[i + 1])
+                s = F_.DiscCatFn.apply(s, y[i + 1], True)      # the map goes into the squeeze output's pad channels
                 s = self.spectral_dict[f'spectral_{i}'][0](s)
             except Exception as e:
                 raise Exception(f'Exception raised in depth = {i}') from e

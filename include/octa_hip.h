@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 301
+#define OCTA_HIP_ABI_VERSION 302
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -427,10 +427,12 @@ int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u
  * x NHWC [B, n] of dtype, w fp32 [n] in the same (h,w,c) order. */
 int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n,
                       int dtype, float sign, const float* sign_dev /* optional device scalar, multiplies sign */,
-                      octa_stream_t stream);
+                      int out_prezeroed /* 1: out is already zero (no init launch) */, octa_stream_t stream);
+/* dx = sign * dout[b] * w;  dw += sign * sum_b dout[b] x[b];  dbias += sign * sum_b dout[b].  dw_c = 0: dw in x's (h,w,c) order;
+ * dw_c = C: dw is [C][n / C], the (1, C, H, W) parameter's own order (a gradient-sink target). */
 int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw,
                       float* dbias, int B, int64_t n, int dtype, float sign, const float* sign_dev,
-                      octa_stream_t stream);
+                      int dw_c, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: fused Adam over a flat fp32 parameter arena (train step a17).

@@ -213,14 +213,14 @@ extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, con
 // ------------------------------------------------------------------------------------------ full-extent conv = dot product
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int64_t n,
-                                                           float sign, const float* __restrict__ sign_dev, int nblk) {
+                                                           float sign, const float* __restrict__ sign_dev, int nblk, const float* __restrict__ bias) {
     __shared__ float red[16];
     if (sign_dev) sign *= sign_dev[0];
     const int b = blockIdx.y;
     float acc[1] = {0.f};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) acc[0] += DT<T>::ld(x + b * n + i) * w[i];
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out + b, sign * acc[0]);
+    if (threadIdx.x == 0) atomicAdd(out + b, sign * (acc[0] + ((bias && blockIdx.x == 0) ? bias[0] : 0.f)));
 }
 __global__ void fullconv_init_kernel(const float* __restrict__ bias, float* __restrict__ out, int B, float sign, const float* __restrict__ sign_dev) {
     if (sign_dev) sign *= sign_dev[0];
@@ -228,17 +228,20 @@ __global__ void fullconv_init_kernel(const float* __restrict__ bias, float* __re
     if (i < B) out[i] = sign * (bias ? bias[0] : 0.f);
 }
 extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n, int dtype, float sign,
-                                 const float* sign_dev, octa_stream_t stream) {
+                                 const float* sign_dev, int out_prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && out && B > 0 && n > 0, "octa_fullconv_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    fullconv_init_kernel<<<cdiv(B, 64), 64, 0, st>>>(bias, out, B, sign, sign_dev);
-    OCTA_CHECK_LAUNCH("fullconv_init");
+    if (!out_prezeroed) {
+        fullconv_init_kernel<<<cdiv(B, 64), 64, 0, st>>>(bias, out, B, sign, sign_dev);
+        OCTA_CHECK_LAUNCH("fullconv_init");
+    }
+    const float* badd = out_prezeroed ? bias : nullptr;      // zeroed `out`: the first workgroup of every sample adds the bias itself
     int nblk = (int)(cdiv64(n, 256 * 8) > 64 ? 64 : cdiv64(n, 256 * 8));
     if (nblk < 1) nblk = 1;
     dim3 grid(nblk, B);
-    if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, sign_dev, nblk);
-    else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, sign_dev, nblk);
-    else if (dtype == OCTA_F16) fullconv_fwd_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, w, out, n, sign, sign_dev, nblk);
+    if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, sign_dev, nblk, badd);
+    else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, sign_dev, nblk, badd);
+    else if (dtype == OCTA_F16) fullconv_fwd_kernel<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, w, out, n, sign, sign_dev, nblk, badd);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_fwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_fwd");
     return OCTA_OK;
@@ -247,8 +250,9 @@ extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bia
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dout,
                                                            T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int B, int64_t n,
-                                                           float sign, const float* __restrict__ sign_dev) {
+                                                           float sign, const float* __restrict__ sign_dev, int dw_c) {
     if (sign_dev) sign *= sign_dev[0];
+    const int64_t hw = dw_c > 0 ? n / dw_c : 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float wi = w[i];
         float g = 0.f;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__
             if (dx) DT<T>::st(dx + b * n + i, d * wi);
             g += d * DT<T>::ld(x + b * n + i);
         }
-        if (dw) dw[i] += g;
+        if (dw) dw[dw_c > 0 ? (i % dw_c) * hw + i / dw_c : i] += g;      // dw_c: dw is [C][HW] (the parameter's own OIHW order)
     }
     if (dbias && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
@@ -266,13 +270,13 @@ __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__
     }
 }
 extern "C" int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw, float* dbias, int B, int64_t n,
-                                 int dtype, float sign, const float* sign_dev, octa_stream_t stream) {
-    OCTA_REQUIRE(x && w && dout && B > 0 && n > 0, "octa_fullconv_bwd: bad arguments");
+                                 int dtype, float sign, const float* sign_dev, int dw_c, octa_stream_t stream) {
+    OCTA_REQUIRE(x && w && dout && B > 0 && n > 0 && dw_c >= 0 && (dw_c == 0 || n % dw_c == 0), "octa_fullconv_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)(cdiv64(n, 256) > 2048 ? 2048 : cdiv64(n, 256));
-    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev);
-    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev);
-    else if (dtype == OCTA_F16) fullconv_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, w, dout, (f16_t*)dx, dw, dbias, B, n, sign, sign_dev);
+    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
+    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
+    else if (dtype == OCTA_F16) fullconv_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, w, dout, (f16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_bwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_bwd");
     return OCTA_OK;

@@ -1501,23 +1501,29 @@ class DiscCatFn(Function):
     y a user-facing NCHW fp32 map; the result lives in a buffer padded to a multiple of 8."""
 
     @staticmethod
-    def forward(ctx, s, y):
+    def forward(ctx, s, y, inplace=False):
         s = to_nhwc(s)
         B, Cs, H, W = s.shape
         Cy = y.shape[1]
         C = Cs + Cy
-        out = nhwc_empty(B, C, H, W, s.dtype, s.device, pad_written=True)
         ld = round8(C)
         L = lib()
         lds = nhwc_ld(s)
-        if lds == ld and s.storage_offset() % 8 == 0:
-            # s lives in a buffer of the same padded width (its pad channels are zero): ONE 16-byte-chunk copy of all ld channels,
-            # then the map overwrites channels Cs .. Cs+Cy-1 and zero-fills the rest
-            L.octa_copy_channels(_p(s), H, W, lds, 0, _p(out), H, W, ld, 0, B, ld, _dt(s), 0, _st())
-        else:
-            s32 = to_nchw_f32(s)
-            L.octa_nchw_to_nhwc(_p(s32), s32.stride(0), s32.stride(1), s32.stride(2), s32.stride(3), _p(out), B, Cs, H, W, ld, 0, Cs, _dt(s), _st())
         yf = y.float()
+        if inplace and lds == ld and s.storage_offset() % 8 == 0 and s.stride() == (H * W * ld, 1, W * ld, ld):
+            # s (the squeeze conv's own output, read again only by that conv's activation backward, channels < Cs) lives in a buffer
+            # of the padded width: the map goes into its pad channels Cs .. Cs+Cy-1 (the rest re-zeroed) and the result is a wider
+            # view of the same storage.  No copy of s.
+            out = torch.as_strided(s, (B, C, H, W), (H * W * ld, 1, W * ld, ld))
+        else:
+            out = nhwc_empty(B, C, H, W, s.dtype, s.device, pad_written=True)
+            if lds == ld and s.storage_offset() % 8 == 0:
+                # same padded width (pad channels zero): ONE 16-byte-chunk copy of all ld channels, then the map overwrites
+                # channels Cs .. Cs+Cy-1 and zero-fills the rest
+                L.octa_copy_channels(_p(s), H, W, lds, 0, _p(out), H, W, ld, 0, B, ld, _dt(s), 0, _st())
+            else:
+                s32 = to_nchw_f32(s)
+                L.octa_nchw_to_nhwc(_p(s32), s32.stride(0), s32.stride(1), s32.stride(2), s32.stride(3), _p(out), B, Cs, H, W, ld, 0, Cs, _dt(s), _st())
         L.octa_nchw_to_nhwc(_p(yf), yf.stride(0), yf.stride(1), yf.stride(2), yf.stride(3), _p(out), B, Cy, H, W, ld, Cs, ld - Cs, _dt(s), _st())
         ctx.cfg = (Cs, Cy)
         return out
@@ -1530,9 +1536,11 @@ class DiscCatFn(Function):
         B, C, H, W = d.shape
         ld = nhwc_ld(d)
         ds = d[:, :Cs]
-        dy = torch.empty((B, Cy, H, W), dtype=torch.float32, device=d.device)
-        lib().octa_nhwc_to_nchw(_p(d), ld, Cs, _dt(d), _p(dy), B, Cy, H, W, 0, _st())
-        return ds, dy
+        dy = None
+        if ctx.needs_input_grad[1]:            # the generator pass; the discriminator's own step feeds detached maps
+            dy = torch.empty((B, Cy, H, W), dtype=torch.float32, device=d.device)
+            lib().octa_nhwc_to_nchw(_p(d), ld, Cs, _dt(d), _p(dy), B, Cy, H, W, 0, _st())
+        return ds, dy, None
 
 
 class SpectralNormFn(Function):
@@ -1550,6 +1558,7 @@ class SpectralNormFn(Function):
         uv = torch.empty((Cout + K,), dtype=torch.float32, device=w.device)      # the u, v THIS forward used (later forwards move them on)
         lib().octa_spectral_norm_fwd(_p(wd), _p(u), _p(v), Cout, K, int(training), eps, _p(sigma), _p(wsn), _p(ws), _p(uv), pz, _st())
         ctx.save_for_backward(wsn, uv, sigma)
+        ctx.w_ref = w
         return wsn
 
     @staticmethod
@@ -1565,8 +1574,13 @@ class SpectralNormFn(Function):
                 khw = dwsn.shape[2] * dwsn.shape[3]
             else:
                 dwsn = dwsn.contiguous()
-        dw = torch.empty_like(wsn)
         ws, pz = _zeroed_f32((1,), wsn.device)
+        sw = _sink(ctx.w_ref)
+        if sw is not None and sw.is_contiguous():
+            # gradient sink: += straight into weight_orig's pre-assigned gradient (no temporary, no accumulation kernel of autograd's)
+            lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(uv), _p(uv[Cout:]), _p(sigma), Cout, K, _p(sw), _p(ws), 1, pz, khw, _st())
+            return None, None, None, None, None
+        dw = torch.empty_like(wsn)
         lib().octa_spectral_norm_bwd(_p(dwsn), _p(wsn), _p(uv), _p(uv[Cout:]), _p(sigma), Cout, K, _p(dw), _p(ws), 0, pz, khw, _st())
         return dw, None, None, None, None
 
@@ -1580,15 +1594,14 @@ class FullConvFn(Function):
         B, C, H, W = x.shape
         if tuple(w.shape) != (1, C, H, W):
             raise OctaError(f"full conv: weight {tuple(w.shape)} does not cover input {tuple(x.shape)}")
-        wp = torch.empty((H * W * C,), dtype=torch.float32, device=x.device)
-        s = w.stride()
-        lib().octa_pack_weight_fwd(_p(w.detach()), s[0], s[1], s[2], s[3], _p(wp), 1, C, H, W, 1, C, OCTA_F32, _st())
-        out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
-        lib().octa_fullconv_fwd(_p(x), _p(wp), _p(bias), _p(out), B, H * W * C, _dt(x), float(sign), _p(sign_dev), _st())
+        wp = _packed(w, "fwd", torch.float32, 1, C)          # (h, w, c) order; cached per parameter, refreshed with the other operands
+        out, pz = _zeroed_f32((B, 1), x.device)
+        lib().octa_fullconv_fwd(_p(x), _p(wp), _p(bias), _p(out), B, H * W * C, _dt(x), float(sign), _p(sign_dev), pz, _st())
         ctx.sign = float(sign)
         ctx.has_bias = bias is not None
+        ctx.refs = (w, bias)
         ctx.save_for_backward(x, wp, sign_dev)
-        return out
+        return out                                   # (inside a TrainStep this is a zero-slab slice: valid until the phase ends, which is as long as the loss needs it)
 
     @staticmethod
     @once_differentiable
@@ -1597,11 +1610,15 @@ class FullConvFn(Function):
         B, C, H, W = x.shape
         dout = dout.float().contiguous()
         dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
-        dwp = torch.zeros_like(wp)
+        w, bias = ctx.refs
+        sw, sb = _sink(w), _sink(bias)
+        if sw is not None and sw.is_contiguous() and (not ctx.has_bias or sb is not None):
+            # gradient sinks: += straight into the (1, C, H, W) parameter gradient and the bias gradient
+            lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(sw), _p(sb), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, _st())
+            return dx, None, None, None, None
+        dw = torch.zeros((1, C, H, W), dtype=torch.float32, device=x.device)
         db = torch.zeros((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dwp), _p(db), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), _st())
-        dw = torch.empty((1, C, H, W), dtype=torch.float32, device=x.device)
-        lib().octa_nhwc_to_nchw(_p(dwp), C, 0, OCTA_F32, _p(dw), 1, C, H, W, 0, _st())
+        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dw), _p(db), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, _st())
         return dx, dw, db, None, None
 
 

@@ -408,6 +408,11 @@ class TrainStep:
         defer_bn_counters(True)
         self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
+        self._disc_stream = None
+        self._disc_slab = F_._ZeroSlab(2 << 20)
+        # replay mode: the discriminator's own step (it needs the attention maps, not the segmentor's gradients) on a second stream
+        # beside the segmentor's backward pass -- a chain of ~200 launch-latency-bound kernels that otherwise costs 3 ms on its own
+        self.concurrent_disc = os.environ.get("OCTA_CONCURRENT_DISC", "1") != "0"
         # eager launches with more than one rank: start each gradient bucket's all-reduce from the stage mark that completes it,
         # i.e. overlapped with the REST of the backward pass (BASELINE config 4).  Captured graphs hold no collective: there the
         # buckets are issued, in the same order, right after the segmentor graph and overlap the discriminator step instead.
@@ -476,7 +481,7 @@ class TrainStep:
             self.seg_arena.all_reduce_bucket_async(self.world, self._comm(), i, self.grad_comm_dtype)
             self._started.append(i)
 
-    def _phase_segmentor(self, x, ys, out, disc, hooks=False):
+    def _phase_segmentor(self, x, ys, out, disc, hooks=False, between=None):
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         self._started = []
@@ -494,6 +499,9 @@ class TrainStep:
             g_adv = F_.lsgan_generator(disc(att))
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
+        att_out = [a.detach() for a in att]
+        if between is not None:
+            between(att_out)                  # capture(): the forward graph ends here (the discriminator's step only needs att_out)
         if callable(hooks):
             F_.add_mark_hook(hooks, self._tag_to_bucket.keys())         # capture(): cuts the graph at the bucket-completing marks
         elif hooks:
@@ -510,18 +518,26 @@ class TrainStep:
             F_.ZERO_SLAB.end()
         out["loss_seg"] = loss.detach()
         flush_bn_counters()
-        return [a.detach() for a in att]
+        return att_out
 
     def _phase_discriminator(self, att, real_pyramid, out, disc):
         """The discriminator's forward/backward.  It depends on the segmentor step only through the (detached)
         attention maps, not on the reduced segmentor gradients, so it runs WHILE those are being all-reduced."""
         if self.adversarial:
             self.disc_arena.zero_grad()
-            d_real = disc(real_pyramid)
-            d_fake = disc(att)
-            l_d = F_.lsgan_discriminator(d_real, d_fake)
-            self._scaled(l_d).backward()
-            F_.flush_wgrads()
+            # a zero slab of its own (spectral-norm workspaces, weight-gradient targets of the 15-channel convs): in replay mode this
+            # phase runs on a second stream beside the segmentor's backward pass, whose slab is still in use
+            seg_slab, F_.ZERO_SLAB = F_.ZERO_SLAB, self._disc_slab
+            F_.ZERO_SLAB.begin(self.disc_arena.g.device)
+            try:
+                d_real = disc(real_pyramid)
+                d_fake = disc(att)
+                l_d = F_.lsgan_discriminator(d_real, d_fake)
+                self._scaled(l_d).backward()
+                F_.flush_wgrads()
+            finally:
+                F_.ZERO_SLAB.end()
+                F_.ZERO_SLAB = seg_slab
             out["loss_disc"] = l_d.detach()
 
     def _scaled(self, loss: Tensor) -> Tensor:
@@ -589,8 +605,9 @@ class TrainStep:
 
     # ------------------------------------------------------------------ hipGraph capture / replay
     def capture(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None, warmup: int = 2):
-        """Capture the step for inputs of x's size into four hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm: segmentor
-        fwd/bwd | discriminator step | segmentor Adam + operand repack | discriminator Adam) around the two all-reduces.
+        """Capture the step for inputs of x's size into hipGraphs (torch.cuda.CUDAGraph = hipGraph on ROCm: segmentor forward |
+        segmentor backward, in pieces when gradients are all-reduced | discriminator step | segmentor Adam + operand repack |
+        discriminator Adam) around the two all-reduces.  The discriminator step replays on a second stream beside the backward pass.
         Inputs are copied into static buffers on every call; the CPU random draws of the discriminator are staged through
         _RngFeed; Adam's step counters live on the device.  Call once per input resolution."""
         dev = x.device
@@ -624,14 +641,11 @@ class TrainStep:
         mode = "thread_local"
         pool = next(iter(self._caps.values())).graphs[0].pool() if self._caps else None
         cap.seg_graphs = None
-        if self.overlap_backward:
-            g1 = self._capture_segmentor_in_pieces(cap, pool)
-        else:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=pool, capture_error_mode=mode):
-                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc)
+        g1 = self._capture_segmentor_in_pieces(cap, pool)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
+        # concurrent replay: a memory pool of its own (graphs that share a pool must replay one after the other, in capture order)
+        d_pool = {} if (self.concurrent_disc and self.adversarial) else {"pool": g1.pool()}
+        with torch.cuda.graph(g2, capture_error_mode=mode, **d_pool):
             self._phase_discriminator(cap.att, cap.sreal, cap.out, cap.disc)
         g2b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=mode):
@@ -657,14 +671,21 @@ class TrainStep:
         state = {"g": torch.cuda.CUDAGraph()}
         kw = {"capture_error_mode": "relaxed"}
 
+        def next_piece(marker):
+            state["g"].capture_end()
+            pieces.append((state["g"], marker))
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=pieces[0][0].pool(), **kw)
+
         def cut(tag):
             i = self._tag_to_bucket.get(tag)
             if i is None or any(b == i for _, b in pieces):
                 return
-            state["g"].capture_end()
-            pieces.append((state["g"], i))
-            state["g"] = torch.cuda.CUDAGraph()
-            state["g"].capture_begin(pool=pieces[0][0].pool(), **kw)
+            next_piece(i)
+
+        def forward_done(att):
+            cap.att = att
+            next_piece("fwd")         # piece 0 = forward pass + losses + the generator pass's discriminator forward
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -674,7 +695,8 @@ class TrainStep:
             else:
                 state["g"].capture_begin(**kw)
             try:
-                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc, hooks=cut)
+                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc, hooks=cut if self.overlap_backward else False,
+                                                between=forward_done)
             finally:
                 state["g"].capture_end()
         pieces.append((state["g"], None))
@@ -786,23 +808,37 @@ class TrainStep:
         g1, g2, g2b, g3 = cap.graphs
         comm = self._comm()
         started: List[int] = []
-        if cap.seg_graphs is not None:
-            # the segmentor phase in pieces: bucket k leaves for RCCL as soon as piece k has been enqueued, the next piece
-            # (the rest of the backward pass) runs meanwhile
-            for g, bucket in cap.seg_graphs:
-                g.replay()
-                if bucket is not None:
-                    self.seg_arena.all_reduce_bucket_async(self.world, comm, bucket, self.grad_comm_dtype)
-                    started.append(bucket)
-        else:
-            g1.replay()
-        # what has not left yet (everything, without the pieces), in completion order on the comm stream: the D step overlaps it
+        cur = torch.cuda.current_stream()
+        side_d = self.concurrent_disc and self.adversarial
+        d_done = None
+        # the segmentor phase in pieces: the forward graph, then the backward pass cut where a gradient bucket completes: bucket k
+        # leaves for RCCL as soon as piece k has been enqueued, the next piece (the rest of the backward pass) runs meanwhile
+        for g, marker in cap.seg_graphs:
+            g.replay()
+            if marker == "fwd":
+                if side_d:
+                    # the discriminator's step beside the backward pass: it reads the attention maps and the spectral-norm state the
+                    # forward graph left, and writes only its own gradient arena
+                    if self._disc_stream is None:
+                        self._disc_stream = torch.cuda.Stream()       # default priority: a high-priority stream gave the whole gain back (28.45 -> 29.2 ms)
+                    self._disc_stream.wait_stream(cur)
+                    with torch.cuda.stream(self._disc_stream):
+                        g2.replay()
+                        d_done = torch.cuda.Event()
+                        d_done.record(self._disc_stream)
+            elif marker is not None:
+                self.seg_arena.all_reduce_bucket_async(self.world, comm, marker, self.grad_comm_dtype)
+                started.append(marker)
+        # what has not left yet (everything, without the bucket cuts), in completion order on the comm stream
         self.seg_arena.all_reduce_begin(self.world, comm, self.grad_comm_dtype, skip=started)
         seg_done = None
         if _dist_on(self.world):
             seg_done = torch.cuda.Event()
             seg_done.record(comm)
-        g2.replay()
+        if d_done is not None:
+            cur.wait_event(d_done)
+        else:
+            g2.replay()
         if self.adversarial:
             # the discriminator's gradients follow the segmentor's on the comm stream and travel while the segmentor's Adam runs
             self.disc_arena.all_reduce_begin(self.world, comm, None)

@@ -399,10 +399,10 @@ def test_train_step_single_rank_rccl_buckets_and_capture():
             st.capture(x, ys, pyr)
             pieces = st._caps[H].seg_graphs
             if distributed:
-                # replay mode overlaps too: the segmentor graph is a chain of pieces cut at the bucket-completing stage marks
-                assert pieces is not None and len(pieces) == nb and [b for _, b in pieces] == list(range(nb - 1)) + [None], pieces
+                # replay mode overlaps too: the forward graph, then the backward pass as a chain of pieces cut at the bucket-completing stage marks
+                assert [b for _, b in pieces] == ["fwd"] + list(range(nb - 1)) + [None], pieces
             else:
-                assert pieces is None
+                assert [b for _, b in pieces] == ["fwd", None], pieces      # forward | backward: the discriminator's step replays beside the latter
             st.launch = "graph"
             o = st(x, ys, pyr)
             o = st(x, ys, pyr)

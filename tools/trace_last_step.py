@@ -14,5 +14,5 @@ for r in rows[lo:hi]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"].replace("void ", "")
     name = name.split("(")[0][:90]
-    print(f"{(s - t0) / 1e3:10.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}  {name}  g{r.get('Grid_Size_X', r.get('Grid_Size', '?'))}")
+    print(f"{(s - t0) / 1e3:10.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}  {name}  g{r.get('Grid_Size_X', r.get('Grid_Size', '?'))} q{r.get('Queue_Id', '?')}")
     prev_end = max(prev_end, e)
