@@ -1342,7 +1342,9 @@ template <> struct WgLds<float> {    // [16 m][128 cols] fp32, rows padded to 14
     __device__ static __forceinline__ int chunk_off(int m, int c) { return m * ROWB + c * 16; }
 };
 
-template <typename T, int WN, int WK, int TN, int TK>
+// SUB: MT-row sub-tiles staged per barrier.  A stage of one sub-tile is 4-16 MFMAs per wave against ~1000 cycles of loop
+// skeleton (address updates, LDS stores, the barrier): with SUB = 2 twice the loads are in flight and half the barriers remain.
+template <typename T, int WN, int WK, int TN, int TK, int SUB = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int MT = WgLds<T>::MT, ROWB = WgLds<T>::ROWB;
@@ -1352,8 +1354,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int QCPR = 128 / EPC;            // Q chunks per row
     constexpr int P_CH = (MT * PCPR + 255) / 256;
     constexpr int Q_CH = MT * QCPR / 256;      // 2
-    __shared__ __attribute__((aligned(16))) unsigned char sP[2][MT * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char sQ[2][MT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sP[2][SUB * MT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[2][SUB * MT * ROWB];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wn = wave / WK, wk = wave % WK;
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int prow0 = t / PCPR;
     const bool pn_ok = (n0 + pc * EPC) < a.Ng;
 
-    uint4 rp[P_CH], rq[Q_CH];
+    uint4 rp[SUB][P_CH], rq[SUB][Q_CH];
     // fused bias gradient: the blocks of k-tile 0 also sum the dy chunks they stage anyway
     const bool do_bias = (a.dbias != nullptr) && (blockIdx.x == 0);
     float bsum[P_CH][EPC];
@@ -1395,14 +1397,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         qb[i] = tq / a.OH;
     }
     const int qdh = qkh - a.pad, qdw = qkw - a.pad;
-    auto load_tile = [&](int mt0) {
+    auto load_tile = [&](int mt00) {
+#pragma unroll
+      for (int sb = 0; sb < SUB; ++sb) {
+        const int mt0 = mt00 + sb * MT;
 #pragma unroll
         for (int i = 0; i < P_CH; ++i) {
             const int row = prow0 + i * (256 / PCPR);
             const int m = mt0 + row;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < MT && m < mend && pn_ok) v = *(const uint4*)(dyg + (size_t)m * a.ldy + n0 + pc * EPC);
-            rp[i] = v;
+            rp[sb][i] = v;
             if (do_bias) {
                 float f[EPC];
                 unpack16<T>(v, f);
@@ -1418,22 +1423,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int ih = qoh[i] * a.stride + qdh, iw = qow[i] * a.stride + qdw;
             if (m < mend && kq_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
                 v = *(const uint4*)(xg + ((size_t)(qb[i] * a.H + ih) * a.W + iw) * a.ldx + qcc);
-            rq[i] = v;
+            rq[sb][i] = v;
             qow[i] += MT;
             while (qow[i] >= a.OW) { qow[i] -= a.OW; if (++qoh[i] == a.OH) { qoh[i] = 0; ++qb[i]; } }
         }
+      }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
+      for (int sb = 0; sb < SUB; ++sb) {
+#pragma unroll
         for (int i = 0; i < P_CH; ++i) {
             const int row = prow0 + i * (256 / PCPR);
-            if (row < MT) *(uint4*)(sP[buf] + WgLds<T>::chunk_off(row, pc)) = rp[i];
+            if (row < MT) *(uint4*)(sP[buf] + sb * MT * ROWB + WgLds<T>::chunk_off(row, pc)) = rp[sb][i];
         }
 #pragma unroll
         for (int i = 0; i < Q_CH; ++i) {
             const int row = qrow0 + i * (256 / QCPR);
-            *(uint4*)(sQ[buf] + WgLds<T>::chunk_off(row, qc)) = rq[i];
+            *(uint4*)(sQ[buf] + sb * MT * ROWB + WgLds<T>::chunk_off(row, qc)) = rq[sb][i];
         }
+      }
     };
 
     f32x4_t acc[TN][TK];
@@ -1443,7 +1452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int r = lane & 15, q = lane >> 4;
-    const int nt = (mend - mbeg + MT - 1) / MT;
+    const int nt = (mend - mbeg + SUB * MT - 1) / (SUB * MT);
     if (nt > 0) {
         load_tile(mbeg);
         store_tile(0);
@@ -1451,7 +1460,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nt) load_tile(mbeg + (it + 1) * MT);
+        if (it + 1 < nt) load_tile(mbeg + (it + 1) * SUB * MT);
+#pragma unroll
+      for (int sb = 0; sb < SUB; ++sb) {
+        const unsigned char* bP = sP[buf] + sb * MT * ROWB;
+        const unsigned char* bQ = sQ[buf] + sb * MT * ROWB;
         if constexpr (sizeof(T) == 2) {
             // transposed fragment: lane (i = r, group q) needs rows m = 8q..8q+7 of column (base + r)
             uint4 pf[TN], qf[TK];
@@ -1470,9 +1483,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 return make_uint4(u1.x, u1.y, u2.x, u2.y);
             };
 #pragma unroll
-            for (int i = 0; i < TN; ++i) pf[i] = rd(sP[buf], (wn * TN + i) * 16);
+            for (int i = 0; i < TN; ++i) pf[i] = rd(bP, (wn * TN + i) * 16);
 #pragma unroll
-            for (int j = 0; j < TK; ++j) qf[j] = rd(sQ[buf], (wk * TK + j) * 16);
+            for (int j = 0; j < TK; ++j) qf[j] = rd(bQ, (wk * TK + j) * 16);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -1484,15 +1497,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 float pf[TN], qf[TK];
                 const int mrow = 4 * s + q;
 #pragma unroll
-                for (int i = 0; i < TN; ++i) pf[i] = *(const float*)(sP[buf] + mrow * ROWB + ((wn * TN + i) * 16 + r) * 4);
+                for (int i = 0; i < TN; ++i) pf[i] = *(const float*)(bP + mrow * ROWB + ((wn * TN + i) * 16 + r) * 4);
 #pragma unroll
-                for (int j = 0; j < TK; ++j) qf[j] = *(const float*)(sQ[buf] + mrow * ROWB + ((wk * TK + j) * 16 + r) * 4);
+                for (int j = 0; j < TK; ++j) qf[j] = *(const float*)(bQ + mrow * ROWB + ((wk * TK + j) * 16 + r) * 4);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[i], qf[j], acc[i][j], 0, 0, 0);
             }
         }
+      }
         if (it + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
     }
@@ -1728,7 +1742,13 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     const int base = tilesK * tilesN * groups;
     // every block ends with BNn x 128 fp32 atomics (~13 us per block at the chip-wide atomic rate): give it at
     // least 16 m-tiles of MFMA work, and no more blocks than ~2 per CU
-    int split = cdiv(512, base);          // (512 blocks, >= 16 m-tiles) re-checked against 384..1024 x 8..16: still the best
+    // 512 blocks (>= 16 m-tiles each), re-checked against 384..1024 x 8..16.  One or two base tiles (N <= 128 and K <= 128: the
+    // few-channel layers, whose gradient is a few KB): 384, every block adds into the same few cache lines and those atomics are
+    // half of the kernel's time at 512 blocks (timing-only builds: 93 -> 43 us without them for the 2 -> 64 k4 s2 layer; 256 / 384 /
+    // 512 / 1024 / 2048 blocks in situ: 28.21 / 28.20 / 28.33 / 28.65 / 28.85 ms per step)
+    static const int target = getenv("OCTA_WGRAD_TARGET") ? atoi(getenv("OCTA_WGRAD_TARGET")) : 512;
+    static const int target1 = getenv("OCTA_WGRAD_TARGET1") ? atoi(getenv("OCTA_WGRAD_TARGET1")) : 384;
+    int split = cdiv(base <= 2 ? target1 : target, base);
     const int maxsplit = max(1, a.M / (MT * 16));
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
@@ -1737,9 +1757,20 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     split = cdiv(a.M, mps);
     a.splitM = split; a.mPerSplit = mps;
     dim3 grid(tilesK, tilesN, groups * split), block(256);
-    if (bnn == 128) conv_wgrad_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
-    else if (bnn == 64) conv_wgrad_kernel<T, 1, 4, 4, 2><<<grid, block, 0, st>>>(a);
-    else conv_wgrad_kernel<T, 1, 4, 2, 2><<<grid, block, 0, st>>>(a);
+    static const int sub_env = getenv("OCTA_WGRAD_SUB") ? atoi(getenv("OCTA_WGRAD_SUB")) : 2;
+    const bool sub2 = sizeof(T) == 2 && sub_env == 2 && mps >= 8 * MT;      // two sub-tiles per barrier (64 KB of LDS: two workgroups per CU)
+    if constexpr (sizeof(T) == 2) {
+        if (sub2) {
+            if (bnn == 128) conv_wgrad_kernel<T, 2, 2, 4, 4, 2><<<grid, block, 0, st>>>(a);
+            else if (bnn == 64) conv_wgrad_kernel<T, 1, 4, 4, 2, 2><<<grid, block, 0, st>>>(a);
+            else conv_wgrad_kernel<T, 1, 4, 2, 2, 2><<<grid, block, 0, st>>>(a);
+        }
+    }
+    if (!sub2) {
+        if (bnn == 128) conv_wgrad_kernel<T, 2, 2, 4, 4><<<grid, block, 0, st>>>(a);
+        else if (bnn == 64) conv_wgrad_kernel<T, 1, 4, 4, 2><<<grid, block, 0, st>>>(a);
+        else conv_wgrad_kernel<T, 1, 4, 2, 2><<<grid, block, 0, st>>>(a);
+    }
     note_kernel<T>("conv_wgrad_kernel", bnn, 0);
     OCTA_CHECK_LAUNCH("conv_wgrad");
     return OCTA_OK;
