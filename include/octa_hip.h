@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 302
+#define OCTA_HIP_ABI_VERSION 303
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -118,6 +118,13 @@ int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed
  * weights): y is complete either way, stats untouched in the latter case and the caller runs the ordinary statistics pass. */
 int octa_conv2d_fwd_stats(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                           float* stats, const float* shift, int replicas, int* fused_host, octa_stream_t stream);
+/* Optional scratch for the 8-wave kernel's TAIL SPLIT (algo 2 / 3, groups == 1): a launch whose tile count leaves the last round of
+ * 256 CUs at most half full runs those last tiles as 2..8 workgroups each over disjoint input-channel ranges; the partial fp32
+ * tiles go through `ws` (caller-owned, `bytes` long, 16-byte aligned; 64 MB covers every layer of the path) and a second small
+ * launch finishes them.  Same results up to fp32 summation order.  The registration is process-wide and read when a conv is
+ * LAUNCHED: launches that may run concurrently on different streams must not both be issued while a workspace is registered
+ * (register NULL / 0 around the launches of the other stream).  Default: none registered, nothing splits. */
+int octa_conv_splitk_workspace(float* ws, int64_t bytes);
 /* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
 int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
                       octa_stream_t stream);

@@ -8,6 +8,7 @@
 // bank-conflict free without padding ("LDS image").
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -35,6 +36,10 @@ struct ConvArgs {
     float* stats;         // [stats_rep][2][stats_ctot] fp32 sums of d = y - shift and d*d, accumulated with float atomics; NULL = off
     const float* stats_shift;   // per output channel (all groups), or NULL = 0
     int stats_rep, stats_ctot;
+    // tail split-K of the 8-wave kernel (igemm8.hpp): tiles [0, sk_full) run whole, every later tile as sk_parts workgroups over
+    // disjoint channel-slice ranges that store raw fp32 partial tiles to sk_ws; igemm8_splitk_fix finishes them.  sk_parts <= 1: off
+    float* sk_ws;
+    int sk_full, sk_parts, sk_gy;
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -43,12 +48,13 @@ __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3;
 // id L runs on XCD L%8.  Re-map so that every XCD owns a CONTIGUOUS range of (m-tile, n-tile) pairs with
 // the n-tiles of one pixel tile adjacent: the pixel rows (and the 3x3 halo rows of the neighbouring
 // tiles) are then re-read from that XCD's L2 instead of HBM.  Bijective for any grid size; speed only.
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& mt, int& nt) {
-    const int total = gx * gy;
-    const int L = blockIdx.x + blockIdx.y * gx;
+__device__ __forceinline__ int xcd_remap(int L, int total) {
     const int xcd = L & 7, j = L >> 3;
     const int qn = total >> 3, rn = total & 7;
-    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+    return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+}
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& mt, int& nt) {
+    const int Lp = xcd_remap(blockIdx.x + blockIdx.y * gx, gx * gy);
     nt = Lp % gy;
     mt = Lp / gy;
 }
@@ -910,6 +916,12 @@ static int check_desc(const octa_conv_desc* d, const char* who) {
 
 static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats, const float* shift,
                            int replicas, int* fused, octa_stream_t stream);
+extern "C" int octa_conv_splitk_workspace(float* ws, int64_t bytes) {
+    OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_conv_splitk_workspace: 16-byte aligned buffer, or NULL / 0");
+    g_sk_ws = bytes > 0 ? ws : nullptr;
+    g_sk_ws_bytes = g_sk_ws ? bytes : 0;
+    return OCTA_OK;
+}
 extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, octa_stream_t stream) {
     return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, 0, nullptr, stream);
 }
@@ -938,6 +950,7 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = stats; a.stats_shift = shift; a.stats_rep = replicas; a.stats_ctot = d->Cout;
+    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
         a.NgSt = (a.Ng + 7) / 8 * 8;
@@ -973,6 +986,7 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = nullptr; a.stats_shift = nullptr; a.stats_rep = 0; a.stats_ctot = 0;
+    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
         a.NgSt = (a.Ng + 7) / 8 * 8;

@@ -61,7 +61,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     const int wm = wave / WN, wn = wave % WN;
     const int g = blockIdx.z;
     int mt, nt;
-    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    // tail split-K (8 waves, one group): a 1-D launch of sk_full whole tiles followed by sk_parts workgroups per remaining tile.
+    // A launch of, say, 316 tiles on 256 CUs otherwise runs a second round that is 23 % full; here its 60 tiles become 240
+    // workgroups of a quarter of the K range each.  part >= 0: this workgroup owns slices [s0, s1) and ends in a raw fp32 store.
+    int part = -1, tail = 0;
+    if (NW == 8 && a.sk_parts > 1) {
+        const int b = blockIdx.x;
+        int Lp;
+        if (b < a.sk_full) Lp = xcd_remap(b, a.sk_full);
+        else { const int bb = b - a.sk_full; tail = bb / a.sk_parts; part = bb - tail * a.sk_parts; Lp = a.sk_full + tail; }
+        nt = Lp % a.sk_gy;
+        mt = Lp / a.sk_gy;
+    } else xcd_tile(gridDim.x, gridDim.y, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
     const int Kc = a.Kc, CgC = a.Cg / EPC, KW = a.KW, Wimg = a.W, ldx = a.ldx;
     const unsigned long zaddr = (unsigned long)(const void*)octa_zero_page;
@@ -118,6 +129,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     // Per-lane state of the stage to be issued next: tap (kh, kw), channel chunk cc = 8 * slice + chunk inside the tap.
     const int ntaps = a.KH * KW;
     int cc = chunk, tap = 0, kh = 0, kw = 0;
+    int nk = (Kc + KP - 1) / KP;
+    if (part >= 0) {
+        const int nsl = CgC / KP;                           // 64-channel slices (Cg % 64 == 0)
+        const int s0 = part * nsl / a.sk_parts, s1 = (part + 1) * nsl / a.sk_parts;
+        cc += KP * s0;
+        nk = (s1 - s0) * ntaps;
+    }
 
     const unsigned sbase = lds_addr(smem);
     auto advanceK = [&]() {                               // next tap of the slice; after the last tap, the next slice
@@ -164,7 +182,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     const unsigned afrag1 = sbase + (unsigned)(wm * 4 * 2048 + lrow + (((4 + q) ^ (r & 7)) << 4));
     const unsigned bfrag0 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((0 + q) ^ (r & 7)) << 4));
     const unsigned bfrag1 = sbase + (unsigned)(A_BYTES + wn * 4 * 2048 + lrow + (((4 + q) ^ (r & 7)) << 4));
-    const int nk = (Kc + KP - 1) / KP;
     if constexpr (NW == 4) {
     // 4-wave variant (two workgroups per CU cover each other's stalls): stage-at-a-time loop, waves 0-1 issue the next stage
     // before their MFMAs, waves 2-3 after
@@ -278,6 +295,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
 #undef IG8_MMA
     }
 
+    if (NW == 8 && part >= 0) {
+        // partial tile: raw fp32 accumulators, [m local][n local], to this (tile, part)'s slot of the workspace
+        float* __restrict__ wsp = a.sk_ws + ((size_t)tail * a.sk_parts + part) * (size_t)(BM * BN);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(f32x4_t*)(wsp + (size_t)((wm * 4 + j) * 16 + r) * BN + (wn * 4 + i) * 16 + q * 4) = acc[i][j];
+        return;
+    }
     // epilogue: lane holds, per (tn, tm), 4 consecutive output channels (rows of D) of pixel column r
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * 4 * 16 + q * 4, g);
@@ -319,6 +346,71 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     }
 }
 
+// Finishes the split tiles: y = act(sum of the parts + bias) [+ addend], stored like the kernel's own epilogue does.
+// One thread per (pixel row, 4 channels); blockIdx.x = tail tile, blockIdx.y = 16-row strip.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm8_splitk_fix_kernel(const ConvArgs a) {
+    const int Lp = a.sk_full + blockIdx.x;
+    const int nt = Lp % a.sk_gy, mt = Lp / a.sk_gy;
+    const int m0 = mt * BM, n0 = nt * BN;
+    constexpr int TPR = BN / 4;                            // threads per row
+    constexpr int RPB = 256 / TPR;                         // rows per pass
+    const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
+    const int nb = n0 + tc * 4;
+    if (nb >= a.NgSt) return;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (nb + e < a.Ng) ? a.bias[nb + e] : 0.f;
+    const float* __restrict__ wsp = a.sk_ws + (size_t)blockIdx.x * a.sk_parts * (size_t)(BM * BN);
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+    const T* __restrict__ ad = (const T*)a.addend;
+    const int rows = BM / gridDim.y;
+    for (int rr = blockIdx.y * rows + tr; rr < (int)(blockIdx.y + 1) * rows; rr += RPB) {
+        const int m = m0 + rr;
+        if (m >= a.M) break;
+        f32x4_t v = *(const f32x4_t*)(wsp + (size_t)rr * BN + tc * 4);
+        for (int p = 1; p < a.sk_parts; ++p) {
+            const f32x4_t u = *(const f32x4_t*)(wsp + (size_t)p * (BM * BN) + (size_t)rr * BN + tc * 4);
+            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = act_apply(v[e] + bv[e], a.act);
+            if (ad && nb + e < a.Ng) o[e] += DT<T>::ld(ad + (size_t)m * a.ldadd + nb + e);
+        }
+        T* dst = yb + (size_t)m * a.ldy + nb;
+        if (a.vec_store && nb + 3 < a.Ng) *(uint2*)dst = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? o[e] : 0.f);
+        }
+    }
+}
+
+// the caller-owned fp32 scratch of the tail split (octa_conv_splitk_workspace); NULL = never split
+static float* g_sk_ws = nullptr;
+static int64_t g_sk_ws_bytes = 0;
+
+// How many parts the tiles behind the last full round of 256 are split into (1 = no split), for a grid of `tiles` tiles whose K
+// range has `nsl` 64-channel slices of `ntaps` stages each.
+static int splitk_parts(int tiles, int nsl, int ntaps, int64_t tile_floats) {
+    static const bool off = getenv("OCTA_NO_SPLITK") != nullptr;
+    if (off || !g_sk_ws) return 1;
+    static const int maxtail = getenv("OCTA_SK_MAXTAIL") ? atoi(getenv("OCTA_SK_MAXTAIL")) : 128;
+    static const int minst = getenv("OCTA_SK_MINSTAGES") ? atoi(getenv("OCTA_SK_MINSTAGES")) : 12;
+    const int tail = tiles % 256;
+    if (tail == 0 || tail > maxtail) return 1;             // the last round is more than half full: nothing worth the extra pass
+    int parts = 256 / tail;
+    if (parts > 8) parts = 8;
+    if (parts > nsl) parts = nsl;
+    while (parts > 1 && (nsl / parts) * ntaps < minst) --parts;    // at least a dozen stages per part: prologue + ring fill are ~4
+    if (parts < 2) return 1;
+    if ((int64_t)tail * parts * tile_floats * 4 > g_sk_ws_bytes) return 1;
+    return parts;
+}
+
 // eligibility + launch; variant 0: 256(M) x 128(N), 1: 128(M) x 256(N), 2: 128 x 128 with 4 waves.  Returns false when the
 // legacy kernels must run.
 template <typename T>
@@ -332,16 +424,29 @@ static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_
         if (a.mode == 0) conv_igemm8_kernel<T, 2, 2, 0><<<grid, 256, 0, st>>>(a);
         else conv_igemm8_kernel<T, 2, 2, 1><<<grid, 256, 0, st>>>(a);
         note_kernel<T>("conv_igemm8_kernel", 128, 128);
-    } else if (variant == 0) {
-        dim3 grid(cdiv(a.M, 256), cdiv(a.Ng, 128), groups);
-        if (a.mode == 0) conv_igemm8_kernel<T, 4, 2, 0><<<grid, 512, 0, st>>>(a);
-        else conv_igemm8_kernel<T, 4, 2, 1><<<grid, 512, 0, st>>>(a);
-        note_kernel<T>("conv_igemm8_kernel", 256, 128);
     } else {
-        dim3 grid(cdiv(a.M, 128), cdiv(a.Ng, 256), groups);
-        if (a.mode == 0) conv_igemm8_kernel<T, 2, 4, 0><<<grid, 512, 0, st>>>(a);
-        else conv_igemm8_kernel<T, 2, 4, 1><<<grid, 512, 0, st>>>(a);
-        note_kernel<T>("conv_igemm8_kernel", 128, 256);
+        const int BM = variant == 0 ? 256 : 128, BN = variant == 0 ? 128 : 256;
+        dim3 grid(cdiv(a.M, BM), cdiv(a.Ng, BN), groups);
+        ConvArgs b = a;
+        const int tiles = grid.x * grid.y;
+        const int parts = (groups == 1 && !a.upshuffle && !a.stats) ? splitk_parts(tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
+        if (parts > 1) {
+            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - tiles % 256; b.sk_gy = grid.y;
+            grid = dim3(b.sk_full + (tiles % 256) * parts, 1, 1);
+        }
+        if (variant == 0) {
+            if (a.mode == 0) conv_igemm8_kernel<T, 4, 2, 0><<<grid, 512, 0, st>>>(b);
+            else conv_igemm8_kernel<T, 4, 2, 1><<<grid, 512, 0, st>>>(b);
+            if (parts > 1) igemm8_splitk_fix_kernel<T, 256, 128><<<dim3(tiles % 256, 8), 256, 0, st>>>(b);
+            note_kernel<T>("conv_igemm8_kernel", 256, 128);
+            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", tiles % 256, parts); }
+        } else {
+            if (a.mode == 0) conv_igemm8_kernel<T, 2, 4, 0><<<grid, 512, 0, st>>>(b);
+            else conv_igemm8_kernel<T, 2, 4, 1><<<grid, 512, 0, st>>>(b);
+            if (parts > 1) igemm8_splitk_fix_kernel<T, 128, 256><<<dim3(tiles % 256, 8), 256, 0, st>>>(b);
+            note_kernel<T>("conv_igemm8_kernel", 128, 256);
+            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", tiles % 256, parts); }
+        }
     }
     return true;
 }

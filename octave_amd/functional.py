@@ -188,6 +188,23 @@ def _zeroed_f32(shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device), 0
 
 
+# ----------------------------------------------------------------------------- tail split-K scratch of the 8-wave conv kernel
+_SPLITK_WS = None
+
+
+def set_splitk_workspace(ws: Optional[Tensor]):
+    """Register (None: withdraw) the fp32 scratch octa_conv_splitk_workspace describes.  Read when a conv is launched: a training
+    step registers it around the segmentor's launches and withdraws it around launches issued for another stream."""
+    global _SPLITK_WS
+    if ws is None:
+        lib().octa_conv_splitk_workspace(None, 0)
+    else:
+        if ws.dtype != torch.float32 or not ws.is_cuda or not ws.is_contiguous():
+            raise OctaError("split-K workspace: contiguous fp32 device tensor")
+        lib().octa_conv_splitk_workspace(_p(ws), ws.numel() * 4)
+    _SPLITK_WS = ws
+
+
 # ----------------------------------------------------------------------------- packed weights
 _WEIGHT_EPOCH = 0
 _PARAM_EPOCH = 0          # bumped whenever a kernel writes parameters or BatchNorm running statistics through raw pointers

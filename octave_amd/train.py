@@ -409,6 +409,9 @@ class TrainStep:
         self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
         self._disc_stream = None
+        # 64 MB of fp32 scratch for the 8-wave conv kernel's tail split (octa_conv_splitk_workspace): the 25 x 25 / 50 x 50 decoder
+        # layers launch 316 / 626 tiles on 256 CUs
+        self._sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=next(net.parameters()).device) if os.environ.get("OCTA_SPLITK", "1") != "0" else None
         self._disc_slab = F_._ZeroSlab(2 << 20)
         # replay mode: the discriminator's own step (it needs the attention maps, not the segmentor's gradients) on a second stream
         # beside the segmentor's backward pass -- a chain of ~200 launch-latency-bound kernels that otherwise costs 3 ms on its own
@@ -482,6 +485,7 @@ class TrainStep:
             self._started.append(i)
 
     def _phase_segmentor(self, x, ys, out, disc, hooks=False, between=None):
+        F_.set_splitk_workspace(self._sk_ws)
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         self._started = []
@@ -529,6 +533,7 @@ class TrainStep:
             # phase runs on a second stream beside the segmentor's backward pass, whose slab is still in use
             seg_slab, F_.ZERO_SLAB = F_.ZERO_SLAB, self._disc_slab
             F_.ZERO_SLAB.begin(self.disc_arena.g.device)
+            F_.set_splitk_workspace(None)          # (same reason: one scratch, two streams)
             try:
                 d_real = disc(real_pyramid)
                 d_fake = disc(att)
@@ -856,6 +861,7 @@ class TrainStep:
         """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""
         F_.set_grad_sink(False)
         F_.defer_wgrads(False)
+        F_.set_splitk_workspace(None)
         F_.clear_mark_hooks()
         defer_bn_counters(False)
         for d in self.discs.values():

@@ -108,8 +108,14 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
     ib, ih, iw = [t.to(dev) for t in _pixels(B, H, W, 160, gen)]
     ref_dx = _ref_dgrad_pixels(dy64, w64, ib, ih, iw, s, p, g, Cin)
     seen = set()
-    for algo in (0, 2, 3, 8, 1):
-        F_._ALGO_OVERRIDE = algo
+    sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+    for algo in (0, 2, 3, 8, 1, 102, 103):
+        # 102 / 103: the 8-wave kernel with the tail-split scratch registered (octa_conv_splitk_workspace): the 316-tile (25 x 25)
+        # and 626-tile (50 x 50) launches then run their last 60 / 114 tiles as 4 / 2 workgroups each + the fix-up launch
+        split = algo >= 100
+        F_._ALGO_OVERRIDE = algo % 100
+        if split:
+            F_.set_splitk_workspace(sk_ws)
         try:
             y = F_.raw_conv_fwd(xn, wq, None, s, p, g)
             kf = L.octa_last_conv_kernel().decode()
@@ -117,6 +123,12 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
             kd = L.octa_last_conv_kernel().decode()
         finally:
             F_._ALGO_OVERRIDE = 0
+            F_.set_splitk_workspace(None)
+        if split and g == 1 and k == 3 and H <= 50:
+            assert "+tail" in kf or "+tail" in kd, (kf, kd)          # (the data gradient's N is Cin: its tile count differs)
+        elif not split:
+            assert "+tail" not in kf and "+tail" not in kd, (kf, kd)
+        algo = algo % 100
         seen.update((kf.split("<")[0], kd.split("<")[0]))
         got_y = y[pb, :, ph, pw].double()
         err = (got_y - ref_y).abs()
