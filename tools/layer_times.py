@@ -18,6 +18,7 @@ batch = (x, ys, mask_pyramid(real))
 step.capture(*batch); step._caps = {}      # capture() autotunes the kernel choice per shape; then record an eager step
 F_.start_recording(); step(*batch); rec = F_.stop_recording()
 torch.cuda.synchronize()
+F_.set_splitk_workspace(step._sk_ws if os.environ.get("LAYER_TIMES_SPLITK", "1") != "0" else None)     # as during the segmentor phase of a step
 L = lib(); st = torch.cuda.current_stream().cuda_stream
 rows = []
 excess = []
