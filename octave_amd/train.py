@@ -416,6 +416,11 @@ class TrainStep:
         # replay mode: the discriminator's own step (it needs the attention maps, not the segmentor's gradients) on a second stream
         # beside the segmentor's backward pass -- a chain of ~200 launch-latency-bound kernels that otherwise costs 3 ms on its own
         self.concurrent_disc = os.environ.get("OCTA_CONCURRENT_DISC", "1") != "0"
+        # ... launched behind the backward piece that ends at this stage mark (None: right behind the forward graph).  Beside the
+        # low-resolution half of the backward pass (MFMA-bound GEMMs on small grids, latency-bound 13 x 13 / 25 x 25 kernels) the
+        # discriminator's HBM-bound kernels cost less than beside the full-resolution decoder stages: swept in situ, forward /
+        # decoder_3 / decoder_4 / encoder_4 / encoder_3 = 28.27 / 28.03 / 27.90 / 28.03 / 28.12 ms per step
+        self._disc_after_tag = os.environ.get("OCTA_DISC_AFTER", "decoder_4")
         # eager launches with more than one rank: start each gradient bucket's all-reduce from the stage mark that completes it,
         # i.e. overlapped with the REST of the backward pass (BASELINE config 4).  Captured graphs hold no collective: there the
         # buckets are issued, in the same order, right after the segmentor graph and overlap the discriminator step instead.
@@ -425,6 +430,9 @@ class TrainStep:
         # with the rest of the backward pass exactly like the eager path
         self._started: List[int] = []
         self._tag_to_bucket = {tag: i for i, (tag, _, _) in enumerate(self.seg_arena.buckets)}
+        self._disc_after = self._tag_to_bucket.get(self._disc_after_tag) if (self.concurrent_disc and self.adversarial) else None
+        if self._disc_after is not None and self._disc_after >= len(self.seg_arena.buckets) - 1:
+            self._disc_after = None           # the last bucket ends with the backward pass: nothing left to run beside
         self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
         self.max_ahead = int(os.environ.get("OCTA_MAX_AHEAD", "0"))      # replayed steps the host may be ahead of the device (0: no pacing; pacing did not cure the stalls)
         self._tick = _StepTick(next(net.parameters()).device)
@@ -507,7 +515,7 @@ class TrainStep:
         if between is not None:
             between(att_out)                  # capture(): the forward graph ends here (the discriminator's step only needs att_out)
         if callable(hooks):
-            F_.add_mark_hook(hooks, self._tag_to_bucket.keys())         # capture(): cuts the graph at the bucket-completing marks
+            F_.add_mark_hook(hooks, getattr(hooks, "tags", None) or self._tag_to_bucket.keys())     # capture(): cuts the graph at the bucket-completing marks
         elif hooks:
             F_.add_mark_hook(self._on_mark, self._tag_to_bucket.keys())
         try:
@@ -691,6 +699,8 @@ class TrainStep:
         def forward_done(att):
             cap.att = att
             next_piece("fwd")         # piece 0 = forward pass + losses + the generator pass's discriminator forward
+        if not self.overlap_backward and self._disc_after is not None:
+            cut.tags = [self.seg_arena.buckets[self._disc_after][0]]       # one cut: where a replay launches the discriminator graph
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -700,7 +710,7 @@ class TrainStep:
             else:
                 state["g"].capture_begin(**kw)
             try:
-                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc, hooks=cut if self.overlap_backward else False,
+                cap.att = self._phase_segmentor(cap.sx, cap.sys, cap.out, cap.disc, hooks=cut if (self.overlap_backward or getattr(cut, "tags", None)) else False,
                                                 between=forward_done)
             finally:
                 state["g"].capture_end()
@@ -820,7 +830,7 @@ class TrainStep:
         # leaves for RCCL as soon as piece k has been enqueued, the next piece (the rest of the backward pass) runs meanwhile
         for g, marker in cap.seg_graphs:
             g.replay()
-            if marker == "fwd":
+            if marker == ("fwd" if self._disc_after is None else self._disc_after):
                 if side_d:
                     # the discriminator's step beside the backward pass: it reads the attention maps and the spectral-norm state the
                     # forward graph left, and writes only its own gradient arena
@@ -831,7 +841,7 @@ class TrainStep:
                         g2.replay()
                         d_done = torch.cuda.Event()
                         d_done.record(self._disc_stream)
-            elif marker is not None:
+            elif marker is not None and marker != "fwd":
                 self.seg_arena.all_reduce_bucket_async(self.world, comm, marker, self.grad_comm_dtype)
                 started.append(marker)
         # what has not left yet (everything, without the bucket cuts), in completion order on the comm stream

@@ -402,7 +402,8 @@ def test_train_step_single_rank_rccl_buckets_and_capture():
                 # replay mode overlaps too: the forward graph, then the backward pass as a chain of pieces cut at the bucket-completing stage marks
                 assert [b for _, b in pieces] == ["fwd"] + list(range(nb - 1)) + [None], pieces
             else:
-                assert [b for _, b in pieces] == ["fwd", None], pieces      # forward | backward: the discriminator's step replays beside the latter
+                # forward | backward, the latter cut once at the stage mark behind which the discriminator's step is launched on its own stream
+                assert [b for _, b in pieces] == ["fwd"] + ([st._disc_after] if st._disc_after is not None else []) + [None], pieces
             st.launch = "graph"
             o = st(x, ys, pyr)
             o = st(x, ys, pyr)
