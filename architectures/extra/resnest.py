@@ -18,6 +18,7 @@ from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_c
 
 BN_MOMENTUM = 0.1
 _FUSE_FANOUT = os.environ.get("OCTA_FUSE_FANOUT", "1") != "0"     # Bottleneck: shortcut gradient added in conv1's data-gradient epilogue
+_FUSE_SPLAT_BN0 = os.environ.get("OCTA_FUSE_SPLAT_BN0", "1") != "0"    # SplAtConv2d (training): bn0 + ReLU recomputed inside the split-attention kernels
 _FUSE_FANOUT_DEC = os.environ.get("OCTA_FUSE_FANOUT_DEC", "1") != "0"     # ResNestDecoder: 3x3 gradient added in the shortcut conv's data gradient
 
 
@@ -50,13 +51,24 @@ class SplAtConv2d(nn.Module):
         self.fc2 = Conv2d(inter_channels, channels * radix, 1, groups=self.cardinality)
 
     def forward(self, x, relu_after: bool = False):
-        x = conv_bn(self.conv, self.bn0, x, relu=True)
-        bn1 = self.bn1
+        bn0, bn1 = self.bn0, self.bn1
         training = bn1.training
+        # training: bn0 + ReLU are recomputed inside the split-attention kernels from the raw conv output (functional.SplatTailFn):
+        # no BatchNorm-apply pass, no stored activation / gradient of the 2C-channel tensor
+        fuse0 = (_FUSE_SPLAT_BN0 and training and bn0.training and bn0.momentum is not None and x.is_cuda and self.conv.act == 0)
+        if fuse0:
+            x = self.conv(x)
+            if bn0.track_running_stats and bn0.num_batches_tracked is not None:
+                bump_counter(bn0.num_batches_tracked)
+            pre = (bn0.weight, bn0.bias, bn0.running_mean if bn0.track_running_stats else None,
+                   bn0.running_var if bn0.track_running_stats else None, bn0.momentum, bn0.eps)
+        else:
+            x = conv_bn(self.conv, bn0, x, relu=True)
+            pre = None
         if training and bn1.num_batches_tracked is not None:
             bump_counter(bn1.num_batches_tracked)
         return F_.splat_tail(x, self.fc1.weight, self.fc1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                             self.fc2.weight, self.fc2.bias, self.cardinality, bn1.momentum, bn1.eps, training, relu_after)
+                             self.fc2.weight, self.fc2.bias, self.cardinality, bn1.momentum, bn1.eps, training, relu_after, bn0=pre)
 
 
 class Bottleneck(nn.Module):

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 303
+#define OCTA_HIP_ABI_VERSION 304
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -319,6 +319,25 @@ int octa_splat_apply(const void* x, const float* logits, void* out, int B, int H
 int octa_splat_bwd(const void* dout, const void* x, const float* logits, const void* out,
                    const float* dgap, void* dx, float* dlogits, int B, int HW, int C, int dtype,
                    int relu, int phase, int prezeroed /* dlogits, phase 0 */, octa_stream_t stream);
+
+/* Split attention with the PRECEDING BatchNorm + ReLU (bn0, resnest.py:100-103) recomputed on the fly: x is the raw conv output
+ * [B, HW, 2C]; mean / invstd (batch statistics: octa_bn_stats) / gamma / beta are bn0's, [2C] each; every kernel evaluates
+ * y = max(x * gamma * invstd + (beta - mean * gamma * invstd), 0) in registers, so y and its gradient are never stored.
+ *   octa_splat_bn_gap        = octa_splat_gap(y);   octa_splat_bn_apply = octa_splat_apply(y)
+ *   octa_splat_bn_bwd_logits = octa_splat_bwd(phase 0) on y
+ *   octa_splat_bn_bwd_dx     = octa_splat_bwd(phase 1) followed by bn0's backward: dx [B, HW, 2C] is the gradient of the RAW conv
+ *                              output, dgamma / dbeta (optional) are accumulated (+=); ws: octa_bn_workspace_floats(B * HW, 2 C). */
+int octa_splat_bn_gap(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      float* gap, int B, int HW, int C, int dtype, int prezeroed, octa_stream_t stream);
+int octa_splat_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        const float* logits, void* out, int B, int HW, int C, int dtype, int relu, octa_stream_t stream);
+int octa_splat_bn_bwd_logits(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const float* logits, const void* out, float* dlogits, int B, int HW, int C,
+                             int dtype, int relu, int prezeroed, octa_stream_t stream);
+int octa_splat_bn_bwd_dx(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* logits, const void* out, const float* dgap, void* dx,
+                         float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int dtype, int relu,
+                         octa_stream_t stream);
 
 /* The attention micro-net on (B, C) vectors (resnest.py:118-125), exact fp32, 2 <= B <= 32:
  * h1 = fc1(gap) [grouped 1x1, + bias]; h2 = relu(bn1(h1)) [batch statistics when training, running stats

@@ -615,6 +615,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     fin[C + c] = (float)(ss / (double)rows);
 }
 
+// (used by splat_aag.hip: split attention with bn0 recomputed on the fly)
+int octa_bn_bwd_finalize_launch(const float* partial, int nby, int C, int64_t rows, float* fin, float* dgamma, float* dbeta, hipStream_t st) {
+    bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(partial, nby, C, rows, fin, dgamma, dbeta);
+    OCTA_CHECK_LAUNCH("bn_bwd_finalize");
+    return OCTA_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, int dyoff, const T* __restrict__ x, int ldx,
                                                            int xoff, const T* __restrict__ y, int ldy, int yoff,

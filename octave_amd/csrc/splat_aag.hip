@@ -241,6 +241,341 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
     return OCTA_OK;
 }
 
+// =========================================================================================== SplAt with bn0 + ReLU on the fly
+// extra/resnest.py:99-103,106-138: conv -> bn0 -> relu -> split attention.  The unfused path materialises y = relu(bn0(x)) (a
+// BatchNorm apply pass: read x, write y) and reads y twice (GAP, weighted sum); its backward materialises dy and runs the
+// BatchNorm backward over it (write dy, read dy + x twice, write dx).  Here x is the RAW conv output and every kernel recomputes
+// y = max(x * sc + sh, 0) (sc = gamma * invstd, sh = beta - mean * sc) in registers: 2 of 6.5 forward passes and 3 of 7 backward
+// passes over the 2C-channel tensor disappear, y and dy are never stored.
+template <int EPC>
+__device__ __forceinline__ void bn_co(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, int ch, float (&sc)[EPC], float (&sh)[EPC]) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float k = gamma[ch + e] * invstd[ch + e];
+        sc[e] = k;
+        sh[e] = beta[ch + e] - mean[ch + e] * k;
+    }
+}
+struct SplatBn { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+
+// gap[b][c] += (1/HW) sum_hw (y[b,hw,c] + y[b,hw,C+c]);  grid (colblocks, hw splits, B)
+template <typename T>
+__global__ __launch_bounds__(256) void splat_gap_bn_kernel(const T* __restrict__ x, SplatBn bn, float* __restrict__ gap, int HW, int C, int TX, int rpb) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    if (col < cpr) {
+        float scu[EPC], shu[EPC], scv[EPC], shv[EPC];
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, col * EPC, scu, shu);
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, C + col * EPC, scv, shv);
+        const T* base = x + (int64_t)b * HW * 2 * C + col * EPC;
+        for (int r = r0 + ry; r < r1; r += RY) {
+            float u[EPC], v[EPC];
+            unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C), u);
+            unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C + C), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += fmaxf(fmaf(u[e], scu[e], shu[e]), 0.f) + fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[((size_t)ry * TX + cx) * EPC + e] = s[e];
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a = 0.f;
+        for (int yy = 0; yy < RY; ++yy) a += red[(size_t)yy * TX * EPC + ch];
+        atomicAdd(gap + (int64_t)b * C + c, a * inv);
+    }
+}
+// out = a0*y[:, :C] + a1*y[:, C:]; grid (hw blocks, B); attention and the BatchNorm coefficients of the sample staged in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void splat_apply_bn_kernel(const T* __restrict__ x, SplatBn bn, const float* __restrict__ logits, T* __restrict__ out,
+                                                             int HW, int C, int relu, int rpb) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float sm[];   // a0[C], sc[2C], sh[2C]
+    float* a0s = sm;
+    float* scs = sm + C;
+    float* shs = sm + 3 * C;
+    const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float l0 = logits[(int64_t)b * 2 * C + c], l1 = logits[(int64_t)b * 2 * C + C + c];
+        a0s[c] = 1.f / (1.f + expf(l1 - l0));
+    }
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const float k = bn.gamma[c] * bn.invstd[c];
+        scs[c] = k;
+        shs[c] = bn.beta[c] - bn.mean[c] * k;
+    }
+    __syncthreads();
+    const int cpr = C / EPC;
+    const int r0 = blockIdx.x * rpb, r1 = min(HW, r0 + rpb);
+    const int64_t total = (int64_t)(r1 - r0) * cpr;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int r = r0 + (int)(i / cpr);
+        const int c0 = (int)(i % cpr) * EPC;
+        float u[EPC], v[EPC];
+        const T* px = x + ((int64_t)b * HW + r) * 2 * C + c0;
+        unpack16<T>(*(const uint4*)px, u);
+        unpack16<T>(*(const uint4*)(px + C), v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float a0 = a0s[c0 + e];
+            const float yu = fmaxf(fmaf(u[e], scs[c0 + e], shs[c0 + e]), 0.f), yv = fmaxf(fmaf(v[e], scs[C + c0 + e], shs[C + c0 + e]), 0.f);
+            float o = a0 * yu + (1.f - a0) * yv;
+            if (relu) o = o > 0.f ? o : 0.f;
+            u[e] = o;
+        }
+        *(uint4*)(out + ((int64_t)b * HW + r) * C + c0) = pack16<T>(u);
+    }
+}
+// backward, logits: da[b][r*C+c] += sum_hw dout' * y_r   (dout' masked by out > 0 when relu)
+template <typename T>
+__global__ __launch_bounds__(256) void splat_bwd_reduce_bn_kernel(const T* __restrict__ dout, const T* __restrict__ x, SplatBn bn, const T* __restrict__ outp,
+                                                                  float* __restrict__ da, int HW, int C, int TX, int rpb, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC][2]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    float s0[EPC], s1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (col < cpr) {
+        float scu[EPC], shu[EPC], scv[EPC], shv[EPC];
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, col * EPC, scu, shu);
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, C + col * EPC, scv, shv);
+        for (int r = r0 + ry; r < r1; r += RY) {
+            float d[EPC], o[EPC], u[EPC], v[EPC];
+            const int64_t po = ((int64_t)b * HW + r) * C + col * EPC;
+            unpack16<T>(*(const uint4*)(dout + po), d);
+            if (relu) unpack16<T>(*(const uint4*)(outp + po), o);
+            const T* px = x + ((int64_t)b * HW + r) * 2 * C + col * EPC;
+            unpack16<T>(*(const uint4*)px, u);
+            unpack16<T>(*(const uint4*)(px + C), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                s0[e] += dd * fmaxf(fmaf(u[e], scu[e], shu[e]), 0.f);
+                s1[e] += dd * fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[(((size_t)ry * TX + cx) * EPC + e) * 2] = s0[e]; red[(((size_t)ry * TX + cx) * EPC + e) * 2 + 1] = s1[e]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a = 0.f, bb = 0.f;
+        for (int yy = 0; yy < RY; ++yy) { a += red[((size_t)yy * TX * EPC + ch) * 2]; bb += red[((size_t)yy * TX * EPC + ch) * 2 + 1]; }
+        atomicAdd(da + (int64_t)b * 2 * C + c, a);
+        atomicAdd(da + (int64_t)b * 2 * C + C + c, bb);
+    }
+}
+// backward, data: the gradient that reaches y is dy_r = a_r * dout' + dgap / HW (never stored); dyp = dy where y > 0.
+//   PASS 0: BatchNorm-backward sums  partial[by][0][ch] = sum dyp, partial[by][1][ch] = sum dyp * xhat   (by = b * gridDim.y + slab)
+//   PASS 1: dx = gamma * invstd * (dyp - fin0 - xhat * fin1)      (fin = sums / (B * HW), bn_bwd_finalize_kernel's output)
+template <typename T, int PASS>
+__global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ outp, const T* __restrict__ x, SplatBn bn,
+                                                           const float* __restrict__ logits, const float* __restrict__ dgap, const float* __restrict__ fin,
+                                                           float* __restrict__ partial, T* __restrict__ dx, int HW, int C, int TX, int rpb, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // PASS 0: [RY][TX*EPC][4]
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    const int C2 = 2 * C;
+    float s[4][EPC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[k][e] = 0.f;
+    if (col < cpr) {
+        const int cu = col * EPC, cv = C + col * EPC;
+        float scu[EPC], shu[EPC], scv[EPC], shv[EPC], a0[EPC], dg[EPC];
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, cu, scu, shu);
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, cv, scv, shv);
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float l0 = logits[(int64_t)b * C2 + cu + e], l1 = logits[(int64_t)b * C2 + cv + e];
+            a0[e] = 1.f / (1.f + expf(l1 - l0));
+            dg[e] = dgap[(int64_t)b * C + cu + e] * inv;
+        }
+        // PASS 0: xhat = (x - mu) * is;  PASS 1: dx = gi * dyp - P * x - Q with P = gi * fin1 * is, Q = gi * fin0 - P * mu
+        float m0[EPC], m1[EPC], n0[EPC], n1[EPC], gu[EPC], gv[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float muu = bn.mean[cu + e], isu = bn.invstd[cu + e], muv = bn.mean[cv + e], isv = bn.invstd[cv + e];
+            if (PASS == 0) { m0[e] = muu; n0[e] = isu; m1[e] = muv; n1[e] = isv; gu[e] = 0.f; gv[e] = 0.f; }
+            else {
+                gu[e] = bn.gamma[cu + e] * isu; gv[e] = bn.gamma[cv + e] * isv;
+                const float pu = gu[e] * fin[C2 + cu + e] * isu, pv = gv[e] * fin[C2 + cv + e] * isv;
+                m0[e] = pu; n0[e] = gu[e] * fin[cu + e] - pu * muu;
+                m1[e] = pv; n1[e] = gv[e] * fin[cv + e] - pv * muv;
+            }
+        }
+        for (int r = r0 + ry; r < r1; r += RY) {
+            float d[EPC], o[EPC], u[EPC], v[EPC];
+            const int64_t po = ((int64_t)b * HW + r) * C + cu;
+            unpack16<T>(*(const uint4*)(dout + po), d);
+            if (relu) unpack16<T>(*(const uint4*)(outp + po), o);
+            const T* px = x + ((int64_t)b * HW + r) * C2 + cu;
+            unpack16<T>(*(const uint4*)px, u);
+            unpack16<T>(*(const uint4*)(px + C), v);
+            float ou[EPC], ov[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                const float du = fmaf(u[e], scu[e], shu[e]) > 0.f ? fmaf(a0[e], dd, dg[e]) : 0.f;
+                const float dv = fmaf(v[e], scv[e], shv[e]) > 0.f ? fmaf(1.f - a0[e], dd, dg[e]) : 0.f;
+                if (PASS == 0) {
+                    s[0][e] += du; s[1][e] += du * (u[e] - m0[e]) * n0[e];
+                    s[2][e] += dv; s[3][e] += dv * (v[e] - m1[e]) * n1[e];
+                } else {
+                    ou[e] = gu[e] * du - m0[e] * u[e] - n0[e];
+                    ov[e] = gv[e] * dv - m1[e] * v[e] - n1[e];
+                }
+            }
+            if (PASS == 1) {
+                T* pd = dx + ((int64_t)b * HW + r) * C2 + cu;
+                *(uint4*)pd = pack16<T>(ou);
+                *(uint4*)(pd + C) = pack16<T>(ov);
+            }
+        }
+    }
+    if (PASS == 1) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[(((size_t)ry * TX + cx) * EPC + e) * 4 + k] = s[k][e];
+    __syncthreads();
+    const int by = b * gridDim.y + blockIdx.y;
+    for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+        const int c = blockIdx.x * TX * EPC + ch;
+        if (c >= C) continue;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int yy = 0; yy < RY; ++yy)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += red[((size_t)yy * TX * EPC + ch) * 4 + k];
+        partial[((size_t)by * 2 + 0) * C2 + c] = a[0];
+        partial[((size_t)by * 2 + 1) * C2 + c] = a[1];
+        partial[((size_t)by * 2 + 0) * C2 + C + c] = a[2];
+        partial[((size_t)by * 2 + 1) * C2 + C + c] = a[3];
+    }
+}
+int octa_bn_bwd_finalize_launch(const float* partial, int nby, int C, int64_t rows, float* fin, float* dgamma, float* dbeta, hipStream_t st);   // norm.hip
+
+#define OCTA_SPLAT_BN_ARGS                                                                                                             \
+    OCTA_REQUIRE(x && mean && invstd && gamma && beta && B > 0 && HW > 0 && C % 8 == 0 && C <= 4096, "octa_splat_bn: bad arguments (C %% 8, C <= 4096)"); \
+    OCTA_REQUIRE(OCTA_DTYPE_OK(dtype), "octa_splat_bn: bad dtype");                                                                    \
+    hipStream_t st = (hipStream_t)stream;                                                                                              \
+    const int epc = dtype == OCTA_F32 ? 4 : 8;                                                                                         \
+    SplatBn bn;                                                                                                                        \
+    bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta
+
+extern "C" int octa_splat_bn_gap(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* gap, int B, int HW,
+                                 int C, int dtype, int prezeroed, octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(gap, "octa_splat_bn_gap: null pointer");
+    if (!prezeroed && octa_zero_async(gap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bn_gap: memset failed");
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int rpb = cdiv(HW, 64);
+    if (rpb < RY * 8) rpb = RY * 8;
+    dim3 grid(gx, cdiv(HW, rpb), B);
+    const size_t sh = (size_t)256 * epc * sizeof(float);
+    if (dtype == OCTA_F32) splat_gap_bn_kernel<float><<<grid, 256, sh, st>>>((const float*)x, bn, gap, HW, C, TX, rpb);
+    else if (dtype == OCTA_BF16) splat_gap_bn_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, bn, gap, HW, C, TX, rpb);
+    else splat_gap_bn_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)x, bn, gap, HW, C, TX, rpb);
+    OCTA_CHECK_LAUNCH("splat_gap_bn");
+    return OCTA_OK;
+}
+extern "C" int octa_splat_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* logits,
+                                   void* out, int B, int HW, int C, int dtype, int relu, octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(logits && out, "octa_splat_bn_apply: null pointer");
+    int rpb = cdiv(HW, 128);
+    if (rpb < 8) rpb = 8;
+    dim3 grid(cdiv(HW, rpb), B);
+    const size_t sh = (size_t)5 * C * sizeof(float);
+    if (dtype == OCTA_F32) splat_apply_bn_kernel<float><<<grid, 256, sh, st>>>((const float*)x, bn, logits, (float*)out, HW, C, relu, rpb);
+    else if (dtype == OCTA_BF16) splat_apply_bn_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)x, bn, logits, (bf16_t*)out, HW, C, relu, rpb);
+    else splat_apply_bn_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)x, bn, logits, (f16_t*)out, HW, C, relu, rpb);
+    OCTA_CHECK_LAUNCH("splat_apply_bn");
+    return OCTA_OK;
+}
+extern "C" int octa_splat_bn_bwd_logits(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                        const float* logits, const void* out, float* dlogits, int B, int HW, int C, int dtype, int relu, int prezeroed,
+                                        octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(dout && logits && dlogits && (!relu || out), "octa_splat_bn_bwd_logits: null pointer (relu needs the forward output)");
+    if (!prezeroed && octa_zero_async(dlogits, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bn_bwd_logits: memset failed");
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int rpb = cdiv(HW, 64);
+    if (rpb < RY * 8) rpb = RY * 8;
+    dim3 grid(gx, cdiv(HW, rpb), B);
+    const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
+    if (dtype == OCTA_F32) splat_bwd_reduce_bn_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, HW, C, TX, rpb, relu);
+    else if (dtype == OCTA_BF16) splat_bwd_reduce_bn_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, bn, (const bf16_t*)out, dlogits, HW, C, TX, rpb, relu);
+    else splat_bwd_reduce_bn_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, bn, (const f16_t*)out, dlogits, HW, C, TX, rpb, relu);
+    OCTA_CHECK_LAUNCH("splat_bwd_reduce_bn");
+    splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
+    OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    return OCTA_OK;
+}
+extern "C" int octa_splat_bn_bwd_dx(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    const float* logits, const void* out, const float* dgap, void* dx, float* dgamma, float* dbeta, float* ws, int B,
+                                    int HW, int C, int dtype, int relu, octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(dout && logits && dgap && dx && ws && (!relu || out), "octa_splat_bn_bwd_dx: null pointer (relu needs the forward output)");
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int nslab = 1024 / B;                                  // partial rows: B * nslab <= 1024 (octa_bn_workspace_floats)
+    if (nslab < 1) nslab = 1;
+    int rpb = cdiv(HW, nslab);
+    if (rpb < RY * 8) rpb = RY * 8;
+    nslab = cdiv(HW, rpb);
+    OCTA_REQUIRE(B * nslab <= 1024, "octa_splat_bn_bwd_dx: batch %d too large for the partial-sum workspace", B);
+    dim3 grid(gx, nslab, B);
+    const int C2 = 2 * C;
+    float* fin = ws + (size_t)1026 * 2 * C2;
+    const size_t sh = (size_t)256 * epc * 4 * sizeof(float);
+#define OCTA_SPLAT_BN_BWD(TT, PASS, SH)                                                                                                          \
+    splat_bn_bwd_kernel<TT, PASS><<<grid, 256, SH, st>>>((const TT*)dout, (const TT*)out, (const TT*)x, bn, logits, dgap, fin, ws, (TT*)dx, HW, C, TX, rpb, relu)
+    if (dtype == OCTA_F32) { OCTA_SPLAT_BN_BWD(float, 0, sh); }
+    else if (dtype == OCTA_BF16) { OCTA_SPLAT_BN_BWD(bf16_t, 0, sh); }
+    else { OCTA_SPLAT_BN_BWD(f16_t, 0, sh); }
+    OCTA_CHECK_LAUNCH("splat_bn_bwd(sums)");
+    const int rc = octa_bn_bwd_finalize_launch(ws, B * nslab, C2, (int64_t)B * HW, fin, dgamma, dbeta, st);
+    if (rc != OCTA_OK) return rc;
+    if (dtype == OCTA_F32) { OCTA_SPLAT_BN_BWD(float, 1, 0); }
+    else if (dtype == OCTA_BF16) { OCTA_SPLAT_BN_BWD(bf16_t, 1, 0); }
+    else { OCTA_SPLAT_BN_BWD(f16_t, 1, 0); }
+#undef OCTA_SPLAT_BN_BWD
+    OCTA_CHECK_LAUNCH("splat_bn_bwd(dx)");
+    return OCTA_OK;
+}
+#undef OCTA_SPLAT_BN_ARGS
+
 // =========================================================================================== SplAt attention micro-net
 // fc1 (grouped 1x1) -> bn1 over the batch -> relu -> fc2 (grouped 1x1) on (B, C) vectors (resnest.py:118-125):
 // a few MFLOP, so instead of ~25 generic launches per split-attention block each direction is a handful of

@@ -1194,10 +1194,14 @@ class SplatTailFn(Function):
     """Everything of SplAtConv2d.forward after bn0+relu (extra/resnest.py:106-138), radix 2:
     radix-sum GAP -> fc1 -> bn1 -> relu -> fc2 -> radix softmax -> weighted sum [-> relu].
     One Function so that the backward can run its two streaming passes around the micro-net, which itself is
-    two (forward) / four (backward) small exact-fp32 kernels."""
+    two (forward) / four (backward) small exact-fp32 kernels.
+    With bn0's parameters (g0 ...; training only) `xr` is the RAW conv output and bn0 + ReLU (resnest.py:100-103) are part of the
+    op: batch statistics first (octa_bn_stats), then every streaming kernel recomputes y = relu(bn0(x)) in registers
+    (octa_splat_bn_*): y and its gradient never exist in memory."""
 
     @staticmethod
-    def forward(ctx, xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu):
+    def forward(ctx, xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu,
+                g0=None, b0=None, rm0=None, rv0=None, momentum0=0.1, eps0=1e-5):
         xr = dense_nhwc(xr)
         B, C2, H, W = xr.shape
         C, HW = C2 // 2, H * W
@@ -1208,8 +1212,24 @@ class SplatTailFn(Function):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, inter, 1, 1)}")
         L = lib()
         dev = xr.device
+        fused = g0 is not None
+        mean0 = invstd0 = None
+        if fused:
+            if not training:
+                raise OctaError("split attention with bn0 on the fly is a training-mode op")
+            if B * HW <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(xr.shape)}")
+            mean0 = torch.empty((C2,), dtype=torch.float32, device=dev)
+            invstd0 = torch.empty_like(mean0)
+            L.octa_bn_stats(_p(xr), B * HW, C2, nhwc_ld(xr), 0, _dt(xr), eps0, momentum0, _p(mean0), _p(invstd0), _p(rm0), _p(rv0),
+                            _p(_bn_ws(B * HW, C2, dev)), _st())
+            if rm0 is not None:
+                bump_param_epoch()           # running statistics moved behind their version counters
         gap, pz = _zeroed_f32((B, C), dev)
-        L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), pz, _st())
+        if fused:
+            L.octa_splat_bn_gap(_p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(gap), B, HW, C, _dt(xr), pz, _st())
+        else:
+            L.octa_splat_gap(_p(xr), _p(gap), B, HW, C, _dt(xr), pz, _st())
         w1, w2 = _dense2d(fc1_w.detach()), _dense2d(fc2_w.detach())
         if w1 is None:
             w1 = fc1_w.detach().float().contiguous()
@@ -1223,18 +1243,21 @@ class SplatTailFn(Function):
         L.octa_splat_mlp_fwd(_p(gap), _p(w1), _p(fc1_b), _p(g1), _p(b1), _p(rm1), _p(rv1), momentum, eps, int(training), _p(w2), _p(fc2_b),
                              _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(logits), B, C, inter, cardinality, _st())
         out = nhwc_empty(B, C, H, W, xr.dtype, dev)
-        L.octa_splat_apply(_p(xr), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
-        ctx.cfg = (cardinality, training, relu, B, C, H, W, inter)
-        ctx.refs = (fc1_w, fc1_b, g1, b1, fc2_w, fc2_b)
-        ctx.save_for_backward(xr, out if relu else None, logits, gap, h1, h2, mean1, invstd1, w1, w2)
+        if fused:
+            L.octa_splat_bn_apply(_p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
+        else:
+            L.octa_splat_apply(_p(xr), _p(logits), _p(out), B, HW, C, _dt(xr), int(relu), _st())
+        ctx.cfg = (cardinality, training, relu, B, C, H, W, inter, fused)
+        ctx.refs = (fc1_w, fc1_b, g1, b1, fc2_w, fc2_b, g0, b0)
+        ctx.save_for_backward(xr, out if relu else None, logits, gap, h1, h2, mean1, invstd1, w1, w2, mean0, invstd0)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        xr, out, logits, gap, h1, h2, mean1, invstd1, w1, w2 = ctx.saved_tensors
-        card, training, relu, B, C, H, W, inter = ctx.cfg
-        fc1_w, fc1_b, g1, b1, fc2_w, fc2_b = ctx.refs
+        xr, out, logits, gap, h1, h2, mean1, invstd1, w1, w2, mean0, invstd0 = ctx.saved_tensors
+        card, training, relu, B, C, H, W, inter, fused = ctx.cfg
+        fc1_w, fc1_b, g1, b1, fc2_w, fc2_b, g0, b0 = ctx.refs
         if not training:
             raise OctaError("SplAt backward in eval mode is not part of the hot path")
         HW = H * W
@@ -1242,7 +1265,11 @@ class SplatTailFn(Function):
         dev = xr.device
         dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
         dlogits, pz = _zeroed_f32((B, 2 * C), dev)
-        L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, pz, _st())
+        if fused:
+            L.octa_splat_bn_bwd_logits(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), B, HW, C,
+                                       _dt(xr), int(relu), pz, _st())
+        else:
+            L.octa_splat_bwd(_p(dout), _p(xr), _p(logits), _p(out), None, None, _p(dlogits), B, HW, C, _dt(xr), int(relu), 0, pz, _st())
         dw1, r_w1 = _grad_buf(fc1_w, True)
         db1f, r_b1f = _grad_buf(fc1_b)
         dg1, r_g1 = _grad_buf(g1)
@@ -1254,12 +1281,23 @@ class SplatTailFn(Function):
         L.octa_splat_mlp_bwd(_p(dlogits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap), _p(dw1),
                              _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, pzg, _st())
         dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, dev)
-        L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, 0, _st())
-        return dx, r_w1, r_b1f, r_g1, r_be1, None, None, r_w2, r_b2, None, None, None, None, None
+        r_g0 = r_b0 = None
+        if fused:
+            dg0, r_g0 = _grad_buf(g0)
+            db0, r_b0 = _grad_buf(b0)
+            L.octa_splat_bn_bwd_dx(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dgap), _p(dx), _p(dg0),
+                                   _p(db0), _p(_bn_ws(B * HW, 2 * C, dev)), B, HW, C, _dt(xr), int(relu), _st())
+        else:
+            L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, 0, _st())
+        return dx, r_w1, r_b1f, r_g1, r_be1, None, None, r_w2, r_b2, None, None, None, None, None, r_g0, r_b0, None, None, None, None
 
 
-def splat_tail(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum=0.1, eps=1e-5, training=True, relu=False):
-    return SplatTailFn.apply(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu)
+def splat_tail(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum=0.1, eps=1e-5, training=True, relu=False, bn0=None):
+    """bn0 = (weight, bias, running_mean, running_var, momentum, eps) of the BatchNorm that precedes the split attention: xr is then
+    the raw conv output (training mode)."""
+    if bn0 is None:
+        return SplatTailFn.apply(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu)
+    return SplatTailFn.apply(xr, fc1_w, fc1_b, g1, b1, rm1, rv1, fc2_w, fc2_b, cardinality, momentum, eps, training, relu, *bn0)
 
 
 class AagFn(Function):

@@ -107,6 +107,67 @@ def scribble(seed, shape=(B, C, H, W), empty_class=None):
     return ys
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(64, 64, 1, 4, 24, 20, False), (128, 64, 2, 3, 33, 17, True), (32, 256, 1, 16, 13, 13, False)])
+def test_splat_with_bn0_on_the_fly_vs_separate_batchnorm(dev, dtype, cfg):
+    """SplAtConv2d in training mode recomputes bn0 + ReLU inside the split-attention kernels (octa_splat_bn_*: no BatchNorm-apply
+    pass, no stored activation); OCTA_FUSE_SPLAT_BN0=0 runs conv -> BatchNorm -> split attention as separate ops.  Same module, same
+    input and cotangent, both ways, two steps: outputs, input gradient, every parameter gradient and every buffer.  fp32: the two
+    differ by summation order only; 16-bit: the separate path rounds the BatchNorm output to the storage type, the fused one does not
+    (bound: a few ulp of the activation scale on outputs, 2 % of the gradient scale on gradients)."""
+    import architectures.extra.resnest as R
+    from octave_amd import functional as F_
+    from octave_amd.layers import BatchNorm2d
+    cin, ch, card, B, H, W, relu_after = cfg
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    x0 = (torch.randn(B, cin, H, W, generator=gen) * 1.5 + 0.3)
+    g0 = torch.randn(B, ch, H, W, generator=gen)
+
+    def run(fused):
+        old = R._FUSE_SPLAT_BN0
+        R._FUSE_SPLAT_BN0 = fused
+        try:
+            torch.manual_seed(5)
+            m = R.SplAtConv2d(cin, ch, 3, padding=1, groups=card, bias=True, radix=2, norm_layer=BatchNorm2d).to(dev).train()
+            with torch.no_grad():
+                m.bn0.weight.copy_(torch.rand(2 * ch, generator=torch.Generator().manual_seed(7)) + 0.5)
+                m.bn0.bias.copy_(torch.randn(2 * ch, generator=torch.Generator().manual_seed(8)) * 0.3)
+            outs = []
+            for it in range(2):
+                for p_ in m.parameters():
+                    p_.grad = None
+                x = F_.to_nhwc(x0.to(dev), dtype=dtype).detach().requires_grad_(True)
+                y = m(x, relu_after)
+                (y.float() * g0.to(dev)).sum().backward()
+                outs.append((F_.to_nchw_f32(y.detach()), F_.to_nchw_f32(x.grad), {n: p_.grad.detach().float().clone() for n, p_ in m.named_parameters()},
+                             {n: b_.detach().float().clone() for n, b_ in m.named_buffers()}))
+            return outs
+        finally:
+            R._FUSE_SPLAT_BN0 = old
+    a, b = run(True), run(False)
+    f32 = dtype == torch.float32
+    for it in range(2):
+        ya, dxa, ga, ba = a[it]
+        yb, dxb, gb, bb = b[it]
+        sy, sdx = float(yb.abs().max()), float(dxb.abs().max())
+        assert float((ya - yb).abs().max()) <= (2e-5 if f32 else 2.5e-2) * sy, (it, float((ya - yb).abs().max()), sy)
+        rel = float((dxa - dxb).norm() / dxb.norm())
+        assert rel <= (2e-4 if f32 else 2e-2), (it, "dx", rel)
+        gmax = max(float(v.abs().max()) for v in gb.values())
+        for n in gb:
+            if n in ("conv.bias", "fc1.bias"):
+                # a bias in front of a BatchNorm (bn0 resp. bn1): the exact gradient is 0, both paths return rounding noise
+                assert float(ga[n].abs().max()) <= (1e-3 if f32 else 5e-2) * gmax and float(gb[n].abs().max()) <= (1e-3 if f32 else 5e-2) * gmax, (it, n)
+                continue
+            rel = float((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-3 * gmax * gb[n].numel() ** 0.5))
+            assert rel <= (1e-3 if f32 else 3e-2), (it, n, rel)
+        for n in bb:
+            if n.endswith("num_batches_tracked"):
+                assert int(ba[n]) == int(bb[n]) == it + 1, (it, n)
+            else:
+                assert float((ba[n] - bb[n]).abs().max()) <= (1e-5 if f32 else 2e-3) * (float(bb[n].abs().max()) + 1.0), (it, n)
+
+
 def test_losses_vs_reference_golden(dev, golden):
     from architectures.discriminator.losses import LSDiscriminatorialLoss, LSGeneratorLoss
     from architectures.segmentor.losses import DiceLoss, InterlayerDivergence, WeightedPartialCE
