@@ -841,7 +841,7 @@ class TrainStep:
                         g2.replay()
                         d_done = torch.cuda.Event()
                         d_done.record(self._disc_stream)
-            elif marker is not None and marker != "fwd":
+            if marker is not None and marker != "fwd":
                 self.seg_arena.all_reduce_bucket_async(self.world, comm, marker, self.grad_comm_dtype)
                 started.append(marker)
         # what has not left yet (everything, without the bucket cuts), in completion order on the comm stream
