@@ -50,11 +50,63 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { mu[e] = mean[col * EPC + e]; is[e] = invstd[col * EPC + e]; }
         }
-        for (int64_t r = r0 + ry; r < r1; r += RY) {
+        int64_t rbeg = r0 + ry;
+        if (MODE == 0 && rbeg < r1) {
+            // shifted sums (shift = this thread's first sample): no E[x^2]-E[x]^2 cancellation.  Four independent row loads in
+            // flight per thread: the one-load-per-iteration loop read at 4.0 TB/s where the other streaming kernels reach 5-6
+            unpack16<T>(*(const uint4*)(x + rbeg * ldx + xoff + col * EPC), mu);
+            const T* __restrict__ xp = x + xoff + col * EPC;
+            int64_t r = rbeg;
+            for (; r + 3 * RY < r1; r += 4 * RY) {
+                const uint4 q0 = *(const uint4*)(xp + r * ldx), q1 = *(const uint4*)(xp + (r + RY) * ldx);
+                const uint4 q2 = *(const uint4*)(xp + (r + 2 * RY) * ldx), q3 = *(const uint4*)(xp + (r + 3 * RY) * ldx);
+                float x0[EPC], x1[EPC], x2[EPC], x3[EPC];
+                unpack16<T>(q0, x0); unpack16<T>(q1, x1); unpack16<T>(q2, x2); unpack16<T>(q3, x3);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float d0 = x0[e] - mu[e], d1 = x1[e] - mu[e], d2 = x2[e] - mu[e], d3 = x3[e] - mu[e];
+                    sa[e] += (d0 + d1) + (d2 + d3);
+                    sb[e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+                cnt += 4;
+            }
+            for (; r < r1; r += RY) {
+                float xv[EPC];
+                unpack16<T>(*(const uint4*)(xp + r * ldx), xv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float d = xv[e] - mu[e]; sa[e] += d; sb[e] += d * d; }
+                ++cnt;
+            }
+            rbeg = r1;
+        }
+        if (MODE == 1) {
+            // two rows per iteration, their (up to six) loads issued before any arithmetic
+            const bool um = relu && rmask, uy = relu && !rmask;
+            for (; rbeg + RY < r1; rbeg += 2 * RY) {
+                const int64_t ra = rbeg, rb2 = rbeg + RY;
+                const uint4 xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC), xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
+                const uint4 da = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC), db = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
+                unsigned ma = 0xffu, mb = 0xffu;
+                uint4 ya = make_uint4(0, 0, 0, 0), yb = ya;
+                if (um) { ma = rmask[ra * cpr + col]; mb = rmask[rb2 * cpr + col]; }
+                if (uy) { ya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); yb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+                float x0[EPC], x1[EPC], d0[EPC], d1[EPC], y0[EPC], y1[EPC];
+                unpack16<T>(xa, x0); unpack16<T>(xb, x1); unpack16<T>(da, d0); unpack16<T>(db, d1);
+                if (uy) { unpack16<T>(ya, y0); unpack16<T>(yb, y1); }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const bool k0 = uy ? (y0[e] > 0.f) : ((ma >> e) & 1u) != 0, k1 = uy ? (y1[e] > 0.f) : ((mb >> e) & 1u) != 0;
+                    const float g0 = k0 ? d0[e] : 0.f, g1 = k1 ? d1[e] : 0.f;
+                    sa[e] += g0 + g1;
+                    sb[e] += (g0 * (x0[e] - mu[e]) + g1 * (x1[e] - mu[e])) * is[e];
+                }
+            }
+        }
+        for (int64_t r = rbeg; r < r1; r += RY) {
             float xv[EPC];
             unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
             if (MODE == 0) {
-                // shifted sums (shift = this thread's first sample): no E[x^2]-E[x]^2 cancellation
+                // (unreachable: the statistics pass ran above)
                 if (cnt == 0) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) mu[e] = xv[e];

@@ -277,7 +277,18 @@ __global__ __launch_bounds__(256) void splat_gap_bn_kernel(const T* __restrict__
         bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, col * EPC, scu, shu);
         bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, C + col * EPC, scv, shv);
         const T* base = x + (int64_t)b * HW * 2 * C + col * EPC;
-        for (int r = r0 + ry; r < r1; r += RY) {
+        int r = r0 + ry;
+        for (; r + RY < r1; r += 2 * RY) {               // two rows (four loads) in flight
+            const uint4 qa = *(const uint4*)(base + (int64_t)r * 2 * C), qb = *(const uint4*)(base + (int64_t)r * 2 * C + C);
+            const uint4 qc = *(const uint4*)(base + (int64_t)(r + RY) * 2 * C), qd = *(const uint4*)(base + (int64_t)(r + RY) * 2 * C + C);
+            float u[EPC], v[EPC], u2[EPC], v2[EPC];
+            unpack16<T>(qa, u); unpack16<T>(qb, v); unpack16<T>(qc, u2); unpack16<T>(qd, v2);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                s[e] += (fmaxf(fmaf(u[e], scu[e], shu[e]), 0.f) + fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f)) +
+                        (fmaxf(fmaf(u2[e], scu[e], shu[e]), 0.f) + fmaxf(fmaf(v2[e], scv[e], shv[e]), 0.f));
+        }
+        for (; r < r1; r += RY) {
             float u[EPC], v[EPC];
             unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C), u);
             unpack16<T>(*(const uint4*)(base + (int64_t)r * 2 * C + C), v);
