@@ -231,7 +231,58 @@ __global__ __launch_bounds__(256) void bn_small_reduce_kernel(const T* __restric
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { mu[e] = mean[col * EPC + e]; is[e] = invstd[col * EPC + e]; }
     }
-    for (int64_t r = r0 + ry; r < r1; r += RY) {
+    int64_t rbeg = r0 + ry;
+    // (these tensors give a thread <= 16 rows: with one load per iteration the kernel is 16 dependent round trips to memory;
+    // four resp. two rows' loads are issued together)
+    if (MODE == 0 && rbeg < r1) {
+        const T* __restrict__ xp = x + xoff + col * EPC;
+        unpack16<T>(*(const uint4*)(xp + rbeg * ldx), mu);
+        int64_t r = rbeg;
+        for (; r + 3 * RY < r1; r += 4 * RY) {
+            const uint4 q0 = *(const uint4*)(xp + r * ldx), q1 = *(const uint4*)(xp + (r + RY) * ldx);
+            const uint4 q2 = *(const uint4*)(xp + (r + 2 * RY) * ldx), q3 = *(const uint4*)(xp + (r + 3 * RY) * ldx);
+            float x0[EPC], x1[EPC], x2[EPC], x3[EPC];
+            unpack16<T>(q0, x0); unpack16<T>(q1, x1); unpack16<T>(q2, x2); unpack16<T>(q3, x3);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d0 = x0[e] - mu[e], d1 = x1[e] - mu[e], d2 = x2[e] - mu[e], d3 = x3[e] - mu[e];
+                sa[e] += (d0 + d1) + (d2 + d3);
+                sb[e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            cnt += 4;
+        }
+        for (; r < r1; r += RY) {
+            float xv[EPC];
+            unpack16<T>(*(const uint4*)(xp + r * ldx), xv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float d = xv[e] - mu[e]; sa[e] += d; sb[e] += d * d; }
+            ++cnt;
+        }
+        rbeg = r1;
+    }
+    if (MODE == 1) {
+        const bool um = relu && rmask, uy = relu && !rmask;
+        for (; rbeg + RY < r1; rbeg += 2 * RY) {
+            const int64_t ra = rbeg, rb2 = rbeg + RY;
+            const uint4 xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC), xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
+            const uint4 da = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC), db = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
+            unsigned ma = 0xffu, mb = 0xffu;
+            uint4 ya = make_uint4(0, 0, 0, 0), yb = ya;
+            if (um) { ma = rmask[ra * cpr + col]; mb = rmask[rb2 * cpr + col]; }
+            if (uy) { ya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); yb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+            float x0[EPC], x1[EPC], d0[EPC], d1[EPC], y0[EPC], y1[EPC];
+            unpack16<T>(xa, x0); unpack16<T>(xb, x1); unpack16<T>(da, d0); unpack16<T>(db, d1);
+            if (uy) { unpack16<T>(ya, y0); unpack16<T>(yb, y1); }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const bool k0 = uy ? (y0[e] > 0.f) : ((ma >> e) & 1u) != 0, k1 = uy ? (y1[e] > 0.f) : ((mb >> e) & 1u) != 0;
+                const float g0 = k0 ? d0[e] : 0.f, g1 = k1 ? d1[e] : 0.f;
+                sa[e] += g0 + g1;
+                sb[e] += (g0 * (x0[e] - mu[e]) + g1 * (x1[e] - mu[e])) * is[e];
+            }
+        }
+    }
+    for (int64_t r = rbeg; r < r1; r += RY) {
         float xv[EPC];
         unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);
         if (MODE == 0) {
@@ -359,7 +410,41 @@ __global__ __launch_bounds__(256) void bn_small_apply_kernel(const T* __restrict
     for (int e = 0; e < EPC; ++e) { mu[e] = coef[cx * EPC + e][0]; sc[e] = coef[cx * EPC + e][1]; be[e] = coef[cx * EPC + e][2]; }
     const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
     // block-uniform trip count (the DPP mask combine below needs every lane of a quad in the loop)
-    for (int64_t rb = r0; rb < r1; rb += RY) {
+    int64_t rb = r0;
+    for (; rb + RY < r1; rb += 2 * RY) {                 // two row groups per iteration, their loads issued together
+        const int64_t ra = rb + ry, rc = rb + RY + ry;
+        const bool la = ra < r1, lc = rc < r1;
+        const int64_t qa = la ? ra : r0, qc = lc ? rc : r0;
+        const uint4 xa = *(const uint4*)(x + qa * ldx + xoff + col * EPC), xc = *(const uint4*)(x + qc * ldx + xoff + col * EPC);
+        uint4 sa = make_uint4(0, 0, 0, 0), sc2 = sa;
+        if (res) { sa = *(const uint4*)(res + qa * ldr + roff + col * EPC); sc2 = *(const uint4*)(res + qc * ldr + roff + col * EPC); }
+        float va[EPC], vc[EPC], ea[EPC], ec[EPC];
+        unpack16<T>(xa, va); unpack16<T>(xc, vc);
+        if (res) { unpack16<T>(sa, ea); unpack16<T>(sc2, ec); }
+        unsigned mba = 0u, mbc = 0u;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float oa = (va[e] - mu[e]) * sc[e] + be[e], oc = (vc[e] - mu[e]) * sc[e] + be[e];
+            if (res) { oa += ea[e]; oc += ec[e]; }
+            if (relu) {
+                if (oa > 0.f) mba |= 1u << e; else oa = 0.f;
+                if (oc > 0.f) mbc |= 1u << e; else oc = 0.f;
+            }
+            va[e] = oa; vc[e] = oc;
+        }
+        if (la) *(uint4*)(y + qa * ldy + yoff + col * EPC) = pack16<T>(va);
+        if (lc) *(uint4*)(y + qc * ldy + yoff + col * EPC) = pack16<T>(vc);
+        if (rmask) {
+            unsigned wa = la ? (mba << (8 * (threadIdx.x & 3))) : 0u, wc = lc ? (mbc << (8 * (threadIdx.x & 3))) : 0u;
+            wa |= (unsigned)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
+            wc |= (unsigned)__builtin_amdgcn_mov_dpp((int)wc, 0xB1, 0xF, 0xF, true);
+            wa |= (unsigned)__builtin_amdgcn_mov_dpp((int)wa, 0x4E, 0xF, 0xF, true);
+            wc |= (unsigned)__builtin_amdgcn_mov_dpp((int)wc, 0x4E, 0xF, 0xF, true);
+            if ((threadIdx.x & 3) == 0 && la) *(unsigned*)(rmask + qa * cpr + col) = wa;
+            if ((threadIdx.x & 3) == 0 && lc) *(unsigned*)(rmask + qc * cpr + col) = wc;
+        }
+    }
+    for (; rb < r1; rb += RY) {
         const int64_t r = rb + ry;
         const bool live = r < r1;
         const int64_t rr_ = live ? r : r0;
@@ -421,7 +506,33 @@ __global__ __launch_bounds__(256) void bn_small_bwd_apply_kernel(const T* __rest
         mu[e] = k[0]; isd[e] = k[1]; gi[e] = k[2]; f0[e] = k[3]; f1[e] = k[4];
     }
     const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
-    for (int64_t r = r0 + ry; r < r1; r += RY) {
+    int64_t rbeg = r0 + ry;
+    {   // two rows per iteration, loads first (see bn_small_reduce_kernel)
+        const bool um = relu && rmask, uy = relu && !rmask;
+        for (; rbeg + RY < r1; rbeg += 2 * RY) {
+            const int64_t ra = rbeg, rb2 = rbeg + RY;
+            const uint4 xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC), xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
+            const uint4 da = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC), db = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
+            unsigned ma = 0xffu, mb = 0xffu;
+            uint4 ya = make_uint4(0, 0, 0, 0), yb = ya;
+            if (um) { ma = rmask[ra * cpr + col]; mb = rmask[rb2 * cpr + col]; }
+            if (uy) { ya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); yb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+            float x0[EPC], x1[EPC], d0[EPC], d1[EPC], y0[EPC], y1[EPC], o0[EPC], o1[EPC];
+            unpack16<T>(xa, x0); unpack16<T>(xb, x1); unpack16<T>(da, d0); unpack16<T>(db, d1);
+            if (uy) { unpack16<T>(ya, y0); unpack16<T>(yb, y1); }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const bool k0 = uy ? (y0[e] > 0.f) : ((ma >> e) & 1u) != 0, k1 = uy ? (y1[e] > 0.f) : ((mb >> e) & 1u) != 0;
+                d0[e] = k0 ? d0[e] : 0.f; d1[e] = k1 ? d1[e] : 0.f;
+                o0[e] = gi[e] * (d0[e] - f0[e] - (x0[e] - mu[e]) * isd[e] * f1[e]);
+                o1[e] = gi[e] * (d1[e] - f0[e] - (x1[e] - mu[e]) * isd[e] * f1[e]);
+            }
+            *(uint4*)(dx + ra * lddx + dxoff + col * EPC) = pack16<T>(o0);
+            *(uint4*)(dx + rb2 * lddx + dxoff + col * EPC) = pack16<T>(o1);
+            if (dres) { *(uint4*)(dres + ra * lddr + droff + col * EPC) = pack16<T>(d0); *(uint4*)(dres + rb2 * lddr + droff + col * EPC) = pack16<T>(d1); }
+        }
+    }
+    for (int64_t r = rbeg; r < r1; r += RY) {
         float dv[EPC], xv[EPC], yv[EPC], o[EPC];
         unpack16<T>(*(const uint4*)(dy + r * lddy + dyoff + col * EPC), dv);
         unpack16<T>(*(const uint4*)(x + r * ldx + xoff + col * EPC), xv);

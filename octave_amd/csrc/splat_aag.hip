@@ -367,7 +367,26 @@ __global__ __launch_bounds__(256) void splat_bwd_reduce_bn_kernel(const T* __res
         float scu[EPC], shu[EPC], scv[EPC], shv[EPC];
         bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, col * EPC, scu, shu);
         bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, C + col * EPC, scv, shv);
-        for (int r = r0 + ry; r < r1; r += RY) {
+        int r = r0 + ry;
+        for (; r + RY < r1; r += 2 * RY) {                 // two rows per iteration, loads first
+            const int64_t pa = ((int64_t)b * HW + r) * C + col * EPC, pb = ((int64_t)b * HW + r + RY) * C + col * EPC;
+            const T* xa = x + ((int64_t)b * HW + r) * 2 * C + col * EPC;
+            const T* xb = x + ((int64_t)b * HW + r + RY) * 2 * C + col * EPC;
+            const uint4 qd0 = *(const uint4*)(dout + pa), qd1 = *(const uint4*)(dout + pb);
+            uint4 qo0 = make_uint4(0, 0, 0, 0), qo1 = qo0;
+            if (relu) { qo0 = *(const uint4*)(outp + pa); qo1 = *(const uint4*)(outp + pb); }
+            const uint4 qu0 = *(const uint4*)xa, qv0 = *(const uint4*)(xa + C), qu1 = *(const uint4*)xb, qv1 = *(const uint4*)(xb + C);
+            float d0[EPC], d1[EPC], o0[EPC], o1[EPC], u0[EPC], v0[EPC], u1[EPC], v1[EPC];
+            unpack16<T>(qd0, d0); unpack16<T>(qd1, d1); unpack16<T>(qu0, u0); unpack16<T>(qv0, v0); unpack16<T>(qu1, u1); unpack16<T>(qv1, v1);
+            if (relu) { unpack16<T>(qo0, o0); unpack16<T>(qo1, o1); }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float da = (relu && !(o0[e] > 0.f)) ? 0.f : d0[e], db = (relu && !(o1[e] > 0.f)) ? 0.f : d1[e];
+                s0[e] += da * fmaxf(fmaf(u0[e], scu[e], shu[e]), 0.f) + db * fmaxf(fmaf(u1[e], scu[e], shu[e]), 0.f);
+                s1[e] += da * fmaxf(fmaf(v0[e], scv[e], shv[e]), 0.f) + db * fmaxf(fmaf(v1[e], scv[e], shv[e]), 0.f);
+            }
+        }
+        for (; r < r1; r += RY) {
             float d[EPC], o[EPC], u[EPC], v[EPC];
             const int64_t po = ((int64_t)b * HW + r) * C + col * EPC;
             unpack16<T>(*(const uint4*)(dout + po), d);
@@ -440,15 +459,10 @@ __global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__
                 m1[e] = pv; n1[e] = gv[e] * fin[cv + e] - pv * muv;
             }
         }
-        for (int r = r0 + ry; r < r1; r += RY) {
-            float d[EPC], o[EPC], u[EPC], v[EPC];
-            const int64_t po = ((int64_t)b * HW + r) * C + cu;
-            unpack16<T>(*(const uint4*)(dout + po), d);
-            if (relu) unpack16<T>(*(const uint4*)(outp + po), o);
-            const T* px = x + ((int64_t)b * HW + r) * C2 + cu;
-            unpack16<T>(*(const uint4*)px, u);
-            unpack16<T>(*(const uint4*)(px + C), v);
-            float ou[EPC], ov[EPC];
+        auto row = [&](int r, const uint4& qd, const uint4& qo, const uint4& qu, const uint4& qv) {
+            float d[EPC], o[EPC], u[EPC], v[EPC], ou[EPC], ov[EPC];
+            unpack16<T>(qd, d); unpack16<T>(qu, u); unpack16<T>(qv, v);
+            if (relu) unpack16<T>(qo, o);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
@@ -467,6 +481,23 @@ __global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__
                 *(uint4*)pd = pack16<T>(ou);
                 *(uint4*)(pd + C) = pack16<T>(ov);
             }
+        };
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        int r = r0 + ry;
+        for (; r + RY < r1; r += 2 * RY) {                 // two rows per iteration: eight loads in flight, then the arithmetic
+            const int64_t pa = ((int64_t)b * HW + r) * C + cu, pb = ((int64_t)b * HW + r + RY) * C + cu;
+            const T* xa = x + ((int64_t)b * HW + r) * C2 + cu;
+            const T* xb = x + ((int64_t)b * HW + r + RY) * C2 + cu;
+            const uint4 qd0 = *(const uint4*)(dout + pa), qd1 = *(const uint4*)(dout + pb);
+            const uint4 qo0 = relu ? *(const uint4*)(outp + pa) : z4, qo1 = relu ? *(const uint4*)(outp + pb) : z4;
+            const uint4 qu0 = *(const uint4*)xa, qv0 = *(const uint4*)(xa + C), qu1 = *(const uint4*)xb, qv1 = *(const uint4*)(xb + C);
+            row(r, qd0, qo0, qu0, qv0);
+            row(r + RY, qd1, qo1, qu1, qv1);
+        }
+        for (; r < r1; r += RY) {
+            const int64_t po = ((int64_t)b * HW + r) * C + cu;
+            const T* px = x + ((int64_t)b * HW + r) * C2 + cu;
+            row(r, *(const uint4*)(dout + po), relu ? *(const uint4*)(outp + po) : z4, *(const uint4*)px, *(const uint4*)(px + C));
         }
     }
     if (PASS == 1) return;
