@@ -354,7 +354,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         bc1 = (float)(1.0 - pow((double)b1, t));
         bc2s = (float)sqrt(1.0 - pow((double)b2, t));
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // 16-byte accesses when the four arrays allow it (the arenas do): a quarter of the memory instructions of the scalar loop
+    int64_t done = 0;
+    if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const float4 g4 = ((const float4*)g)[i], p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
+            const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, pa[4] = {p4.x, p4.y, p4.z, p4.w}, ma[4] = {m4.x, m4.y, m4.z, m4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w};
+            float po[4], mo[4], vo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float gg = ga[e] * gs;
+                if (wd != 0.f) gg += wd * pa[e];
+                mo[e] = b1 * ma[e] + (1.f - b1) * gg;
+                vo[e] = b2 * va[e] + (1.f - b2) * gg * gg;
+                const float denom = sqrtf(vo[e]) / bc2s + eps;
+                po[e] = pa[e] - (lr / bc1) * (mo[e] / denom);
+            }
+            ((float4*)m)[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            ((float4*)v)[i] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+            ((float4*)p)[i] = make_float4(po[0], po[1], po[2], po[3]);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gg = g[i] * gs;
         const float pp = p[i];
         if (wd != 0.f) gg += wd * pp;
@@ -373,7 +396,7 @@ extern "C" int octa_adam_step(float* p, const float* g, float* m, float* v, int6
     if (step < 1) step = 1;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    adam_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev, ls_state, ls_flag);
+    adam_kernel<<<ew_blocks((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev, ls_state, ls_flag);
     OCTA_CHECK_LAUNCH("adam");
     return OCTA_OK;
 }
