@@ -5,6 +5,7 @@ Parity contract kept from the reference: every training-mode cal
 order, one ``torch.normal(size=(H, W))`` plane and one ``FloatTensor(1).uniform_`` from the GLOBAL
 CPU generator, and advances the four spectral-norm (u, v) pairs by one power iteration.
 """
+import os
 from typing import List, Literal, Sequence
 
 import torch
@@ -15,6 +16,9 @@ from architectures.utils import rand_uniform
 from octave_amd import functional as F_
 from octave_amd._lib import ACT_LEAKY02, ACT_SIGMOID, ACT_TANH
 from octave_amd.layers import Conv2d
+
+
+_SN_BATCH = os.environ.get("OCTA_SN_BATCH", "1") != "0"      # one batched power iteration per discriminator call
 
 
 class SpectralConv2d(Conv2d):
@@ -34,8 +38,11 @@ class SpectralConv2d(Conv2d):
         self.register_buffer('weight_v', v)
         self.sn_eps = eps
 
-    def forward(self, x):
-        w = F_.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, self.sn_eps)
+    def forward(self, x, w=None):
+        """`w`: the normalised weight when the caller ran this layer's power iteration together with other layers'
+        (functional.spectral_norm_batch); None: run it here."""
+        if w is None:
+            w = F_.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, self.sn_eps)
         return F_.conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.groups, self.act)
 
 
@@ -164,11 +171,15 @@ class DiscriminatorBlock(nn.Module):
             s = self.stack_0[1](s)
         else:
             s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype))
+        # the spectral-norm convs' power iterations (independent of each other and of the activations): one batched call
+        sn = [self.spectral_dict[f'spectral_{i}'][0] for i in range(self.depth)]
+        wn = F_.spectral_norm_batch([(m.weight_orig, m.weight_u, m.weight_v) for m in sn], sn[0].training, sn[0].sn_eps) \
+            if (_SN_BATCH and 1 <= self.depth <= 8 and all(m.training == sn[0].training and m.sn_eps == sn[0].sn_eps for m in sn)) else [None] * self.depth
         for i in range(self.depth):
             try:
                 s = self.squeeze_dict[f'squeeze_{i}'][0](s)
                 s = F_.DiscCatFn.apply(s, y[i + 1], True)      # the map goes into the squeeze output's pad channels
-                s = self.spectral_dict[f'spectral_{i}'][0](s)
+                s = sn[i](s, wn[i])
             except Exception as e:
                 raise Exception(f'Exception raised in depth = {i}') from e
         fc = self.out[0]

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 304
+#define OCTA_HIP_ABI_VERSION 305
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -449,6 +449,19 @@ int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Cout, int K, 
 int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v,
                            const float* sigma, int Cout, int K, float* dw, float* ws, int accumulate, int ws_prezeroed, int dwsn_khw,
                            octa_stream_t stream);
+/* The same for up to 8 independent layers in one launch per kernel (a discriminator call normalises four conv weights:
+ * 12 launches -> 3 forward, 8 -> 2 backward).  Job arrays live in HOST memory (they travel as kernel arguments). */
+typedef struct octa_sn_job {
+    const float* w; float* u; float* v; float* sigma; float* w_sn; float* ws /* K + Cout floats */; float* uv_saved /* optional */;
+    int32_t Cout, K;
+} octa_sn_job;
+typedef struct octa_sn_bwd_job {
+    const float* dw_sn; const float* w_sn; const float* u; const float* v; const float* sigma; float* dw; float* ws /* 1 float */;
+    int32_t Cout, K, accumulate, dwsn_khw;
+} octa_sn_bwd_job;
+int octa_spectral_norm_fwd_batch(const octa_sn_job* jobs_host, int n, int do_power_iter, float eps, int ws_prezeroed,
+                                 octa_stream_t stream);
+int octa_spectral_norm_bwd_batch(const octa_sn_bwd_job* jobs_host, int n, int ws_prezeroed, octa_stream_t stream);
 /* Full-extent conv = per-sample dot product (blocks.py:68-72): out[b] = x[b,:].w + bias.
  * x NHWC [B, n] of dtype, w fp32 [n] in the same (h,w,c) order. */
 int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* out, int B, int64_t n,

@@ -34,6 +34,17 @@ class PackDesc(ctypes.Structure):
                 ("s_w", ctypes.c_int64)] + [(n, ctypes.c_int32) for n in ("kind", "dtype", "Cout_g", "Cin_g", "KH", "KW", "groups", "pad_to")]
 
 
+class SnJob(ctypes.Structure):
+    """octa_sn_job: one layer of a batched spectral normalisation (octa_spectral_norm_fwd_batch)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w", "u", "v", "sigma", "w_sn", "ws", "uv_saved")] + [("Cout", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
+class SnBwdJob(ctypes.Structure):
+    """octa_sn_bwd_job (octa_spectral_norm_bwd_batch)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dw_sn", "w_sn", "u", "v", "sigma", "dw", "ws")] + \
+               [(n, ctypes.c_int32) for n in ("Cout", "K", "accumulate", "dwsn_khw")]
+
+
 class OctaError(RuntimeError):
     pass
 

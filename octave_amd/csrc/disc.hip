@@ -210,6 +210,201 @@ extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, con
     return OCTA_OK;
 }
 
+// ------------------------------------------------------------------------------------------ spectral norm, several layers per launch
+// A discriminator call normalises four conv weights (blocks.py:97-110), each three launches of a few microseconds in a chain
+// that is pure launch latency.  The layers are independent: one launch per kernel covers all of them (blockIdx.x -> (layer,
+// block of the layer) through a prefix table passed by value).
+#define SN_MAXJOBS 8
+struct SnBatch {
+    int n;
+    int first[SN_MAXJOBS + 1];                // first block of job j (A / B: row blocks, C: element blocks, bwd: element blocks)
+    const float* w[SN_MAXJOBS]; float* u[SN_MAXJOBS]; float* v[SN_MAXJOBS]; float* sigma[SN_MAXJOBS]; float* wsn[SN_MAXJOBS];
+    float* ws[SN_MAXJOBS]; float* uvs[SN_MAXJOBS];
+    int Cout[SN_MAXJOBS], K[SN_MAXJOBS];
+};
+__device__ __forceinline__ int sn_job_of(const SnBatch& b, int blk, int& local) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < SN_MAXJOBS; ++i) if (i < b.n && blk >= b.first[i]) j = i;
+    local = blk - b.first[j];
+    return j;
+}
+__global__ __launch_bounds__(256) void spectral_A_batch_kernel(const SnBatch b) {
+    int lb;
+    const int j = sn_job_of(b, blockIdx.x, lb);
+    const float* __restrict__ w = b.w[j];
+    const float* __restrict__ u = b.u[j];
+    float* __restrict__ vraw = b.ws[j];
+    const int Cout = b.Cout[j], K = b.K[j];
+    const int r0 = lb * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+    for (int c = threadIdx.x; c < K; c += 256) {
+        float s = 0.f;
+        for (int i = r0; i < r1; ++i) s += w[(int64_t)i * K + c] * u[i];
+        atomicAdd(vraw + c, s);
+    }
+}
+__global__ __launch_bounds__(256) void spectral_B_batch_kernel(const SnBatch b, int iter, float eps) {
+    extern __shared__ float sm[];   // vs[Kmax], red[4]
+    int lb;
+    const int j = sn_job_of(b, blockIdx.x, lb);
+    const float* __restrict__ w = b.w[j];
+    const int Cout = b.Cout[j], K = b.K[j];
+    float* __restrict__ v = b.v[j];
+    const float* __restrict__ vraw = b.ws[j];
+    float* __restrict__ wv = b.ws[j] + K;
+    float* vsave = b.uvs[j] ? b.uvs[j] + Cout : nullptr;
+    float* vs = sm;
+    float* red = sm + K;
+    float nrm = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) { const float x = iter ? vraw[c] : v[c]; vs[c] = x; nrm += x * x; }
+    nrm = sqrtf(block_total256(nrm, red));
+    if (iter) {
+        const float d = fmaxf(nrm, eps);
+        for (int c = threadIdx.x; c < K; c += 256) vs[c] /= d;
+        __syncthreads();
+        if (lb == 0) for (int c = threadIdx.x; c < K; c += 256) v[c] = vs[c];
+    }
+    if (vsave && lb == 0) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < K; c += 256) vsave[c] = vs[c];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = lb * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+    for (int i = r0 + wave; i < r1; i += 4) {
+        float s = 0.f;
+        for (int c = lane; c < K; c += 64) s += w[(int64_t)i * K + c] * vs[c];
+        s = wave_sum(s);
+        if (lane == 0) wv[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void spectral_C_batch_kernel(const SnBatch b, int iter, float eps) {
+    __shared__ float red[4];
+    int lb;
+    const int j = sn_job_of(b, blockIdx.x, lb);
+    const int nblk = b.first[j + 1] - b.first[j];
+    const float* __restrict__ w = b.w[j];
+    const int Cout = b.Cout[j], K = b.K[j];
+    float* __restrict__ u = b.u[j];
+    const float* __restrict__ wv = b.ws[j] + K;
+    float* __restrict__ wsn = b.wsn[j];
+    float* usave = b.uvs[j];
+    float a = 0.f, bb = 0.f;     // |wv|^2 and u_old . wv
+    for (int i = threadIdx.x; i < Cout; i += 256) { const float x = wv[i]; a += x * x; bb += u[i] * x; }
+    a = block_total256(a, red);
+    bb = block_total256(bb, red);
+    float sg;
+    if (iter) {
+        const float d = fmaxf(sqrtf(a), eps);
+        sg = a / d;
+        // every block has read the old u above (and needs it for nothing else): block 0 may overwrite it only after the
+        // OTHER blocks of this layer have read it too -- they do not read it when iter != 0 beyond the sum above, whose value
+        // (bb) is unused in this branch, so the order does not matter
+        if (lb == 0) for (int i = threadIdx.x; i < Cout; i += 256) { const float un = wv[i] / d; u[i] = un; if (usave) usave[i] = un; }
+    } else {
+        sg = bb;
+        if (usave && lb == 0) for (int i = threadIdx.x; i < Cout; i += 256) usave[i] = u[i];
+    }
+    if (lb == 0 && threadIdx.x == 0) b.sigma[j][0] = sg;
+    const float inv = 1.f / sg;
+    const int64_t n = (int64_t)Cout * K;
+    for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) wsn[i] = w[i] * inv;
+}
+extern "C" int octa_spectral_norm_fwd_batch(const octa_sn_job* jobs, int n, int do_power_iter, float eps, int ws_prezeroed, octa_stream_t stream) {
+    OCTA_REQUIRE(jobs && n >= 1 && n <= SN_MAXJOBS, "octa_spectral_norm_fwd_batch: 1..%d jobs", SN_MAXJOBS);
+    hipStream_t st = (hipStream_t)stream;
+    SnBatch rb, cb;
+    rb.n = cb.n = n;
+    int rtot = 0, ctot = 0, kmax = 0;
+    for (int j = 0; j < n; ++j) {
+        const octa_sn_job& q = jobs[j];
+        OCTA_REQUIRE(q.w && q.u && q.v && q.sigma && q.w_sn && q.ws && q.Cout > 0 && q.K > 0, "octa_spectral_norm_fwd_batch: job %d: bad arguments (ws: K + Cout floats)", j);
+        rb.first[j] = rtot; cb.first[j] = ctot;
+        rtot += cdiv(q.Cout, SN_ROWS);
+        int nc = (int)cdiv64((int64_t)q.Cout * q.K, 256 * 8);
+        ctot += nc < 1 ? 1 : nc;
+        rb.w[j] = cb.w[j] = q.w; rb.u[j] = cb.u[j] = q.u; rb.v[j] = cb.v[j] = q.v; rb.sigma[j] = cb.sigma[j] = q.sigma;
+        rb.wsn[j] = cb.wsn[j] = q.w_sn; rb.ws[j] = cb.ws[j] = q.ws; rb.uvs[j] = cb.uvs[j] = q.uv_saved;
+        rb.Cout[j] = cb.Cout[j] = q.Cout; rb.K[j] = cb.K[j] = q.K;
+        if (q.K > kmax) kmax = q.K;
+        if (do_power_iter && !ws_prezeroed && octa_zero_async(q.ws, (size_t)q.K * sizeof(float), st) != hipSuccess)
+            OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd_batch: memset failed");
+    }
+    rb.first[n] = rtot; cb.first[n] = ctot;
+    if (do_power_iter) {
+        spectral_A_batch_kernel<<<rtot, 256, 0, st>>>(rb);
+        OCTA_CHECK_LAUNCH("spectral_A(batch)");
+    }
+    spectral_B_batch_kernel<<<rtot, 256, (size_t)(kmax + 4) * sizeof(float), st>>>(rb, do_power_iter, eps);
+    OCTA_CHECK_LAUNCH("spectral_B(batch)");
+    spectral_C_batch_kernel<<<ctot, 256, 0, st>>>(cb, do_power_iter, eps);
+    OCTA_CHECK_LAUNCH("spectral_C(batch)");
+    return OCTA_OK;
+}
+struct SnBwdBatch {
+    int n;
+    int first[SN_MAXJOBS + 1];
+    const float* dwsn[SN_MAXJOBS]; const float* wsn[SN_MAXJOBS]; const float* u[SN_MAXJOBS]; const float* v[SN_MAXJOBS];
+    const float* sigma[SN_MAXJOBS]; float* dw[SN_MAXJOBS]; float* dot[SN_MAXJOBS];
+    int K[SN_MAXJOBS], khw[SN_MAXJOBS], acc[SN_MAXJOBS];
+    int64_t nel[SN_MAXJOBS];
+};
+template <int PASS>
+__global__ __launch_bounds__(256) void spectral_bwd_batch_kernel(const SnBwdBatch b) {
+    __shared__ float red[4];
+    int lb = blockIdx.x, j = 0;
+#pragma unroll
+    for (int i = 1; i < SN_MAXJOBS; ++i) if (i < b.n && (int)blockIdx.x >= b.first[i]) j = i;
+    lb -= b.first[j];
+    const int nblk = b.first[j + 1] - b.first[j];
+    const float* __restrict__ dwsn = b.dwsn[j];
+    const int K = b.K[j], khw = b.khw[j];
+    const int64_t n = b.nel[j];
+    if (PASS == 0) {
+        const float* __restrict__ wsn = b.wsn[j];
+        float s = 0.f;
+        for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) s += dwsn[sn_src(i, K, khw)] * wsn[i];
+        s = block_total256(s, red);
+        if (threadIdx.x == 0) atomicAdd(b.dot[j], s);
+    } else {
+        const float* __restrict__ u = b.u[j];
+        const float* __restrict__ v = b.v[j];
+        float* __restrict__ dw = b.dw[j];
+        const float inv = 1.f / b.sigma[j][0], s = b.dot[j][0];
+        const int accumulate = b.acc[j];
+        for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+            const int r = (int)(i / K), c = (int)(i % K);
+            const float g = (dwsn[sn_src(i, K, khw)] - s * u[r] * v[c]) * inv;
+            dw[i] = accumulate ? dw[i] + g : g;
+        }
+    }
+}
+extern "C" int octa_spectral_norm_bwd_batch(const octa_sn_bwd_job* jobs, int n, int ws_prezeroed, octa_stream_t stream) {
+    OCTA_REQUIRE(jobs && n >= 1 && n <= SN_MAXJOBS, "octa_spectral_norm_bwd_batch: 1..%d jobs", SN_MAXJOBS);
+    hipStream_t st = (hipStream_t)stream;
+    SnBwdBatch b;
+    b.n = n;
+    int tot = 0;
+    for (int j = 0; j < n; ++j) {
+        const octa_sn_bwd_job& q = jobs[j];
+        OCTA_REQUIRE(q.dw_sn && q.w_sn && q.u && q.v && q.sigma && q.dw && q.ws && q.Cout > 0 && q.K > 0 && q.dwsn_khw >= 0 &&
+                         (q.dwsn_khw == 0 || q.K % q.dwsn_khw == 0),
+                     "octa_spectral_norm_bwd_batch: job %d: bad arguments (ws: 1 float; dwsn_khw divides K)", j);
+        b.first[j] = tot;
+        const int64_t nel = (int64_t)q.Cout * q.K;
+        int nb = (int)cdiv64(nel, 256 * 8);
+        tot += nb < 1 ? 1 : nb;
+        b.dwsn[j] = q.dw_sn; b.wsn[j] = q.w_sn; b.u[j] = q.u; b.v[j] = q.v; b.sigma[j] = q.sigma; b.dw[j] = q.dw; b.dot[j] = q.ws;
+        b.K[j] = q.K; b.khw[j] = q.dwsn_khw; b.acc[j] = q.accumulate; b.nel[j] = nel;
+        if (!ws_prezeroed && octa_zero_async(q.ws, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd_batch: memset failed");
+    }
+    b.first[n] = tot;
+    spectral_bwd_batch_kernel<0><<<tot, 256, 0, st>>>(b);
+    OCTA_CHECK_LAUNCH("spectral_bwd_dot(batch)");
+    spectral_bwd_batch_kernel<1><<<tot, 256, 0, st>>>(b);
+    OCTA_CHECK_LAUNCH("spectral_bwd_apply(batch)");
+    return OCTA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ full-extent conv = dot product
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int64_t n,

@@ -1640,6 +1640,100 @@ class SpectralNormFn(Function):
         return dw, None, None, None, None
 
 
+class SpectralNormBatchFn(Function):
+    """SpectralNormFn for several independent layers at once (the four spectral-norm convs of a discriminator call): three
+    launches forward and two backward for all of them instead of three / two per layer.  apply(training, eps, w0, u0, v0, w1, u1,
+    v1, ...) -> (w0 / sigma0, w1 / sigma1, ...)."""
+
+    @staticmethod
+    def forward(ctx, training, eps, *wuv):
+        from ._lib import SnJob
+        n = len(wuv) // 3
+        if n < 1 or n > 8 or len(wuv) != 3 * n:
+            raise OctaError("spectral_norm_batch: 1..8 (weight, u, v) triples")
+        ws_, keep, outs = [], [], []
+        jobs = (SnJob * n)()
+        dev = wuv[0].device
+        sizes = []
+        for i in range(n):
+            w, u, v = wuv[3 * i:3 * i + 3]
+            _require_gpu(w)
+            wd = w.detach().contiguous()
+            Cout = wd.shape[0]
+            K = wd.numel() // Cout
+            sizes.append((Cout, K))
+        tot = sum(K + Cout for Cout, K in sizes)
+        ws_all, pz = _zeroed_f32((tot,), dev)              # one zero-initialised slice for every layer's v accumulator
+        off = 0
+        for i in range(n):
+            w, u, v = wuv[3 * i:3 * i + 3]
+            Cout, K = sizes[i]
+            wd = w.detach().contiguous()
+            sigma = torch.empty((1,), dtype=torch.float32, device=dev)
+            wsn = torch.empty_like(wd)
+            uv = torch.empty((Cout + K,), dtype=torch.float32, device=dev)
+            ws = ws_all[off:off + K + Cout]
+            off += K + Cout
+            j = jobs[i]
+            j.w, j.u, j.v, j.sigma, j.w_sn, j.ws, j.uv_saved, j.Cout, j.K = _p(wd), _p(u), _p(v), _p(sigma), _p(wsn), _p(ws), _p(uv), Cout, K
+            keep.append((wd, sigma, uv))
+            outs.append(wsn)
+        if not pz:
+            ws_all.zero_()
+        lib().octa_spectral_norm_fwd_batch(jobs, n, int(training), eps, 1, _st())
+        ctx.n = n
+        ctx.w_refs = [wuv[3 * i] for i in range(n)]
+        ctx.sizes = sizes
+        ctx.save_for_backward(*[t for (wd, sigma, uv), wsn in zip(keep, outs) for t in (wsn, uv, sigma)])
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dwsns):
+        from ._lib import SnBwdJob
+        n = ctx.n
+        saved = ctx.saved_tensors
+        live = [i for i in range(n) if dwsns[i] is not None]
+        grads = [None] * n
+        if live:
+            jobs = (SnBwdJob * len(live))()
+            dots, pz = _zeroed_f32((len(live),), saved[0].device)
+            if not pz:
+                dots.zero_()
+            keep = []
+            for q, i in enumerate(live):
+                wsn, uv, sigma = saved[3 * i:3 * i + 3]
+                Cout, K = ctx.sizes[i]
+                dwsn = dwsns[i].float()
+                khw = 0
+                if not dwsn.is_contiguous():
+                    if dwsn.dim() == 4 and dwsn.is_contiguous(memory_format=torch.channels_last):
+                        khw = dwsn.shape[2] * dwsn.shape[3]
+                    else:
+                        dwsn = dwsn.contiguous()
+                sw = _sink(ctx.w_refs[i])
+                if sw is not None and sw.is_contiguous():
+                    dw, acc = sw, 1                      # gradient sink: += straight into weight_orig's pre-assigned gradient
+                else:
+                    dw, acc = torch.empty_like(wsn), 0
+                    grads[i] = dw
+                j = jobs[q]
+                j.dw_sn, j.w_sn, j.u, j.v, j.sigma, j.dw, j.ws = _p(dwsn), _p(wsn), _p(uv), _p(uv[Cout:]), _p(sigma), _p(dw), _p(dots[q:q + 1])
+                j.Cout, j.K, j.accumulate, j.dwsn_khw = Cout, K, acc, khw
+                keep.append((dwsn, dw))
+            lib().octa_spectral_norm_bwd_batch(jobs, len(live), 1, _st())
+        out = [None, None]
+        for i in range(n):
+            out += [grads[i], None, None]
+        return tuple(out)
+
+
+def spectral_norm_batch(triples, training: bool, eps: float):
+    """[(weight_orig, u, v), ...] -> [weight / sigma, ...] with one power iteration each in training (blocks.py:105-108)."""
+    flat = [t for tr in triples for t in tr]
+    return list(SpectralNormBatchFn.apply(training, eps, *flat))
+
+
 class FullConvFn(Function):
     """Conv2d whose kernel covers the whole map (blocks.py:68-72) = one dot product per sample."""
 
