@@ -118,7 +118,7 @@ int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed
  * weights): y is complete either way, stats untouched in the latter case and the caller runs the ordinary statistics pass. */
 int octa_conv2d_fwd_stats(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                           float* stats, const float* shift, int replicas, int* fused_host, octa_stream_t stream);
-/* Optional scratch for the 8-wave kernel's TAIL SPLIT (algo 2 / 3, groups == 1): a launch whose tile count leaves the last round of
+/* Optional scratch for the 8-wave kernel's TAIL SPLIT (algo 2 / 3): a launch whose tile count leaves the last round of
  * 256 CUs at most half full runs those last tiles as 2..8 workgroups each over disjoint input-channel ranges; the partial fp32
  * tiles go through `ws` (caller-owned, `bytes` long, 16-byte aligned; 64 MB covers every layer of the path) and a second small
  * launch finishes them.  Same results up to fp32 summation order.  The registration is process-wide and read when a conv is

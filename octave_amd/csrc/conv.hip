@@ -39,7 +39,7 @@ struct ConvArgs {
     // tail split-K of the 8-wave kernel (igemm8.hpp): tiles [0, sk_full) run whole, every later tile as sk_parts workgroups over
     // disjoint channel-slice ranges that store raw fp32 partial tiles to sk_ws; igemm8_splitk_fix finishes them.  sk_parts <= 1: off
     float* sk_ws;
-    int sk_full, sk_parts, sk_gy;
+    int sk_full, sk_parts, sk_gy, sk_tpg;
 };
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -950,7 +950,7 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = stats; a.stats_shift = shift; a.stats_rep = replicas; a.stats_ctot = d->Cout;
-    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0;
+    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
         a.NgSt = (a.Ng + 7) / 8 * 8;
@@ -986,7 +986,7 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = nullptr; a.stats_shift = nullptr; a.stats_rep = 0; a.stats_ctot = 0;
-    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0;
+    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
         a.NgSt = (a.Ng + 7) / 8 * 8;

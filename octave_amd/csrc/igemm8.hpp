@@ -59,9 +59,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int g = blockIdx.z;
+    int g = blockIdx.z;
     int mt, nt;
-    // tail split-K (8 waves, one group): a 1-D launch of sk_full whole tiles followed by sk_parts workgroups per remaining tile.
+    // tail split-K (8 waves): a 1-D launch of sk_full whole tiles followed by sk_parts workgroups per remaining tile (tiles are
+    // numbered group-major: sk_tpg tiles per group).
     // A launch of, say, 316 tiles on 256 CUs otherwise runs a second round that is 23 % full; here its 60 tiles become 240
     // workgroups of a quarter of the K range each.  part >= 0: this workgroup owns slices [s0, s1) and ends in a raw fp32 store.
     int part = -1, tail = 0;
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
         int Lp;
         if (b < a.sk_full) Lp = xcd_remap(b, a.sk_full);
         else { const int bb = b - a.sk_full; tail = bb / a.sk_parts; part = bb - tail * a.sk_parts; Lp = a.sk_full + tail; }
+        g = Lp / a.sk_tpg;
+        Lp -= g * a.sk_tpg;
         nt = Lp % a.sk_gy;
         mt = Lp / a.sk_gy;
     } else xcd_tile(gridDim.x, gridDim.y, mt, nt);
@@ -350,7 +353,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
 // One thread per (pixel row, 4 channels); blockIdx.x = tail tile, blockIdx.y = 16-row strip.
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm8_splitk_fix_kernel(const ConvArgs a) {
-    const int Lp = a.sk_full + blockIdx.x;
+    int Lp = a.sk_full + blockIdx.x;
+    const int g = Lp / a.sk_tpg;
+    Lp -= g * a.sk_tpg;
     const int nt = Lp % a.sk_gy, mt = Lp / a.sk_gy;
     const int m0 = mt * BM, n0 = nt * BN;
     constexpr int TPR = BN / 4;                            // threads per row
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void igemm8_splitk_fix_kernel(const ConvArgs a
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.bias)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = (nb + e < a.Ng) ? a.bias[nb + e] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[e] = (nb + e < a.Ng) ? a.bias[g * a.Ng + nb + e] : 0.f;
     const float* __restrict__ wsp = a.sk_ws + (size_t)blockIdx.x * a.sk_parts * (size_t)(BM * BN);
     T* __restrict__ yb = (T*)a.y + a.yoff;
     const T* __restrict__ ad = (const T*)a.addend;
@@ -378,9 +383,9 @@ __global__ __launch_bounds__(256) void igemm8_splitk_fix_kernel(const ConvArgs a
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             o[e] = act_apply(v[e] + bv[e], a.act);
-            if (ad && nb + e < a.Ng) o[e] += DT<T>::ld(ad + (size_t)m * a.ldadd + nb + e);
+            if (ad && nb + e < a.Ng) o[e] += DT<T>::ld(ad + (size_t)m * a.ldadd + g * a.Ng + nb + e);
         }
-        T* dst = yb + (size_t)m * a.ldy + nb;
+        T* dst = yb + (size_t)m * a.ldy + g * a.Ng + nb;
         if (a.vec_store && nb + 3 < a.Ng) *(uint2*)dst = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
         else {
 #pragma unroll
@@ -428,10 +433,11 @@ static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_
         const int BM = variant == 0 ? 256 : 128, BN = variant == 0 ? 128 : 256;
         dim3 grid(cdiv(a.M, BM), cdiv(a.Ng, BN), groups);
         ConvArgs b = a;
-        const int tiles = grid.x * grid.y;
-        const int parts = (groups == 1 && !a.upshuffle && !a.stats) ? splitk_parts(tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
+        const int tiles = grid.x * grid.y * groups;
+        // (grouped layers: NgSt == Ng, i.e. no pad channels to zero-fill between the groups)
+        const int parts = (!a.upshuffle && !a.stats && (groups == 1 || a.NgSt == a.Ng)) ? splitk_parts(tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
         if (parts > 1) {
-            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - tiles % 256; b.sk_gy = grid.y;
+            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - tiles % 256; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
             grid = dim3(b.sk_full + (tiles % 256) * parts, 1, 1);
         }
         if (variant == 0) {
