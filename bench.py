@@ -355,7 +355,7 @@ def main():
                        + f"batch {B}/GPU, {H}x{H}", "global_batch": world * B, "image": H, "parallelism": f"dp{world}",
                        "weights": "default init, torch.manual_seed(0)", "optimizer": "Adam (fused, flat arena)",
                        "data": "generated on the device (octa_synth_octa)", "grad_buckets": len(step.seg_arena.buckets),
-                       "launch": "eager" if args.no_graph else ("hipGraph replay (4 graphs around the 2 gradient all-reduces)" if step.launch == "graph"
+                       "launch": "eager" if args.no_graph else ("hipGraph replay (forward | backward pieces | discriminator step on a second stream | Adam, around the 2 gradient all-reduces)" if step.launch == "graph"
                                                                else "eager launches of the captured static step (auto-tuned: faster than graph replay on this host)")},
             "final_loss_seg": round(loss, 5),
         }
