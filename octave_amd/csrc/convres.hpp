@@ -18,7 +18,9 @@
 
 template <int NCH> __device__ __forceinline__ int res_swz(int p) { return NCH == 1 ? ((p >> 2) & 3) : (p & 7); }
 
-template <typename T, int TAPS, int NCH, int TN, int MODE>
+// NH: output-channel passes per tile.  TN = 16 n-tiles at once need 128 accumulator + 128 weight-fragment registers and spill; with
+// NH = 2 a tile is two passes of TN = 8 over the SAME resident patch (the 64 -> 256 pointwise / up-shuffle layers).
+template <typename T, int TAPS, int NCH, int TN, int MODE, int NH = 1>
 __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int ntiles, int tiles_x, int tiles_y, int exact) {
     constexpr int EPC = DT<T>::EPC;
     static_assert(EPC == 8, "16-bit element types only");
@@ -30,11 +32,11 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     constexpr int LP = (PROWS + RPI * 8 - 1) / (RPI * 8);   // DMA instructions per wave per patch
     constexpr int SROWS = LP * 8 * RPI;           // rows of one ring stage
     constexpr int NST = NCH == 1 ? (TAPS == 9 ? 3 : 4) : 2;
-    constexpr int BNR = TN * 16;
+    constexpr int BNR = TN * NH * 16;             // all output channels of the tile (every pass)
     constexpr int NSTEP = TAPS * NCH;
     constexpr int TM = 2;
     constexpr int NP = TN >= 2 ? TN / 2 : 1;      // 16-byte output stores per pixel row of a lane (fragment pairs)
-    constexpr int NS = TM * NP;                   // output store instructions per wave per full tile (exact mode)
+    constexpr int NS = TM * NP * NH;              // output store instructions per wave per full tile (exact mode)
     constexpr int WAIT_BASE = (NST - 2) * LP;     // the younger patches
     constexpr int WAIT_ST = WAIT_BASE + (NST - 1) * NS > 60 ? 60 : WAIT_BASE + (NST - 1) * NS;
     constexpr int W_INSTR = NSTEP * 4 * BNR / 64; // weight DMA instructions per workgroup
@@ -167,12 +169,28 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
         __builtin_amdgcn_s_barrier();
         if (!(dbg & 4)) issue_patch(tl + (NST - 1) * tstep, (it + NST - 1) % NST, it + NST - 1 < nmine);
 
+        const char* const pst = (const char*)sP + stage * SROWS * RB;
+        // tile geometry (once per tile; the passes below share it)
+        int b = 0, y0 = 0, x0 = 0;
+        bool full;
+        if (TAPS == 9) {
+            const int tx = tl % tiles_x;
+            const int tq = tl / tiles_x;
+            b = tq / tiles_y;
+            y0 = (tq - b * tiles_y) * 16;
+            x0 = tx * 16;
+            full = (y0 + 16 <= a.OH) & (x0 + 16 <= a.OW);
+        } else {
+            full = tl * 256 + 256 <= a.M;
+        }
+        hist = ((hist << 1) | (full ? 0 : 1)) & ((1 << NST) - 1);
+#pragma unroll
+      for (int nh = 0; nh < NH; ++nh) {
         f32x4_t acc[TN][TM];
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const char* const pst = (const char*)sP + stage * SROWS * RB;
         if (!(dbg & 2)) {
             // fragments of step s+1 are fetched before the MFMAs of step s (two register sets)
             uint4 xf[2][TM], wf[2][TN];
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
                 }
                 const uint4* pB = pB0 + step * 4 * BNR;
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wf[buf][i] = pB[i * 16];
+                for (int i = 0; i < TN; ++i) wf[buf][i] = pB[(nh * TN + i) * 16];
             };
             fetch(0, 0);
 #pragma unroll
@@ -205,24 +223,11 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
         if (DEFER && (dbg & 2) && have) RES_FLUSH_ALL()
 
         // epilogue: lane holds, per (i, j), 4 consecutive output channels of one pixel
-        int b = 0, y0 = 0, x0 = 0;
-        bool full;
-        if (TAPS == 9) {
-            const int tx = tl % tiles_x;
-            const int tq = tl / tiles_x;
-            b = tq / tiles_y;
-            y0 = (tq - b * tiles_y) * 16;
-            x0 = tx * 16;
-            full = (y0 + 16 <= a.OH) & (x0 + 16 <= a.OW);
-        } else {
-            full = tl * 256 + 256 <= a.M;
-        }
-        hist = ((hist << 1) | (full ? 0 : 1)) & ((1 << NST) - 1);
         if (dbg & 1) { if (acc[0][0][0] == 123.456f) yb[0] = T{}; continue; }
         // bias and activation over the whole accumulator tile first (one activation decision per tile, see act_tile)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const int nb = TN >= 2 ? (i >> 1) * 32 + q * 8 + (i & 1) * 4 : q * 4;
+            const int nb = (TN >= 2 ? (i >> 1) * 32 + q * 8 + (i & 1) * 4 : q * 4) + nh * TN * 16;
             const int bidx = (TAPS == 1 && a.upshuffle) ? nb % a.CoutT : nb;
             const float4 bv = *(const float4*)(sBias + bidx);
 #pragma unroll
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
                 constexpr int CW = TN >= 2 ? 8 : 4;             // channels per lane per store
-                const int nb = TN >= 2 ? ip * 32 + q * 8 : q * 4;
+                const int nb = (TN >= 2 ? ip * 32 + q * 8 : q * 4) + nh * TN * 16;
                 if (nb >= a.NgSt) continue;
                 int chan = nb;
                 if (TAPS == 1 && a.upshuffle) {
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
                 }
             }
         }
+      }     // nh
     }
     if constexpr (DEFER) {
         if (have) RES_FLUSH_ALL()
@@ -352,14 +358,14 @@ static inline int res_lds_bytes(int taps, int nch, int tn) {
     return taps * nch * 4 * tn * 16 * 16 + nst * srows * 64 * nch + tn * 16 * 4 + ((tn == 2 || tn == 4) ? 8 * 2 * 16 * (tn / 2) * 4 * 16 : 0);
 }
 
-template <typename T, int TAPS, int NCH, int TN, int MODE>
+template <typename T, int TAPS, int NCH, int TN, int MODE, int NH = 1>
 static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int exact, hipStream_t st) {
-    const int per_cu = res_lds_bytes(TAPS, NCH, TN) * 2 <= 160 * 1024 ? 2 : 1;
+    const int per_cu = res_lds_bytes(TAPS, NCH, TN * NH) * 2 <= 160 * 1024 ? 2 : 1;
     int grid = 256 * per_cu;
     if (const char* e = getenv("OCTA_CONVRES_GRID")) { const int g = atoi(e); if (g > 0) grid = g; }    // tests: many tiles per workgroup
     if (grid > ntiles) grid = ntiles;
     if (const char* e = getenv("OCTA_CONVRES_DBG")) exact |= atoi(e) << 8;
-    conv_res_kernel<T, TAPS, NCH, TN, MODE><<<grid, 512, 0, st>>>(a, ntiles, tx, ty, exact);
+    conv_res_kernel<T, TAPS, NCH, TN, MODE, NH><<<grid, 512, 0, st>>>(a, ntiles, tx, ty, exact);
 }
 
 // eligibility + launch.  Returns false when another kernel must run.
@@ -381,9 +387,9 @@ static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool force
             tn = need <= 32 ? 2 : 4;
             if (need > 64 || (nch == 2 && tn == 4)) return false;      // 72 KB of weights + two 48 KB patches do not fit
         } else {
-            tn = need <= 16 ? 1 : need <= 32 ? 2 : need <= 64 ? 4 : 16;
-            if (need > 256 || (nch == 1 && (tn == 1 || tn == 16))) return false;
-            if (tn == 16 && !forced) return false;      // 128 accumulator registers per lane: spills; only when asked for (autotune)
+            tn = need <= 16 ? 1 : need <= 32 ? 2 : need <= 64 ? 4 : need <= 128 ? 8 : 16;
+            if (need > 256 || (nch == 1 && (tn == 1 || tn >= 8))) return false;
+            if (tn >= 8 && !forced) return false;      // (two passes of 8 n-tiles, NH = 2) only when asked for: the autotuner decides
         }
         const int exact = a.vec16 && a.Ng == tn * 16 && a.NgSt == a.Ng;
         int ntiles, tx = 0, ty = 0;
@@ -403,7 +409,8 @@ static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool force
             if (tn == 1) launch_res_one<T, 1, 2, 1, 0>(a, ntiles, tx, ty, exact, st);
             else if (tn == 2) launch_res_one<T, 1, 2, 2, 0>(a, ntiles, tx, ty, exact, st);
             else if (tn == 4) launch_res_one<T, 1, 2, 4, 0>(a, ntiles, tx, ty, exact, st);
-            else launch_res_one<T, 1, 2, 16, 0>(a, ntiles, tx, ty, exact, st);
+            else if (tn == 8) launch_res_one<T, 1, 2, 8, 0>(a, ntiles, tx, ty, exact, st);
+            else launch_res_one<T, 1, 2, 8, 0, 2>(a, ntiles, tx, ty, exact, st);      // 16 n-tiles as two passes of 8 (no spills)
         } else {
             if (tn == 2) launch_res_one<T, 1, 1, 2, 0>(a, ntiles, tx, ty, exact, st);
             else launch_res_one<T, 1, 1, 4, 0>(a, ntiles, tx, ty, exact, st);

@@ -626,7 +626,9 @@ RES_CASES = [
     (2, 64, 100, 97, 32, 3, 1),
     (2, 32, 67, 300, 24, 3, 1),
     (2, 64, 150, 131, 13, 1, 0),
-    (2, 64, 130, 120, 256, 1, 0),
+    (2, 64, 130, 120, 256, 1, 0),      # 16 n-tiles: two passes of 8 over the resident patch
+    (2, 64, 110, 90, 128, 1, 0),       # 8 n-tiles, one pass
+    (2, 64, 75, 101, 200, 1, 0),       # two passes, ragged channel tail
     (3, 32, 140, 140, 64, 1, 0),
     (2, 64, 90, 200, 40, 1, 0),
 ]
