@@ -11,8 +11,10 @@ activations, synthetic OCTA-like data, default-initialised weights.  Weak scalin
 the same per-GPU batch; gradients are all-reduced over RCCL.
 
 One JSON line is printed by rank 0.  Extra objects: "roofline" (MFMA-bound conv engine kernel:
-algorithmic FLOPs / HIP-event time of its launches) and "cpu_baseline" (the CPU oracle's step on
-the host cores, a bounded sample).
+algorithmic FLOPs / HIP-event time of its launches), "cpu_baseline" (the CPU oracle's step on
+the host cores, a bounded sample), "sustained_ms_per_step" (>= 500 back-to-back steps), "dice_vs_ref"
+(eval-mode one-hot masks against the reference's own, tests/golden/round4.npz) and, with more than
+one rank, "dist" (ranks the RCCL communicator spans, per-bucket all-reduce times, exposed wait).
 """
 import argparse
 import math
@@ -172,13 +174,7 @@ def roofline_leg(step, batch, dtype_name):
     name, (f, t, n, byt, t_mfma, t_hbm) = max(agg.items(), key=lambda kv: kv[1][1])
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # their own runs, gfx950 correction applied by tools/pmc_traffic.py); null when the kernel was not profiled
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
-        if name in pm and batch[0].shape[0] == 16 and batch[0].shape[-1] == 400:
-            traffic = round(pm[name]["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
+    traffic, traffic_src = pmc_traffic(name, batch)
     per_kernel = {k: {"launches_per_step": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2),
                       "gbs": round(v[3] / v[1] / 1e9, 1), "bound": "mfma" if v[4] >= v[5] else "hbm",
                       "frac": round(max(v[4], v[5]) / v[1], 4)} for k, v in agg.items()}
@@ -189,12 +185,64 @@ def roofline_leg(step, batch, dtype_name):
     else:
         bound = {"bound": "hbm", "achieved": round(byt / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(byt / t / 1e9 / PEAK_HBM_GBS, 4)}
     return {
-        **bound, "kernel": name, "traffic": traffic, "mfma_frac": round(f / t / 1e12 / peak, 4), "hbm_frac": round(byt / t / 1e9 / PEAK_HBM_GBS, 4),
+        **bound, "kernel": name, "traffic": traffic, "traffic_source": traffic_src, "mfma_frac": round(f / t / 1e12 / peak, 4), "hbm_frac": round(byt / t / 1e9 / PEAK_HBM_GBS, 4),
         "launches_per_step": n, "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n, "bytes_per_launch_avg": byt / n,
         "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
                              "time_ms_per_step": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_f / 1e9, 1)},
         "per_kernel": per_kernel,
     }
+
+
+def dice_vs_ref_leg(dev, sizes=(400, 304)):
+    """BASELINE.json's metric ends "; Dice vs ref": ``ResnestUNet.predict(x, 'one-hot')`` (segmentor/compose.py:189-199) in eval
+    mode on the HIP path, on the INPUT of the reference fixture tests/golden/round4.npz (closed-form weights and image,
+    octave_amd/synth.py; B = 2), against the mask the reference itself produced there (oracle/gen_golden.py round4).  Dice
+    coefficient per class (segmentor/losses.py:70-74 without the 1 -), the minimum over samples and classes is the figure; plus
+    the number of pixels that differ and how many of those are decidable in float64 (must be 0)."""
+    import numpy as np
+    from architectures.models.octa import OctaScribbleNet
+    from octave_amd import functional as F_
+    from octave_amd.synth import fill_state_dict, hash_input
+    G = np.load(os.path.join(ROOT, "tests", "golden", "round4.npz"))
+    out = {}
+    for H in sizes:
+        B = int(G[f"eval{H}/shape"][0])
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), False, False)
+        fill_state_dict(net.state_dict())
+        net = net.to(dev).eval()
+        x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+        with torch.no_grad():
+            oh = net.segmentor.predict(x, "one-hot")[1]
+        n = B * H * H
+        want = np.unpackbits(G[f"eval{H}/onehot_cls1_bits"])[:n].reshape(B, H, H).astype(bool)
+        ok = np.unpackbits(G[f"eval{H}/decidable_bits"])[:n].reshape(B, H, H).astype(bool)
+        got = oh[:, 1].cpu().numpy().astype(bool)
+        ref = torch.from_numpy(np.stack([~want, want], 1).astype(np.float32)).to(dev)
+        got2 = oh.float()
+        inter = (got2 * ref).sum(dim=(2, 3))
+        dice_c = (2 * inter / (got2.sum(dim=(2, 3)) + ref.sum(dim=(2, 3)) + 1e-12)).cpu().numpy()      # [B, class]
+        out[str(H)] = {"dice_min_over_samples_and_classes": round(float(dice_c.min()), 6),
+                       "dice_all_pixels": round(float(F_.dice_coefficient(got2, ref).min()), 6),
+                       "pixels": n, "differ": int((got != want).sum()), "differ_decidable_in_f64": int((got != want)[ok].sum())}
+        del net
+    return {"value": min(v["dice_min_over_samples_and_classes"] for v in out.values()), "mode": "eval, predict('one-hot'), fp32, B=2",
+            "fixture": "tests/golden/round4.npz (reference masks, oracle/gen_golden.py round4)", "per_size": out}
+
+
+def pmc_traffic(name, batch):
+    """HBM bytes per launch of kernel `name` from the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    their own runs, gfx950 correction applied by tools/pmc_traffic.py), with the file and the commit it was measured at so
+    that the constant is traceable; (None, None) when the kernel was not profiled or the workload is not the profiled one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+            k = pm["kernels"]
+            if name in k and batch[0].shape[0] == 16 and batch[0].shape[-1] == 400:
+                return round(k[name]["hbm_bytes_per_launch"]), {"file": os.path.relpath(path, ROOT), "commit": pm.get("commit"), "measured": pm.get("date")}
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline_leg(net_state, seconds_budget=25.0):
@@ -250,6 +298,10 @@ def main():
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
                     help="after capture: replay the hipGraphs, launch the same static step from Python, or time both and pick (default)")
     ap.add_argument("--algo-cache", default=None, help="JSON file with measured per-shape conv kernel choices: loaded if present, written after warm-up")
+    ap.add_argument("--grad-comm", default="auto", choices=["auto", "f32", "bf16"],
+                    help="dtype of the gradient all-reduce: auto = bf16 when --gpus > 1 (143 MB instead of 286 MB per step over xGMI), f32 otherwise")
+    ap.add_argument("--sustained", type=int, default=500, help="replayed steps of the sustained-rate leg after the timed region (0: skip)")
+    ap.add_argument("--no-dice", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -294,7 +346,8 @@ def main():
     net_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
     cdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     ls = (1024.0 if args.dtype == "f16" else 1.0) if args.loss_scale is None else ("dynamic" if args.loss_scale == "dynamic" else float(args.loss_scale))
-    step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only, loss_scale=ls)
+    comm_dt = torch.bfloat16 if (args.grad_comm == "bf16" or (args.grad_comm == "auto" and world > 1)) else None
+    step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only, loss_scale=ls, grad_comm_dtype=comm_dt)
     x, ys, real = synth_batch(B, H, rank, dev)
     batch = (x, ys, mask_pyramid(real))
 
@@ -341,6 +394,27 @@ def main():
     if not all(math.isfinite(float(v.item())) for v in out.values()):
         sys.exit(f"bench.py: non-finite losses after the timed steps ({ {k: float(v.item()) for k, v in out.items()} }): the measurement is void")
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host enqueue {t_enq / args.steps * 1e3:.1f} ms/step)")
+    # sustained rate: >= 500 back-to-back steps on the launch path chosen above, nothing on the host inside the loop but the
+    # step call itself (no health checks, no .item()); same barriers and max over ranks as the headline
+    sustained = None
+    if args.sustained > 0:
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.sustained):
+            out = step(*batch)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        ds = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([ds], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ds = float(t.item())
+        sustained = (ds / args.sustained * 1e3, all(math.isfinite(float(v.item())) for v in out.values()))
+        log(f"sustained leg done: {sustained[0]:.2f} ms/step over {args.sustained} steps")
+    dist_diag = step.comm_diagnosis(*batch) if use_dist else None
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)
 
@@ -359,12 +433,23 @@ def main():
                                                                else "eager launches of the captured static step (auto-tuned: faster than graph replay on this host)")},
             "final_loss_seg": round(loss, 5),
         }
+        res["config"]["grad_comm_dtype"] = "bf16" if comm_dt is not None else "fp32"
+        if sustained is not None:
+            res["sustained_ms_per_step"] = round(sustained[0], 3)
+            res["sustained"] = {"steps": args.sustained, "images_per_sec": round(world * B / sustained[0] * 1e3, 2), "losses_finite": sustained[1],
+                                "launch": step.launch}
+        if dist_diag is not None:
+            res["dist"] = dist_diag
         if not args.no_roofline:
             res["roofline"] = roofline_leg(step, batch, args.dtype)
             log("roofline leg done")
         if net_state is not None:
             res["cpu_baseline"] = cpu_baseline_leg(net_state)
             log("cpu baseline leg done")
+        if not args.no_dice:
+            step.close()                  # leave the fused-training mode: the Dice leg is a plain eval-mode forward
+            res["dice_vs_ref"] = dice_vs_ref_leg(dev)
+            log("dice-vs-reference leg done")
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -496,7 +496,8 @@ __global__ void step_end_kernel(float* state, int nflags, float growth, float ba
     if (state) {
         bool found = false;
         for (int k = 0; k < nflags; ++k) { found |= state[2 + k] != 0.f; state[2 + k] = 0.f; }
-        if (found) { state[0] = fmaxf(state[0] * backoff, 1.f); state[1] = 0.f; }
+        if (growth == 1.f && backoff == 1.f) { state[1] = 0.f; }        // static scale: the value the caller set never moves (no clamps either)
+        else if (found) { state[0] = fmaxf(state[0] * backoff, 1.f); state[1] = 0.f; }
         else {
             const float t = state[1] + 1.f;
             if (t >= (float)interval) { state[0] = fminf(state[0] * growth, 16777216.f); state[1] = 0.f; }

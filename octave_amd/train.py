@@ -181,6 +181,19 @@ class FlatArena:
             for _, lo, hi in self.buckets:
                 self._reduce_range(lo, hi, comm_dtype)
 
+    def _timed_reduce(self, idx: int, lo: int, hi: int, comm_dtype):
+        """_reduce_range on the current (= comm) stream; with `self.diag` set (a list) the call is bracketed by two events:
+        (bucket, handed to RCCL, complete) -- the self-diagnosis of a multi-GPU run (bench.py "dist")."""
+        diag = getattr(self, "diag", None)
+        if diag is None or not self.g.is_cuda:
+            self._reduce_range(lo, hi, comm_dtype)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._reduce_range(lo, hi, comm_dtype)
+        e1.record()
+        diag.append((idx, e0, e1))
+
     def all_reduce_bucket_async(self, world: int, comm_stream, idx: int, comm_dtype=None):
         """Start the all-reduce of bucket `idx` on `comm_stream` once the gradients written so far on the current stream are
         complete; all_reduce_end() joins."""
@@ -192,7 +205,7 @@ class FlatArena:
             return
         comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(comm_stream):
-            self._reduce_range(lo, hi, comm_dtype)
+            self._timed_reduce(idx, lo, hi, comm_dtype)
 
     def all_reduce_begin(self, world: int, comm_stream, comm_dtype=None, skip: Sequence[int] = ()):
         """Start every bucket not yet started (in arena = completion order) on `comm_stream`; the caller overlaps independent
@@ -208,7 +221,7 @@ class FlatArena:
         with torch.cuda.stream(comm_stream):
             for i, (_, lo, hi) in enumerate(self.buckets):
                 if i not in skip:
-                    self._reduce_range(lo, hi, comm_dtype)
+                    self._timed_reduce(i, lo, hi, comm_dtype)
 
     def all_reduce_end(self, world: int, comm_stream):
         if _dist_on(world) and comm_stream is not None:
@@ -224,6 +237,8 @@ class FlatArena:
         device-side counter `step_dev`, so the launch is hipGraph-capturable as it stands.  `ls_state` (loss scaling): the arena
         is checked for inf / nan first and a flagged update is skipped.  commit=False: the caller ends the step itself with
         octa_step_end (TrainStep does: one launch for both optimisers, the loss scale and the step tick)."""
+        if commit and ls_state is not None:       # refuse BEFORE any launch: a late raise would leave moments updated and the counter not
+            raise ValueError("FlatArena.adam(ls_state=..., commit=True): the loss-scale state is updated by octa_step_end, pass commit=False")
         st = torch.cuda.current_stream().cuda_stream
         if ls_state is not None:
             # flag the arena (after the all-reduce: every rank sees the same infs) before the update
@@ -234,8 +249,6 @@ class FlatArena:
                                  betas[1], eps, weight_decay, 0, grad_scale, self.step_dev.data_ptr(),
                                  None if ls_state is None else ls_state.data_ptr(), ls_flag, st)
         if commit:
-            if ls_state is not None:
-                raise ValueError("FlatArena.adam(ls_state=..., commit=True): the loss-scale state is updated by octa_step_end, pass commit=False")
             lib().octa_step_end(None, 0, 1.0, 1.0, 1, self.step_dev.data_ptr(), None, None, None, st)
         # one launch refreshes every cached packed conv operand of THIS network; nothing else went stale, so the global
         # weight epoch is left alone (bumping it here made the other network's operands look stale: ~170 redundant
@@ -431,6 +444,10 @@ class TrainStep:
         self._started: List[int] = []
         self._tag_to_bucket = {tag: i for i, (tag, _, _) in enumerate(self.seg_arena.buckets)}
         self._disc_after = self._tag_to_bucket.get(self._disc_after_tag) if (self.concurrent_disc and self.adversarial) else None
+        if self.concurrent_disc and self.adversarial and self._disc_after is None and self._disc_after_tag not in ("", "forward", "fwd"):
+            import warnings
+            warnings.warn(f"TrainStep: OCTA_DISC_AFTER={self._disc_after_tag!r} names no gradient bucket (have {sorted(self._tag_to_bucket)}): "
+                          f"the discriminator's graph is launched right behind the forward graph")
         if self._disc_after is not None and self._disc_after >= len(self.seg_arena.buckets) - 1:
             self._disc_after = None           # the last bucket ends with the backward pass: nothing left to run beside
         self.launch = "graph"        # after capture(): "graph" replays the hipGraphs, "eager" launches the same step from Python
@@ -493,11 +510,24 @@ class TrainStep:
             self._started.append(i)
 
     def _phase_segmentor(self, x, ys, out, disc, hooks=False, between=None):
+        # the tail-split scratch and the zero slab are process-wide and read by every conv at launch time: registered for THIS
+        # phase only (withdrawn in the finally below), so that a conv launched on another stream between steps -- a validation
+        # forward, a second TrainStep -- never shares the partial-tile workspace
         F_.set_splitk_workspace(self._sk_ws)
+        try:
+            return self._phase_segmentor_body(x, ys, out, disc, hooks, between)
+        finally:
+            F_.set_splitk_workspace(None)
+
+    def _phase_segmentor_body(self, x, ys, out, disc, hooks, between):
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         self._started = []
-        att, agg, _ = self.seg(x)
+        try:
+            att, agg, _ = self.seg(x)
+        except BaseException:
+            F_.ZERO_SLAB.end()
+            raise
         l = F_.wpce_dice(agg, ys, from_logits=True)
         loss = l[0] + l[1] if self.use_dice else l[0]
         out["wpce"], out["dice"] = l[0].detach(), l[1].detach()
@@ -508,7 +538,10 @@ class TrainStep:
             # (zeroed before D's step, here and in the reference), so they are not computed at all
             for q in self.disc_arena.params:
                 q.requires_grad_(False)
+            # (this is also what makes the concurrent discriminator graph safe: with requires_grad off nothing in the segmentor's
+            # backward pass writes the discriminator's gradient arena, which that graph zeroes and fills on its own stream)
             g_adv = F_.lsgan_generator(disc(att))
+            assert not any(q.requires_grad for q in self.disc_arena.params)
             loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
             out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
         att_out = [a.detach() for a in att]
@@ -540,16 +573,19 @@ class TrainStep:
             # a zero slab of its own (spectral-norm workspaces, weight-gradient targets of the 15-channel convs): in replay mode this
             # phase runs on a second stream beside the segmentor's backward pass, whose slab is still in use
             seg_slab, F_.ZERO_SLAB = F_.ZERO_SLAB, self._disc_slab
-            F_.ZERO_SLAB.begin(self.disc_arena.g.device)
-            F_.set_splitk_workspace(None)          # (same reason: one scratch, two streams)
+            began = False
             try:
+                F_.ZERO_SLAB.begin(self.disc_arena.g.device)
+                began = True
+                F_.set_splitk_workspace(None)          # (same reason: one scratch, two streams)
                 d_real = disc(real_pyramid)
                 d_fake = disc(att)
                 l_d = F_.lsgan_discriminator(d_real, d_fake)
                 self._scaled(l_d).backward()
                 F_.flush_wgrads()
             finally:
-                F_.ZERO_SLAB.end()
+                if began:
+                    F_.ZERO_SLAB.end()
                 F_.ZERO_SLAB = seg_slab
             out["loss_disc"] = l_d.detach()
 
@@ -717,6 +753,13 @@ class TrainStep:
         pieces.append((state["g"], None))
         cur.wait_stream(side)
         cap.seg_graphs = pieces
+        if self._disc_after is not None and not any(b == self._disc_after for _, b in pieces):
+            # the stage mark behind which a replay starts the discriminator's graph on its own stream never fired during capture
+            # (a network without that stage): without this, _replay would silently fall back to a serial discriminator graph
+            import warnings
+            warnings.warn(f"TrainStep: the stage mark {self._disc_after_tag!r} (OCTA_DISC_AFTER) did not fire during capture; the discriminator's "
+                          f"graph is launched right behind the forward graph instead")
+            self._disc_after = None
         return pieces[0][0]
 
     @property
@@ -858,7 +901,14 @@ class TrainStep:
             # the discriminator's gradients follow the segmentor's on the comm stream and travel while the segmentor's Adam runs
             self.disc_arena.all_reduce_begin(self.world, comm, None)
         if seg_done is not None:
+            wd = getattr(self, "_wait_diag", None)
+            if wd is not None:                  # diagnosis: how long the main stream sits in front of Adam waiting for the last bucket
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record()
             torch.cuda.current_stream().wait_event(seg_done)
+            if wd is not None:
+                w1.record()
+                wd.append((w0, w1))
         g2b.replay()
         if self.adversarial:
             self.disc_arena.all_reduce_end(self.world, comm)
@@ -866,6 +916,45 @@ class TrainStep:
         F_.bump_weight_epoch()      # the weights moved behind the pack cache's back
         F_.bump_param_epoch()
         return cap.out
+
+    def comm_diagnosis(self, x, ys, real_pyramid=None, steps: int = 5) -> Dict:
+        """Self-diagnosis of the gradient exchange (run AFTER a timed region, it records events around every collective):
+        `steps` further steps with, per gradient bucket, the time from "handed to RCCL on the comm stream" to "complete", and the
+        time the main stream waits in front of the segmentor's Adam for the last bucket (the EXPOSED part of the exchange).
+        Also counts the ranks the communicator really spans (an all-reduce of ones).  Every rank must call it."""
+        if not _dist_on(self.world):
+            return {"world_size": self.world, "note": "single process: no collective is issued"}
+        dev = self.seg_arena.g.device
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        self.seg_arena.diag, self._wait_diag = [], []
+        if self.disc_arena is not None:
+            self.disc_arena.diag = []
+        try:
+            for _ in range(steps):
+                self(x, ys, real_pyramid)
+            torch.cuda.synchronize()
+            per = collections.defaultdict(list)
+            for idx, e0, e1 in self.seg_arena.diag:
+                per[idx].append(e0.elapsed_time(e1))
+            waits = [w0.elapsed_time(w1) for w0, w1 in self._wait_diag]
+            dsc = [e0.elapsed_time(e1) for _, e0, e1 in (self.disc_arena.diag if self.disc_arena is not None else [])]
+        finally:
+            self.seg_arena.diag = self._wait_diag = None
+            if self.disc_arena is not None:
+                self.disc_arena.diag = None
+        es = 4 if self.grad_comm_dtype in (None, torch.float32) else 2
+        med = lambda v: sorted(v)[len(v) // 2] if v else None     # noqa: E731
+        return {
+            "world_size": dist.get_world_size(), "ranks_in_communicator": int(round(float(ones.item()))), "backend": dist.get_backend(),
+            "grad_comm_dtype": "fp32" if es == 4 else str(self.grad_comm_dtype).replace("torch.", ""),
+            "launch": self.launch, "overlap_backward": bool(self.overlap_backward), "steps": steps,
+            "buckets": [{"tag": tag, "mbytes": round((hi - lo) * es / 1e6, 1), "rccl_ms_median": med(per.get(i, [])),
+                         "gbps_algorithmic": (round((hi - lo) * es / 1e6 / med(per[i]), 1) if per.get(i) and med(per[i]) > 0 else None)}
+                        for i, (tag, lo, hi) in enumerate(self.seg_arena.buckets)],
+            "discriminator_allreduce_ms_median": med(dsc),
+            "exposed_wait_before_adam_ms_median": med(waits),
+        }
 
     def close(self):
         """Leave the fused-training mode (per-parameter gradients, immediate BatchNorm counters)."""

@@ -488,9 +488,10 @@ def gen_unet304():
 
 
 
-def _adversarial_step_fixture(B, H, d, noise_seed=2024):
+def _adversarial_step_fixture(B, H, d, noise_seed=2024, logits=False):
     """One full adversarial step on the reference modules at (B, H): the four loss parts, both losses and every
-    gradient norm, in fp32 and (same modules, .double()) in float64."""
+    gradient norm, in fp32 and (same modules, .double()) in float64.  logits=True also stores the segmentor's logits (the
+    float64 twin rounded to float32: 2e-6 absolute, three orders below the reference's own fp32-vs-fp64 band)."""
     from architectures.models.octa import OctaScribbleNet
     from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
     x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
@@ -512,6 +513,8 @@ def _adversarial_step_fixture(B, H, d, noise_seed=2024):
         real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous().to(dt) for i in range(5)]
         torch.manual_seed(noise_seed)
         att, agg, _ = net.segmentor(xx)
+        if logits:
+            d["agg" + ("_f64_as_f32" if tag else "")] = _np(agg).astype(np.float32)
         p = F.softmax(agg, dim=1)
         parts = [net.supervised_loss(p, yy), DiceLoss()(p, yy), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
         l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
@@ -528,6 +531,50 @@ def _adversarial_step_fixture(B, H, d, noise_seed=2024):
         d["l_d" + tag] = _np(l_d)
         for k, pr in net.discriminator.named_parameters():
             d[f"disc_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+
+
+def gen_trainstep400():
+    """The HEADLINE resolution (BASELINE configs[2]: 400 x 400, H/16 = 25 odd -> pad / crop compose.py:122-130,142-147, 12 x 12
+    discriminator head blocks.py:68-72) end to end on the reference modules at B = 2 (fp32 + float64 twin): logits, loss parts,
+    both losses, every gradient norm and the consumed CPU random draws."""
+    d = {}
+    _adversarial_step_fixture(2, 400, d, logits=True)
+    _save("trainstep_400.npz", d)
+
+
+def gen_round4():
+    """Eval-mode inference of the reference at the two BASELINE resolutions (B = 2, 304 x 304 and 400 x 400, closed-form
+    weights): ``ResnestUNet.predict(x, 'one-hot')`` (compose.py:189-199) as a packed bit mask of class 1, plus the packed mask
+    of pixels whose float64 logit margin exceeds 1e-4 x the logit scale (where the argmax is decidable: the HIP path must be
+    bit-exact there).  Used by the ``dice_vs_ref`` figure of bench.py and by tests/test_round4.py."""
+    from architectures.models.octa import OctaScribbleNet
+    d = {}
+    for H in (304, 400):
+        B = 2
+        x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+        net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), False, False)
+        fill_state_dict(net.state_dict())
+        net.eval()
+        net64 = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), False, False)
+        fill_state_dict(net64.state_dict())
+        net64 = net64.double().eval()
+        with torch.no_grad():
+            onehot = net.segmentor.predict(x, "one-hot")[1]
+            agg = net.segmentor(x)[1]
+            agg64 = net64.segmentor(x.double())[1]
+        assert onehot.shape == (B, 2, H, H)
+        cls1 = _np(onehot[:, 1]).astype(np.uint8)
+        assert ((cls1 == 1) == (_np(onehot[:, 0]) == 0)).all()
+        scale = float(agg64.abs().max())
+        margin = (agg64[:, 1] - agg64[:, 0]).abs()
+        d[f"eval{H}/onehot_cls1_bits"] = np.packbits(cls1.reshape(-1))
+        d[f"eval{H}/decidable_bits"] = np.packbits((_np(margin) > 1e-4 * scale).astype(np.uint8).reshape(-1))
+        d[f"eval{H}/shape"] = np.array([B, H, H])
+        d[f"eval{H}/logit_scale"] = np.array([scale])
+        d[f"eval{H}/ref32_vs_ref64_maxabs"] = np.array([float((agg.double() - agg64).abs().max())])
+        d[f"eval{H}/agg_f64_sub8"] = _np(agg64[:, :, ::8, ::8]).astype(np.float32)
+        d[f"eval{H}/frac_cls1"] = np.array([float(cls1.mean())])
+    _save("round4.npz", d)
 
 
 def gen_trainstep304():
@@ -585,7 +632,8 @@ if __name__ == "__main__":
     _install_standins()
     torch.set_num_threads(8)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304", "trainstep304", "round3"]
+    which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304", "trainstep304", "round3",
+                             "trainstep400", "round4"]
     if "blocks" in which:
         gen_blocks()
     if "losses" in which:
@@ -604,3 +652,7 @@ if __name__ == "__main__":
         gen_trainstep304()
     if "round3" in which:
         gen_round3()
+    if "trainstep400" in which:
+        gen_trainstep400()
+    if "round4" in which:
+        gen_round4()

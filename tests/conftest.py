@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# Train-mode end-to-end band rule: |hip - ref64| <= BAND x |ref32 - ref64| + 1e-4 x scale.  The reference's own
+# fp32 result is one draw of the rounding noise 93 train-mode BatchNorms amplify; an independent fp32 implementation is another
+# draw.  Round 4 tightened the factor from 4 to 2.5 (measured ratios: profiles/r04_band_ratios.txt).
+BAND = float(os.environ.get("OCTA_BAND", "2.5"))
 
 
 def pytest_configure(config):

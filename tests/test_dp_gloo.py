@@ -210,6 +210,88 @@ def test_bucket_schedule_bf16_exchange_world2_gloo():
     assert err <= 2.0 ** -8 * scale and nstarted == 3, (err, scale, nstarted)
 
 
+def _worker_identical_after_update(rank, world, port, q):
+    """Two ranks that start from DIFFERENT parameters and see DIFFERENT shards: after the broadcast, the bucketed all-reduce and
+    one averaged Adam update the replicas hold bit-identical parameters, equal to a single process's update with the average of
+    both shards' gradients.  (The fused Adam launch is a HIP kernel; on the host the same update is torch.optim.Adam over the
+    arena's parameter views with grad_scale = 1 / world applied to the reduced arena, which is what octa_adam_step folds in.)"""
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    ok = False
+    try:
+        from octave_amd import train as T
+        P = _make_state()
+        named = [(k, p) for k, p in P.items() if isinstance(p, torch.nn.Parameter)]
+        half = (len(named) + 1) // 2
+        groups = [("decoder_4", [k for k, _ in named[:half]]), ("end", [k for k, _ in named[half:]])]
+        arena = T.FlatArena(named, groups, min_bucket=1)
+        start0 = arena.p.clone()
+        if rank == 1:
+            with torch.no_grad():
+                arena.p.mul_(1.5).add_(0.01)            # a replica built from another seed
+        arena.broadcast(0)
+        assert torch.equal(arena.p, start0) if rank == 0 else True
+        arena.zero_grad()
+        _local_grads(P, rank, reset=False)              # this rank's shard, gradients land in the arena views
+        mine = arena.g.clone()
+        arena.all_reduce_bucket_async(world, None, 0, None)
+        arena.all_reduce_begin(world, None, None, skip=[0])
+        arena.all_reduce_end(world, None)
+        with torch.no_grad():
+            arena.g.mul_(1.0 / world)                   # grad_scale of the fused Adam launch
+        opt = torch.optim.Adam([p for _, p in named], lr=1e-3)
+        opt.step()
+        chk = arena.p.clone()
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        same = torch.equal(chk, world * arena.p)        # both ranks hold the same bits (x2 is exact)
+        moved = (arena.p - start0).abs().max().item() if rank == 0 else 0.0
+        other = mine.clone()
+        dist.all_reduce(other, op=dist.ReduceOp.SUM)
+        differ = not torch.equal(other, world * mine)   # the shards really produced different local gradients
+        if rank == 0:
+            # single-process reference: the average of both shards' gradients, one Adam step from rank 0's parameters
+            P2 = _make_state()
+            named2 = [(k, p) for k, p in P2.items() if isinstance(p, torch.nn.Parameter)]
+            g = [_local_grads(P2, r) for r in range(world)]
+            for k, p in named2:
+                p.grad = sum(gr[k] for gr in g) / world
+            torch.optim.Adam([p for _, p in named2], lr=1e-3).step()
+            err = max((p.detach() - dict(named)[k].detach()).abs().max().item() for k, p in named2)
+            q.put(("ok", (same, differ, moved, err), 0, 0))
+        ok = True
+    except Exception:
+        import traceback
+        q.put(("fail", traceback.format_exc(), 0, 0))
+        raise
+    finally:
+        if ok:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_replicas_identical_after_broadcast_and_averaged_update_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_identical_after_update, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        status, res, _, _ = q.get(timeout=200)
+    finally:
+        for p in procs:
+            p.join(timeout=100)
+            if p.is_alive():
+                p.kill()
+    assert status == "ok", res
+    same, differ, moved, err = res
+    assert same and differ and moved > 1e-4 and err < 1e-6, res
+
+
 def test_bench_shards_data_by_rank():
     import importlib.util
     import sys

@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import BAND
+
 from oracle import ref_ops as R
 from oracle.fill import fill_state_dict, hash_input
 
@@ -230,16 +232,16 @@ def test_hip_parallel_head_unets(dev, golden):
         scale = float(np.abs(G[f"{tag}/agg"]).max())
         e64 = float(np.abs(agg.cpu().numpy().astype(np.float64) - G[f"{tag}/agg_f64"]).max())
         print(f"[{tag}] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} scale {scale:.2f}")
-        assert tuple(agg.shape) == tuple(G[f"{tag}/agg"].shape) and e64 <= 4 * noise + 1e-4 * scale
+        assert tuple(agg.shape) == tuple(G[f"{tag}/agg"].shape) and e64 <= BAND * noise + 1e-4 * scale
         if tag == "phag":
             (att, att_c) = out[0]
             assert [len(att), len(att_c)] == G["phag/n_att"].tolist()
             for i, a in enumerate(att):
                 n_i = float(np.abs(G[f"phag/att{i}"] - G[f"phag/att{i}_f64"]).max())
-                _close(f"phag att{i}", a, G[f"phag/att{i}_f64"], 4 * n_i + 1e-4)
+                _close(f"phag att{i}", a, G[f"phag/att{i}_f64"], BAND * n_i + 1e-4)
             for i, a in enumerate(att_c):
                 n_i = float(np.abs(G[f"phag/att_c{i}"] - G[f"phag/att_c{i}_f64"]).max())
-                _close(f"phag att_c{i}", a, G[f"phag/att_c{i}_f64"], 4 * n_i + 1e-4)
+                _close(f"phag att_c{i}", a, G[f"phag/att_c{i}_f64"], BAND * n_i + 1e-4)
             pred = m.predict(x, "one-hot")[1]
             assert pred.shape[0] == 2 and pred.shape[1] == B and pred.dtype == torch.int64
 
@@ -261,8 +263,8 @@ def test_hip_unet_304_vs_reference(dev, golden):
     noise = float(np.abs(ref32 - ref64).max())
     scale = float(np.abs(ref32).max())
     e64 = float(np.abs(agg.astype(np.float64) - ref64).max())
-    print(f"[unet 304] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} scale {scale:.1f}")
-    assert e64 <= 4 * noise + 1e-4 * scale, (e64, noise)
+    print(f"[unet 304] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} ratio {e64 / noise:.2f} scale {scale:.1f}")
+    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
     margin = np.abs(ref64[:, 0] - ref64[:, 1])
     safe = margin > 10 * noise
     assert np.array_equal(np.argmax(agg, 1)[safe], np.argmax(ref32, 1)[safe])

@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import BAND
+
 from oracle.fill import fill_state_dict, hash_input
 
 pytestmark = pytest.mark.gpu
@@ -419,7 +421,7 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     """End to end against the reference's CPU fp32 result.  93 train-mode BatchNorms (some over 3
     samples) amplify fp32 rounding noise: the reference's OWN fp32 output is max|ref32-ref64| away from
     its float64 evaluation (stored in the fixture).  The HIP fp32 path must (a) be as close to the
-    float64 reference as the fp32 reference itself is (factor 4), and (b) produce the same argmax mask
+    float64 reference as the fp32 reference itself is (factor BAND = 2.5, conftest.py), and (b) produce the same argmax mask
     wherever the decision margin exceeds that noise."""
     from architectures.segmentor.losses import DiceLoss
     G = golden(f"unet_{Hn}.npz")
@@ -431,12 +433,12 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     scale = float(np.abs(G["agg"]).max())
     e64 = float(np.abs(agg.detach().cpu().numpy().astype(np.float64) - G["agg_f64"]).max())
     e32 = float(np.abs(agg.detach().cpu().numpy() - G["agg"]).max())
-    print(f"[unet {Hn}] logits: |hip-ref64| {e64:.3e}  |ref32-ref64| {noise:.3e}  |hip-ref32| {e32:.3e}  scale {scale:.1f}")
-    assert e64 <= 4 * noise + 1e-4 * scale, (e64, noise)
-    assert e32 <= 5 * noise + 1e-4 * scale, (e32, noise)
+    print(f"[unet {Hn}] logits: |hip-ref64| {e64:.3e}  |ref32-ref64| {noise:.3e}  ratio {e64 / noise:.2f}  |hip-ref32| {e32:.3e}  scale {scale:.1f}")
+    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
+    assert e32 <= (BAND + 1) * noise + 1e-4 * scale, (e32, noise)
     for i, a in enumerate(att):
         n_i = float(np.abs(G[f"att{i}"] - G[f"att{i}_f64"]).max())
-        check(f"att{i}", a, G[f"att{i}_f64"], 0, 4 * n_i + 1e-4)
+        check(f"att{i}", a, G[f"att{i}_f64"], 0, BAND * n_i + 1e-4)
     want_arg = np.argmax(G["agg"], axis=1)
     got_arg = torch.argmax(agg, dim=1).cpu().numpy()
     margin = np.abs(G["agg"][:, 0] - G["agg"][:, 1])
@@ -453,7 +455,7 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     loss = net.supervised_loss(p, ys) + DiceLoss()(p, ys)
     loss.backward()
     l64, l32 = float(G["loss_f64"]), float(G["loss"])
-    assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l32, l64)
+    assert abs(loss.item() - l64) <= BAND * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l32, l64)
     params, bufs = dict(net.segmentor.named_parameters()), dict(net.segmentor.named_buffers())
     norms = {}
     for k, g in G.items():
@@ -479,8 +481,8 @@ def test_unet_vs_reference_golden_fp32(dev, golden, Hn):
     worst_ref = max(d[1] for d in devs.values())
     med_hip = float(np.median([d[0] for d in devs.values()]))
     med_ref = float(np.median([d[1] for d in devs.values()]))
-    assert worst_hip <= 4 * worst_ref + 2e-3, (worst_hip, worst_ref)
-    assert med_hip <= 4 * med_ref + 1e-3, (med_hip, med_ref)
+    assert worst_hip <= BAND * worst_ref + 2e-3, (worst_hip, worst_ref)
+    assert med_hip <= BAND * med_ref + 1e-3, (med_hip, med_ref)
     for k in G["nograd_keys"].tolist():
         assert params[k].grad is None, f"{k} must not receive a gradient"
     print(f"[unet {Hn}] grad norms vs float64 reference: worst/median deviation HIP {worst_hip:.2e}/{med_hip:.2e}, reference fp32 {worst_ref:.2e}/{med_ref:.2e}")

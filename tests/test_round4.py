@@ -1,0 +1,399 @@
+"""Round-4 reference pins (fixtures written by oracle/gen_golden.py {trainstep400, round4} from the reference itself):
+  * the full adversarial step at the HEADLINE resolution, B = 2, 400 x 400 (BASELINE configs[2] geometry: H/16 = 25 is odd ->
+    pad / crop of segmentor/compose.py:122-130,142-147; 12 x 12 discriminator head of discriminator/blocks.py:68-72), logits
+    included, fp32 + float64 twin;
+  * eval-mode ``predict('one-hot')`` at 304 x 304 and 400 x 400 (segmentor/compose.py:189-199) as packed bit masks -- the
+    ``dice_vs_ref`` figure of bench.py is the Dice coefficient of the HIP mask against these;
+  * fp16 (BASELINE configs[4]: "fp16 with fp32 loss accumulate") against the reference fixtures unet_64.npz / trainstep_48.npz, and
+    config 5 at its real size (B = 16, steps alternating 304 x 304 / 400 x 400, static and dynamic loss scale, eager and replay).
+CPU half: the oracle against the fixtures; GPU half: the HIP path under the float64-anchored noise-band rule."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import BAND
+from oracle import ref_ops as R
+from oracle.fill import fill_state_dict, hash_input
+
+
+def _step_inputs(Bn, H):
+    x = hash_input((Bn, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    u = hash_input((Bn, 1, H, H), 4321)
+    ys = torch.zeros(Bn, 2, H, H)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    real = F.one_hot((hash_input((Bn, H, H), 999) > 0.8).long(), 2).permute(0, 3, 1, 2).float()
+    return x, ys, real
+
+
+def _bits(G, key, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(G[key])[:n].reshape(shape).astype(bool)
+
+
+# ----------------------------------------------------------------------------------------- CPU: the oracle
+def test_oracle_trainstep_400(golden):
+    """The oracle's full adversarial step at 400 x 400 (B = 2) against the reference's: logits, losses, all gradient norms."""
+    from test_oracle import unet_state
+    G = golden("trainstep_400.npz")
+    Bn, H = 2, 400
+    P = unet_state(H, with_disc=True)
+    x, ys, real = _step_inputs(Bn, H)
+    noise = [torch.from_numpy(G[f"noise{c}"]) for c in range(3)]
+    flip = [bool(G[f"uniform{c}"][0] < 0.1) for c in range(3)]
+    with torch.no_grad():
+        agg = R.resnest_unet_forward(x, {k: v.detach() for k, v in P.items()})[1]
+    ref32, ref64 = G["agg"], G["agg_f64_as_f32"].astype(np.float64)
+    band = float(np.abs(ref32 - ref64).max())
+    # same op sequence as the reference (different thread partition of the sums at most): far inside the reference's own band
+    assert float(np.abs(agg.numpy() - ref32).max()) <= 0.05 * band + 1e-4 * float(np.abs(ref32).max())
+    l_seg, att, _ = R.segmentor_loss(P, x, ys, noise=noise[0], flip=flip[0])
+    l_seg.backward()
+    lb = abs(float(G["l_seg"]) - float(G["l_seg_f64"]))
+    assert abs(l_seg.item() - float(G["l_seg"])) <= 0.05 * lb + 1e-4 * abs(float(G["l_seg"])), (l_seg.item(), float(G["l_seg"]), lb)
+    dev = []
+    for k, g in G.items():
+        if k.startswith("seg_gradnorm/") and float(g) > 1e-9:
+            gn = P["segmentor." + k[13:]].grad.double().norm().item()
+            dev.append(abs(gn - float(g)) / float(g))
+    assert np.median(dev) <= 2e-3 and np.max(dev) <= 5e-2, (np.median(dev), np.max(dev))
+    for p in P.values():
+        p.grad = None
+    l_d = R.discriminator_loss(P, R.mask_pyramid(real), att, noise[1], flip[1], noise[2], flip[2])
+    l_d.backward()
+    assert abs(l_d.item() - float(G["l_d"])) <= 1e-3 * abs(float(G["l_d"])) + 1e-6
+    for k, g in G.items():
+        if k.startswith("disc_gradnorm/"):
+            gn = P["discriminator." + k[14:]].grad.double().norm().item()
+            assert abs(gn - float(g)) <= 5e-3 * float(g) + 1e-8, (k, gn, float(g))
+
+
+@pytest.mark.parametrize("H", [304, 400])
+def test_oracle_eval_onehot_at_baseline_resolutions(golden, H):
+    """Eval-mode forward + predict('one-hot') of the oracle against the reference's packed masks: bit-exact on every pixel whose
+    float64 margin is decidable (> 1e-4 x logit scale); the sub-sampled float64 logits within 1e-4 of the logit scale."""
+    from test_extras import _eval_state
+    G = golden("round4.npz")
+    B = 2
+    assert G[f"eval{H}/shape"].tolist() == [B, H, H]
+    net = _eval_state(H)
+    P = {k: v.clone() for k, v in net.state_dict().items()}
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        agg = R.resnest_unet_forward(x, P, training=False)[1]
+        oh = R.predict(agg, "one-hot").numpy()
+    want = _bits(G, f"eval{H}/onehot_cls1_bits", (B, H, H))
+    ok = _bits(G, f"eval{H}/decidable_bits", (B, H, H))
+    assert ok.mean() > 0.999
+    assert np.array_equal(oh[:, 1].astype(bool)[ok], want[ok])
+    scale = float(G[f"eval{H}/logit_scale"][0])
+    assert float(np.abs(agg[:, :, ::8, ::8].numpy() - G[f"eval{H}/agg_f64_sub8"]).max()) <= 1e-4 * scale
+
+
+# ----------------------------------------------------------------------------------------- GPU: HIP path
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the MI355X (run with -m gpu on the GPU box)")
+    return torch.device("cuda:0")
+
+
+def _norm_band(tag, got, G, pre32, pre64, floor, band=BAND):
+    dh, dr = [], []
+    top = max(float(g) for k, g in G.items() if k.startswith(pre64))
+    for k, g64 in G.items():
+        if k.startswith(pre64) and float(g64) > 1e-6 * top and k[len(pre64):] in got:
+            name = k[len(pre64):]
+            dh.append(abs(got[name] - float(g64)) / float(g64))
+            dr.append(abs(float(G[pre32 + name]) - float(g64)) / float(g64))
+    assert len(dh) >= 10, (tag, len(dh))
+    p95h, p95r = np.percentile(dh, 95), np.percentile(dr, 95)
+    print(f"[{tag}] grad-norm deviation from ref64: HIP median {np.median(dh):.2e} p95 {p95h:.2e} max {np.max(dh):.2e}; "
+          f"ref32 median {np.median(dr):.2e} p95 {p95r:.2e} max {np.max(dr):.2e}")
+    assert np.median(dh) <= band * np.median(dr) + floor and p95h <= band * p95r + 2 * floor and np.max(dh) <= 2 * band * np.max(dr) + 2 * floor, \
+        (tag, np.median(dh), p95h, np.max(dh), np.median(dr), p95r, np.max(dr))
+
+
+@pytest.mark.gpu
+def test_hip_adversarial_step_400_vs_reference(dev, golden):
+    """The headline resolution end to end on the HIP path (fp32): B = 2, 400 x 400, logits + four losses + every gradient norm +
+    the discriminator step against the reference's step, with the reference's CPU random draws replayed through the global
+    generator.  Train-mode band rule: |hip - ref64| <= BAND x |ref32 - ref64| + 1e-4 x scale."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
+    from octave_amd.train import mask_pyramid
+    G = golden("trainstep_400.npz")
+    Bn, H = 2, 400
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    assert tuple(net.discriminator.out[0].weight.shape[-2:]) == (12, 12)      # blocks.py:68-72 at 400 x 400
+    x, ys, real = (t.to(dev) for t in _step_inputs(Bn, H))
+    torch.manual_seed(2024)
+    att, agg, x4 = net.segmentor(x)
+    assert tuple(x4.shape) == (Bn, 2048, 13, 13) and [a.shape[-1] for a in att] == [400, 200, 100, 50, 25]
+    ref32, ref64 = G["agg"], G["agg_f64_as_f32"].astype(np.float64)
+    noise = float(np.abs(ref32 - ref64).max())
+    scale = float(np.abs(ref32).max())
+    got = agg.detach().cpu().numpy()
+    e64 = float(np.abs(got.astype(np.float64) - ref64).max())
+    print(f"[trainstep 400] logits |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} ratio {e64 / noise:.2f} scale {scale:.1f}")
+    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
+    margin = np.abs(ref64[:, 0] - ref64[:, 1])
+    safe = margin > 10 * noise
+    assert safe.mean() > 0.5 and np.array_equal(np.argmax(got, 1)[safe], np.argmax(ref32, 1)[safe])
+    p = torch.softmax(agg, dim=1)
+    parts = [net.supervised_loss(p, ys), DiceLoss()(p, ys), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
+    l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
+    net.zero_grad()
+    l_seg.backward()
+    p32, p64 = G["parts"], G["parts_f64"]
+    for i, name in enumerate(("wpce", "dice", "kl", "g_adv")):
+        print(f"[trainstep 400] {name}: hip {parts[i].item():.6f} ref32 {p32[i]:.6f} ref64 {p64[i]:.6f}")
+        assert abs(parts[i].item() - p64[i]) <= BAND * abs(p32[i] - p64[i]) + 2e-4 * abs(p64[i]) + 1e-6, (name, parts[i].item(), p32[i], p64[i])
+    l32, l64 = float(G["l_seg"]), float(G["l_seg_f64"])
+    assert abs(l_seg.item() - l64) <= BAND * abs(l32 - l64) + 1e-4 * abs(l64), (l_seg.item(), l32, l64)
+    gn = {k: q.grad.double().norm().item() for k, q in net.segmentor.named_parameters() if q.grad is not None}
+    _norm_band("trainstep 400 seg", gn, G, "seg_gradnorm/", "seg_gradnorm_f64/", floor=1e-3)
+    net.zero_grad()
+    l_d = net.discriminatorial_loss(net.discriminator(mask_pyramid(real)), net.discriminator([a.detach() for a in att]))
+    l_d.backward()
+    d32, d64 = float(G["l_d"]), float(G["l_d_f64"])
+    assert abs(l_d.item() - d64) <= BAND * abs(d32 - d64) + 2e-4 * abs(d64), (l_d.item(), d32, d64)
+    gnd = {k: q.grad.double().norm().item() for k, q in net.discriminator.named_parameters()}
+    _norm_band("trainstep 400 disc", gnd, G, "disc_gradnorm/", "disc_gradnorm_f64/", floor=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [304, 400])
+def test_hip_eval_onehot_at_baseline_resolutions(dev, golden, H):
+    """predict('one-hot') in eval mode (folded BatchNorm) at both BASELINE resolutions against the reference's mask: bit-exact on
+    every decidable pixel, Dice (both classes) = 1 up to the undecidable band, float64 logits within 1e-4 of the logit scale."""
+    from octave_amd import functional as F_
+    from test_extras import _eval_state
+    G = golden("round4.npz")
+    B = 2
+    net = _eval_state(H).to(dev).eval()
+    x = hash_input((B, 1, H, H), 1234).repeat(1, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        agg = net.segmentor(x)[1]
+        oh = net.segmentor.predict(x, "one-hot")[1]
+    want = _bits(G, f"eval{H}/onehot_cls1_bits", (B, H, H))
+    ok = _bits(G, f"eval{H}/decidable_bits", (B, H, H))
+    got = oh[:, 1].cpu().numpy().astype(bool)
+    nbad = int((got != want).sum())
+    assert np.array_equal(got[ok], want[ok]), f"{int((got != want)[ok].sum())} decidable pixels differ"
+    scale = float(G[f"eval{H}/logit_scale"][0])
+    e = float(np.abs(agg[:, :, ::8, ::8].cpu().numpy().astype(np.float64) - G[f"eval{H}/agg_f64_sub8"]).max())
+    assert e <= 1e-4 * scale, (e, scale)
+    ref = torch.from_numpy(np.stack([~want, want], 1).astype(np.float32)).to(dev)
+    dice = F_.dice_coefficient(oh.float(), ref)
+    print(f"[eval {H}] one-hot vs reference: {nbad} of {got.size} pixels differ (all undecidable), Dice per sample {dice.tolist()}, |hip-ref64| {e:.2e} (scale {scale:.2f})")
+    assert float(dice.min()) >= 1 - 1e-4
+
+
+@pytest.mark.gpu
+def test_unet_fp16_vs_reference(dev, golden):
+    """fp16 activations (BASELINE configs[4]) against the reference's 64 x 64 fixture: finite, logits within the fp16 rounding
+    budget of the fp32 reference, the same argmax on all but low-margin pixels, the WPCE + Dice loss (accumulated in fp32) within
+    2 % of the reference's, finite gradients.  The reference's own epsilons (1e-12, segmentor/losses.py:38,52) underflow in
+    fp16 -- which is why the loss kernels never run in fp16: they take the fp32 class maps."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss
+    G = golden("unet_64.npz")
+    Bn, Hn = 3, 64
+    net = OctaScribbleNet(torch.Size((Bn, 3, Hn, Hn)), torch.Size((Bn, 2, Hn, Hn)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    net.segmentor.compute_dtype = torch.float16
+    x = hash_input((Bn, 1, Hn, Hn), 1234).repeat(1, 3, 1, 1).to(dev)
+    att, agg, x4 = net.segmentor(x)
+    assert agg.dtype == torch.float32 and torch.isfinite(agg).all() and all(torch.isfinite(a).all() for a in att)
+    ref = G["agg"]
+    err = agg.detach().cpu().numpy() - ref
+    rms, ref_rms = float(np.sqrt((err ** 2).mean())), float(np.sqrt((ref ** 2).mean()))
+    print(f"[fp16 unet 64] logits max abs err {np.abs(err).max():.3e}, rms {rms:.3e}, ref rms {ref_rms:.3e}")
+    assert rms <= 0.03 * ref_rms          # bf16 sits at ~0.1 of the reference's rms here; fp16 has 3 more mantissa bits
+    margin = np.abs(ref[:, 0] - ref[:, 1])
+    big = margin > 0.1 * np.abs(ref).max()
+    assert (torch.argmax(agg, 1).cpu().numpy()[big] == np.argmax(ref, 1)[big]).mean() > 0.995
+    u = hash_input((Bn, 1, Hn, Hn), 4321)
+    ys = torch.zeros(Bn, 2, Hn, Hn)
+    ys[:, 1:2] = (u < 0.05).float()
+    ys[:, 0:1] = ((u > 0.5) & (u < 0.55)).float()
+    ys = ys.to(dev)
+    p = torch.softmax(agg, 1)
+    loss = net.supervised_loss(p, ys) + DiceLoss()(p, ys)
+    assert loss.dtype == torch.float32
+    l32 = float(G["loss"])
+    print(f"[fp16 unet 64] loss {loss.item():.6f} vs reference fp32 {l32:.6f}")
+    assert abs(loss.item() - l32) <= 0.02 * abs(l32)
+    (loss * 64.0).backward()
+    for k, q in net.segmentor.named_parameters():
+        if q.grad is not None:
+            assert torch.isfinite(q.grad).all(), k
+    # well-conditioned gradients (next to the output) against the reference's, after un-scaling
+    for k in ("fc.weight", "fc.bias", "aag_0.conv1.weight", "decoder_0.conv.0.weight"):
+        w = G[f"grad/{k}"]
+        g = dict(net.segmentor.named_parameters())[k].grad.cpu().numpy() / 64.0
+        rel = float(np.linalg.norm(g - w) / np.linalg.norm(w))
+        print(f"[fp16 unet 64] grad {k}: relative L2 error vs reference {rel:.3e}")
+        assert rel <= 0.05, (k, rel)
+
+
+@pytest.mark.gpu
+def test_adversarial_step_fp16_vs_reference_48(dev, golden):
+    """The 48 x 48 adversarial step of trainstep_48.npz with fp16 activations: the four loss parts (accumulated in fp32 from the
+    fp32 class maps) and both losses within the fp16 budget of the reference's values, every gradient finite, the gradient
+    norms of the decoder-side parameters within 10 % of the reference's float64 norms."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
+    from octave_amd.train import mask_pyramid
+    G = golden("trainstep_48.npz")
+    Bn, H = 6, 48
+    net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+    fill_state_dict(net.state_dict())
+    net = net.to(dev).train()
+    net.segmentor.compute_dtype = torch.float16
+    net.discriminator.compute_dtype = torch.float16
+    x, ys, real = (t.to(dev) for t in _step_inputs(Bn, H))
+    torch.manual_seed(2024)
+    att, agg, _ = net.segmentor(x)
+    p = torch.softmax(agg, dim=1)
+    parts = [net.supervised_loss(p, ys), DiceLoss()(p, ys), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
+    assert all(v.dtype == torch.float32 for v in parts)
+    l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
+    p64 = G["parts_f64"]
+    for i, (name, tol) in enumerate((("wpce", 0.02), ("dice", 0.02), ("kl", 0.03), ("g_adv", 0.05))):
+        print(f"[fp16 trainstep 48] {name}: hip {parts[i].item():.6f} ref64 {p64[i]:.6f}")
+        assert np.isfinite(parts[i].item()) and abs(parts[i].item() - p64[i]) <= tol * abs(p64[i]) + 1e-4, (name, parts[i].item(), p64[i])
+    net.zero_grad()
+    (l_seg * 8.0).backward()
+    n_dec = 0
+    for k, q in net.segmentor.named_parameters():
+        if q.grad is None:
+            continue
+        assert torch.isfinite(q.grad).all(), k
+        g64 = float(G[f"seg_gradnorm_f64/{k}"])
+        if k.split(".")[0] in ("fc", "aag_0", "decoder_0", "upsampling_0", "aag_1") and g64 > 1e-6:
+            gn = q.grad.double().norm().item() / 8.0
+            assert abs(gn - g64) <= 0.10 * g64, (k, gn, g64)
+            n_dec += 1
+    assert n_dec >= 10
+    net.zero_grad()
+    l_d = net.discriminatorial_loss(net.discriminator(mask_pyramid(real)), net.discriminator([a.detach() for a in att]))
+    l_d.backward()
+    d64 = float(G["l_d_f64"])
+    print(f"[fp16 trainstep 48] l_d hip {l_d.item():.5f} ref64 {d64:.5f}")
+    assert abs(l_d.item() - d64) <= 0.05 * abs(d64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1024.0, "dynamic"])
+def test_train_step_fp16_mixed_resolution_config5_full_size(dev, scale):
+    """BASELINE configs[4] at its real per-GPU size: B = 16, steps alternating 304 x 304 and 400 x 400, fp16 activations with the
+    losses accumulated in fp32, static (1024) and dynamic loss scale, launched eagerly AND replayed from hipGraphs captured per
+    resolution.  Checks: finite losses; per gradient bucket |g_fp16| / |g_fp32| in [0.9, 1.1] against the HIP fp32 step on the same
+    weights and inputs; only the discriminator head of the step's resolution moves (blocks.py:68-72: 9 x 9 vs 12 x 12 head)."""
+    from architectures.discriminator.blocks import DiscriminatorBlock
+    from octave_amd import functional as F_
+    from octave_amd.train import TrainStep, mask_pyramid
+    from test_train_step import _net
+    B, Ha, Hb = 16, 304, 400
+    batches = {}
+    for H in (Ha, Hb):
+        x, ys, real = F_.synth_octa_batch(B, H, H, seed=70 + H, device=dev, vessel=True)
+        batches[H] = (x, ys, mask_pyramid(real))
+
+    def build():
+        torch.manual_seed(0)
+        net = _net(B, Ha, dev, seed_fill=False)
+        d_b = DiscriminatorBlock(torch.Size((B, 2, Hb, Hb)), is_training=True, depth=4, num_filters=64).to(dev).train().share_body_with(net.discriminator)
+        for d in (net.discriminator, d_b):
+            if d._has_noise:
+                d.stack_0[0].is_training = False            # same (absent) instance noise in the fp32 and fp16 runs
+        return net, d_b
+    # fp32 gradients per resolution (lr = 0: the weights stay put, the arenas keep the step's gradients)
+    ref = {}
+    net, d_b = build()
+    st = TrainStep(net, lr=0.0, compute_dtype=torch.float32, extra_discriminators={Hb: d_b})
+    try:
+        for H in (Ha, Hb):
+            torch.manual_seed(3)
+            o = st(*batches[H])
+            torch.cuda.synchronize()
+            ref[H] = ({k: float(v) for k, v in o.items()}, st.seg_arena.g.double().clone(), st.disc_arena.g.double().clone(), list(st.seg_arena.buckets))
+    finally:
+        st.close()
+    del net, d_b, st
+    torch.cuda.empty_cache()
+    net, d_b = build()
+    assert net.discriminator.out[0].weight.shape[-1] == 9 and d_b.out[0].weight.shape[-1] == 12
+    st = TrainStep(net, lr=0.0, compute_dtype=torch.float16, loss_scale=scale, extra_discriminators={Hb: d_b})
+    try:
+        for H in (Ha, Hb):
+            for attempt in range(8):                        # a dynamic scale starts at 65536 and may back off first
+                torch.manual_seed(3)
+                s, n0 = float(st.ls_state[0]), int(st.seg_arena.step_count)
+                o = {k: float(v) for k, v in st(*batches[H]).items()}
+                torch.cuda.synchronize()
+                if int(st.seg_arena.step_count) == n0 + 1:
+                    break
+                assert scale == "dynamic", f"the static scale {scale} overflowed at {H} x {H}"
+            else:
+                raise AssertionError("the dynamic loss scale never reached a clean step")
+            assert all(np.isfinite(v) for v in o.values()), (H, o)
+            o32, g32, d32, bk = ref[H]
+            for k in o32:
+                assert abs(o[k] - o32[k]) <= 0.02 * abs(o32[k]) + 2e-3, (H, k, o32[k], o[k])
+            g16, d16 = st.seg_arena.g.double() / s, st.disc_arena.g.double() / s
+            rows = [(tag, (g16[lo:hi].norm() / g32[lo:hi].norm()).item()) for tag, lo, hi in bk]
+            rng = st._disc_ranges[id(st._pick_disc(batches[H][0]))]
+            dn16 = sum(d16[lo:hi].norm().item() ** 2 for lo, hi in rng) ** 0.5
+            dn32 = sum(d32[lo:hi].norm().item() ** 2 for lo, hi in rng) ** 0.5
+            rows.append(("discriminator", dn16 / dn32))
+            print(f"[config5 {H} scale {scale}] loss scale {s:g}; |g_fp16|/|g_fp32| per bucket: " + "; ".join(f"{t}: {r:.4f}" for t, r in rows))
+            for tag, r in rows:
+                assert 0.9 <= r <= 1.1, (H, tag, r)
+    finally:
+        st.close()
+    del st
+    torch.cuda.empty_cache()
+    # training steps (lr > 0): only the head of the step's resolution moves; eager, then captured per resolution and replayed
+    st = TrainStep(net, lr=1e-4, compute_dtype=torch.float16, loss_scale=scale, extra_discriminators={Hb: d_b})
+    try:
+        head = {Ha: net.discriminator.out[0].weight, Hb: d_b.out[0].weight}
+        body = net.discriminator.squeeze_dict["squeeze_0"][0].weight
+
+        def one(H):
+            other = Hb if H == Ha else Ha
+            h0, o0, b0 = head[H].detach().clone(), head[other].detach().clone(), body.detach().clone()
+            skipped0 = int(st.disc_arena.step_count)
+            out = {k: float(v) for k, v in st(*batches[H]).items()}
+            torch.cuda.synchronize()
+            assert all(np.isfinite(v) for v in out.values()), (H, out)
+            assert torch.equal(head[other], o0), f"the {other} x {other} head moved in a {H} x {H} step"
+            if int(st.disc_arena.step_count) > skipped0:             # (a dynamic scale may skip its first updates)
+                assert not torch.equal(head[H], h0) and not torch.equal(body, b0)
+            return out
+        for H in (Ha, Hb, Ha, Hb):
+            one(H)
+        if scale == "dynamic":
+            for _ in range(12):                                     # let the scale settle below the overflow threshold
+                one(Ha); one(Hb)
+        for H in (Ha, Hb):
+            st.capture(*batches[H])
+        assert sorted(st._caps) == [Ha, Hb]
+        st.launch = "graph"
+        n0 = int(st.seg_arena.step_count)
+        for H in (Ha, Hb, Ha, Hb):
+            one(H)
+        assert int(st.seg_arena.step_count) == n0 + 4, "a replayed fp16 step was skipped for a non-finite gradient"
+        for k, q in net.segmentor.named_parameters():
+            assert torch.isfinite(q).all(), k
+        for d in (net.discriminator, d_b):
+            for k, q in d.named_parameters():
+                assert torch.isfinite(q).all(), k
+    finally:
+        st.close()
