@@ -792,7 +792,20 @@ static bool launch_halo(const ConvArgs& a, int groups, hipStream_t st) {
     return true;
 }
 
+// CUs of the current device (the tail-split heuristics and the persistent grids are sized by it; 256 on MI355X)
+static int octa_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 #include "igemm8.hpp"
+#include "pwgemm.hpp"
+#include "halo8.hpp"
 #include "convres.hpp"
 
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
@@ -808,7 +821,8 @@ static void launch_dma(const ConvArgs& a, dim3 grid, hipStream_t st) {
     else conv_igemm_dma_kernel<T, WM, WN, TM, TN, 3, 2><<<grid, 256, 0, st>>>(a);
 }
 
-// algo (octa_conv_desc.algo): 0 = heuristic, 1 = 4-wave kernels (halo / generic), 2 / 3 = 8-wave kernel with 256x128 / 128x256 slabs
+// algo (octa_conv_desc.algo): 0 = heuristic, 1 = 4-wave kernels (halo / generic), 2 / 3 = 8-wave kernel with 256x128 / 128x256 slabs,
+// 4 / 5 / 6 = explicit 4-wave tiles, 7 = resident weights, 8 = 4-wave 128x128 slab, 9 / 10 / 11 = persistent pointwise GEMM, 12 = 8-wave 3x3 patch kernel
 // *fused (optional): set to 1 when the kernel that ran accumulates a.stats in its epilogue (the generic 4-wave tiles and the
 // 8-wave kernel do; the 3x3 halo, resident-weight and LDS-DMA kernels do not and ignore a.stats)
 template <typename T>
@@ -829,6 +843,10 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         }
         if ((want == 2 || want == 3) && launch_igemm8<T>(a, groups, want - 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); if (fused) *fused = 1; return OCTA_OK; }
         if (want == 8 && launch_igemm8<T>(a, groups, 2, st)) { OCTA_CHECK_LAUNCH("conv_igemm8"); if (fused) *fused = 1; return OCTA_OK; }     // 4-wave 128x128 slab
+        // persistent pointwise GEMM (pwgemm.hpp): 9 = 256x128, 10 = 128x256, 11 = 128x128 (4 waves); ineligible shapes fall through
+        if (want >= 9 && want <= 11 && launch_pwgemm<T>(a, groups, want - 9, st)) { OCTA_CHECK_LAUNCH("pwgemm"); return OCTA_OK; }
+        // 8-wave 3x3 kernel with a 2-D pixel patch per tile (halo8.hpp)
+        if (want == 12 && launch_halo8<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_halo8"); return OCTA_OK; }
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
         if (!a.addend && (want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }

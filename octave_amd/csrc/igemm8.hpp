@@ -405,9 +405,10 @@ static int splitk_parts(int tiles, int nsl, int ntaps, int64_t tile_floats) {
     if (off || !g_sk_ws) return 1;
     static const int maxtail = getenv("OCTA_SK_MAXTAIL") ? atoi(getenv("OCTA_SK_MAXTAIL")) : 128;
     static const int minst = getenv("OCTA_SK_MINSTAGES") ? atoi(getenv("OCTA_SK_MINSTAGES")) : 12;
-    const int tail = tiles % 256;
-    if (tail == 0 || tail > maxtail) return 1;             // the last round is more than half full: nothing worth the extra pass
-    int parts = 256 / tail;
+    const int ncu = octa_num_cus();                        // one workgroup per CU: a round is ncu tiles (256 on MI355X)
+    const int tail = tiles % ncu;
+    if (tail == 0 || tail > maxtail * ncu / 256) return 1; // the last round is more than half full: nothing worth the extra pass
+    int parts = ncu / tail;
     if (parts > 8) parts = 8;
     if (parts > nsl) parts = nsl;
     while (parts > 1 && (nsl / parts) * ntaps < minst) --parts;    // at least a dozen stages per part: prologue + ring fill are ~4
@@ -436,22 +437,23 @@ static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_
         const int tiles = grid.x * grid.y * groups;
         // (grouped layers: NgSt == Ng, i.e. no pad channels to zero-fill between the groups)
         const int parts = (!a.upshuffle && !a.stats && (groups == 1 || a.NgSt == a.Ng)) ? splitk_parts(tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
+        const int ntail = tiles % octa_num_cus();             // tiles behind the last full round
         if (parts > 1) {
-            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - tiles % 256; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
-            grid = dim3(b.sk_full + (tiles % 256) * parts, 1, 1);
+            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
+            grid = dim3(b.sk_full + ntail * parts, 1, 1);
         }
         if (variant == 0) {
             if (a.mode == 0) conv_igemm8_kernel<T, 4, 2, 0><<<grid, 512, 0, st>>>(b);
             else conv_igemm8_kernel<T, 4, 2, 1><<<grid, 512, 0, st>>>(b);
-            if (parts > 1) igemm8_splitk_fix_kernel<T, 256, 128><<<dim3(tiles % 256, 8), 256, 0, st>>>(b);
+            if (parts > 1) igemm8_splitk_fix_kernel<T, 256, 128><<<dim3(ntail, 8), 256, 0, st>>>(b);
             note_kernel<T>("conv_igemm8_kernel", 256, 128);
-            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", tiles % 256, parts); }
+            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", ntail, parts); }
         } else {
             if (a.mode == 0) conv_igemm8_kernel<T, 2, 4, 0><<<grid, 512, 0, st>>>(b);
             else conv_igemm8_kernel<T, 2, 4, 1><<<grid, 512, 0, st>>>(b);
-            if (parts > 1) igemm8_splitk_fix_kernel<T, 128, 256><<<dim3(tiles % 256, 8), 256, 0, st>>>(b);
+            if (parts > 1) igemm8_splitk_fix_kernel<T, 128, 256><<<dim3(ntail, 8), 256, 0, st>>>(b);
             note_kernel<T>("conv_igemm8_kernel", 128, 256);
-            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", tiles % 256, parts); }
+            if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", ntail, parts); }
         }
     }
     return true;

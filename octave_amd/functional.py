@@ -448,6 +448,10 @@ def _choose_algo(kind: str, d, launch) -> int:
         cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
     if kind != "dgrad_add" and cg in (32, 64) and d.groups == 1 and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
+    if cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
+        cands += [9, 10, 11]        # persistent pointwise GEMM (pwgemm.hpp): 256x128, 128x256, 128x128 tiles, cross-tile pipelined
+    if kind != "dgrad_add" and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
+        cands += [12]               # 8-wave 3x3 kernel, 2-D pixel patch per tile (halo8.hpp)
     best, best_t = 1, None
     if len(cands) > 1:
         for c in cands:

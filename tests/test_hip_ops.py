@@ -530,6 +530,121 @@ def test_igemm8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     check(f"igemm8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+PWGEMM_CASES = [
+    # B, Cin, H, W, Cout : 1x1 / stride 1 / no padding (the persistent pointwise GEMM, pwgemm.hpp)
+    (3, 128, 12, 10, 320),     # two K stages, N = 256 + tail, M = 360 (tile tails on both axes)
+    (2, 64, 37, 23, 72),       # one K stage per tile, odd image, N tail inside one tile
+    (5, 256, 17, 19, 576),     # 13 M tiles x 3-5 N tiles; the data gradient runs 9 K stages
+    (1, 192, 9, 7, 192),       # a single M tile, three K stages, N = 1.5 tiles
+    (2, 512, 33, 31, 264),     # eight K stages, N = 256 + 8 (the data gradient, K = 264, falls back)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("algo", [9, 10, 11])
+@pytest.mark.parametrize("case", PWGEMM_CASES)
+def test_pwgemm_forward_dgrad_addend_vs_torch(dev, case, algo, dtype):
+    """pwgemm.hpp (octa_conv_desc.algo 9 / 10 / 11: 256 x 128, 128 x 256, 128 x 128 tiles): forward (+ bias, ReLU), data gradient
+    and data gradient with the fused addend against torch's CPU conv on the same rounded operands; tile tails on M and N, one to
+    eight K stages per tile, several tiles per workgroup."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout = case
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias))
+    t = TOL[dtype]
+    F_._ALGO_OVERRIDE = algo
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 0, 1, 1)
+        name = lib().octa_last_conv_kernel().decode()
+        assert "pwgemm_kernel" in name, name
+        check(f"pwgemm fwd {case} algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+        dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
+        dyd = F_.to_nhwc(dy.to(dev), dtype=dtype)
+        dx = F_.raw_conv_dgrad(dyd, wd, (B, Cin, H, W), 1, 0, 1)
+        assert ("pwgemm_kernel" in lib().octa_last_conv_kernel().decode()) == (Cout % 64 == 0)        # K = Cout must be whole 64-channel stages
+        add = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+        dxa = F_.raw_conv_dgrad(dyd, wd, (B, Cin, H, W), 1, 0, 1, addend=F_.to_nhwc(add.to(dev), dtype=dtype))
+        assert ("pwgemm_kernel" in lib().octa_last_conv_kernel().decode()) == (Cout % 64 == 0)
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w, None).backward(dy)
+    check(f"pwgemm dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+    check(f"pwgemm dgrad+addend {case} algo {algo}", dxa, xr.grad + add, t["rtol"], t["atol"] * float((xr.grad + add).abs().max()))
+
+
+@pytest.mark.parametrize("algo", [9, 10, 11])
+def test_pwgemm_conv_transpose_upshuffle_vs_torch(dev, algo):
+    """The conv-transpose k2 s2 up-shuffle (a pointwise GEMM with N = 4 Cout scattered to (2i + di, 2j + dj)) through pwgemm."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout = 2, 128, 11, 13, 72
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Cin, H, W, generator=gen).bfloat16().float()
+    w = (torch.randn(Cin, Cout, 2, 2, generator=gen) * 0.1).bfloat16().float()
+    bias = torch.randn(Cout, generator=gen)
+    want = torch.nn.functional.conv_transpose2d(x, w, bias, stride=2)
+    F_._ALGO_OVERRIDE = algo
+    try:
+        with torch.no_grad():
+            y = F_.conv_transpose2x2(x.to(dev).to(torch.bfloat16), w.to(dev), bias.to(dev))
+        assert "pwgemm_kernel" in lib().octa_last_conv_kernel().decode(), lib().octa_last_conv_kernel().decode()
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    t = TOL[torch.bfloat16]
+    check(f"pwgemm up-shuffle algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+
+
+HALO8_CASES = [
+    # B, Cin, H, W, Cout, groups : 3x3 / stride 1 / pad 1 (halo8.hpp)
+    (2, 64, 17, 19, 136, 1),       # odd image, N tail, one 64-channel slice
+    (1, 128, 26, 50, 256, 1),      # two slices, several patches per image (partial patches at the right / bottom edge)
+    (2, 128, 9, 9, 256, 2),        # grouped: Cg = 64, Ng = 128
+    (3, 192, 25, 25, 320, 1),      # three slices, 25 x 25 (the decoder_4 / encoder_3 image), N = 256 + 64
+    (1, 256, 13, 13, 512, 4),      # four groups of 64 -> 128
+    (1, 64, 40, 7, 72, 1),         # narrow image: patch narrower than any default
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("algo", [12])
+@pytest.mark.parametrize("case", HALO8_CASES)
+def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
+    """halo8.hpp (octa_conv_desc.algo 12): the 8-wave 3x3 kernel with a 2-D pixel patch per tile, forward (+ bias, ReLU) and
+    data gradient (flipped taps) against torch's CPU conv on the same rounded operands."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, g = case
+    gen = torch.Generator().manual_seed(19)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, 3, 3, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, 1, 1, g))
+    t = TOL[dtype]
+    F_._ALGO_OVERRIDE = algo
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
+        name = lib().octa_last_conv_kernel().decode()
+        assert "conv_halo8_kernel" in name, name
+        check(f"halo8 fwd {case} algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+        dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
+        dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)
+        assert ("conv_halo8_kernel" in lib().octa_last_conv_kernel().decode()) == ((Cout // g) % 64 == 0)
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
+    check(f"halo8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
 ADD_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, groups
     (2, 256, 13, 11, 64, 1, 1, 0, 1),      # a bottleneck's conv1 (1x1): dx has 256 channels

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import BAND
+from conftest import BAND, BAND_GRAD
 
 from oracle import ref_ops as R
 from oracle.fill import fill_state_dict, fill_tensor, hash_input
@@ -54,7 +54,7 @@ def _band_check(tag, got, G, pre32, pre64, floor=1e-3, chaotic=False):
     print(f"[{tag}] grad-norm deviation from ref64: HIP median {np.median(dh):.2e} p95 {p95h:.2e} max {np.max(dh):.2e}; "
           f"ref32 median {np.median(dr):.2e} p95 {p95r:.2e} max {np.max(dr):.2e}")
     f_med, f_tail = (1.5e-2, 5e-2) if chaotic else (floor, 2 * floor)
-    assert np.median(dh) <= BAND * np.median(dr) + f_med and p95h <= BAND * p95r + f_tail and np.max(dh) <= 2 * BAND * np.max(dr) + f_tail, \
+    assert np.median(dh) <= BAND_GRAD * np.median(dr) + f_med and p95h <= BAND_GRAD * p95r + f_tail and np.max(dh) <= 2 * BAND_GRAD * np.max(dr) + f_tail, \
         (tag, np.median(dh), p95h, np.max(dh), np.median(dr), p95r, np.max(dr))
 
 
@@ -214,7 +214,7 @@ def test_hip_parallel_heads_backward_vs_reference(dev, golden, tag):
         if "_c." in k or k.startswith(("fc.", "fc_c.")):
             g64, g32 = float(G[f"{tag}/gradnorm_f64/{k}"]), float(G[f"{tag}/gradnorm/{k}"])
             if g64 > 1e-6 * top:
-                assert abs(got[k] - g64) <= BAND * abs(g32 - g64) + 2e-3 * g64 + 1e-7, (k, got[k], g32, g64)
+                assert abs(got[k] - g64) <= BAND_GRAD * abs(g32 - g64) + 2e-3 * g64 + 1e-7, (k, got[k], g32, g64)
 
 
 @pytest.mark.gpu

@@ -8,7 +8,7 @@ from octave_amd import functional as F_
 from tools.conv8_micro import LAYERS
 
 dev = torch.device("cuda:0")
-ALGOS = tuple(int(a) for a in os.environ.get("PW_ALGOS", "1,4,5,6,2,3,8").split(","))
+ALGOS = tuple(int(a) for a in os.environ.get("PW_ALGOS", "1,4,5,6,2,3,8,9,10,11").split(","))
 REPS = 20
 
 
@@ -51,6 +51,6 @@ def run(name):
 
 
 if __name__ == "__main__":
-    names = [a for a in sys.argv[1:] if a in LAYERS] or ["enc1_c1", "enc1_c3", "enc2_c1", "enc2_c3", "enc3_c1", "enc3_c3", "enc3_ds", "enc4_c1", "enc4_c3", "dec4_1x1", "dec3_1x1"]
+    names = [a for a in sys.argv[1:] if a in LAYERS] or ["enc1_c1", "enc1_c3", "enc2_c1", "enc2_c3", "enc3_c1", "enc3_c3", "enc3_ds", "enc4_c1", "enc4_c3", "dec4_1x1", "dec3_1x1", "dec2_1x1"]
     for n in names:
         run(n)
