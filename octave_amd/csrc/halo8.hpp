@@ -81,15 +81,27 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
-    const int g = blockIdx.z;
-    int mt, nt;
-    xcd_tile(gridDim.x, gridDim.y, mt, nt);
+    // tail split (as conv_igemm8_kernel's): a 1-D launch of sk_full whole tiles followed by sk_parts workgroups per remaining tile, each
+    // over a contiguous range of the 64-channel slices, ending in a raw fp32 store; halo8_splitk_fix_kernel finishes those tiles
+    int g = blockIdx.z, mt, nt, part = -1, tail = 0;
+    if (a.sk_parts > 1) {
+        const int bx = blockIdx.x;
+        int Lp;
+        if (bx < a.sk_full) Lp = xcd_remap(bx, a.sk_full);
+        else { const int bb = bx - a.sk_full; tail = bb / a.sk_parts; part = bb - tail * a.sk_parts; Lp = a.sk_full + tail; }
+        g = Lp / a.sk_tpg;
+        Lp -= g * a.sk_tpg;
+        nt = Lp % a.sk_gy;
+        mt = Lp / a.sk_gy;
+    } else xcd_tile(gridDim.x, gridDim.y, mt, nt);
     const int tx = mt % tiles_x;
     const int ty = (mt / tiles_x) % tiles_y;
     const int b = mt / (tiles_x * tiles_y);
     const int y0 = ty * PH, x0 = tx * PW, n0 = nt * BN;
     const int PW2 = PW + 2, PR = (PH + 2) * PW2, NI = 2 * ((PR + 15) >> 4), NPIX = PH * PW;
-    const int Cg = a.Cg, nslices = Cg >> 6;
+    const int Cg = a.Cg;
+    int s0 = 0, s1 = Cg >> 6;                              // this workgroup's 64-channel slices
+    if (part >= 0) { const int nsl = s1; s0 = part * nsl / a.sk_parts; s1 = (part + 1) * nsl / a.sk_parts; }
     const unsigned Cg2 = (unsigned)Cg * 2u;
     const unsigned long zaddr = (unsigned long)(const void*)octa_zero_page;
     const unsigned long xbase = (unsigned long)((const T*)a.x + a.xoff + g * a.CgStride);
@@ -175,18 +187,18 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
 #define H8_SB __builtin_amdgcn_sched_barrier(0)
     // prologue: patch 0, B(0), B(1), B(2); then wait for the patch and B(0), fetch the fragments of (0, step 0) and (0, step 1)
 #pragma unroll
-    for (int j = 0; j < H8_A_IPW; ++j) dmaA(j, 0);
+    for (int j = 0; j < H8_A_IPW; ++j) dmaA(j, s0);
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
-        for (int j = 0; j < B_IPW; ++j) dmaB(j, (unsigned)u * Cg2, u);           // stages 0..2 = taps 0..2 of slice 0
+        for (int j = 0; j < B_IPW; ++j) dmaB(j, (unsigned)u * Cg2 + (unsigned)(s0 * 128), u);      // stages 0..2 = taps 0..2 of the first slice
     wait_vmcnt<2 * B_IPW>();
     __builtin_amdgcn_s_barrier();
     // fragments of a k16-step: [0..MI) pixels, [MI..MI+NJ) weights; three sets
     ig8_u32x4_t f0[4], f1[4], f2[4];
     unsigned cur[MI];                                      // this stage's pixel fragment addresses (step 0)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) cur[i] = ta[0][i];
+    for (int i = 0; i < MI; ++i) cur[i] = ta[0][i] + (unsigned)((s0 & 1) * H8_A_BYTES);
 #pragma unroll
     for (int i = 0; i < MI; ++i) f0[i] = h8_rd(cur[i]);
 #pragma unroll
@@ -247,8 +259,8 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
         }                                                                                     \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) cur[i] = nx[i];                        \
     }
-    for (int slice = 0; slice < nslices; ++slice) {
-        const bool lastslice = slice + 1 == nslices;
+    for (int slice = s0; slice < s1; ++slice) {
+        const bool lastslice = slice + 1 == s1;
         const unsigned aoffs = (unsigned)((slice & 1) * H8_A_BYTES), naoffs = (unsigned)(((slice + 1) & 1) * H8_A_BYTES);
         const unsigned kslice = (unsigned)(slice * 128);
         // (opaque re-definition: otherwise the XOR-ed / offset variants of these 20 loop-invariant addresses are hoisted out of the
@@ -267,6 +279,22 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
 
     // ---- epilogue.  D[n][m]: lane l holds pixel m = l & 31 of block i and, for v = 0 .. 15, channel 8 (v >> 2) + 4 (l >> 5) + (v & 3)
     // of block jn: four groups of 4 consecutive channels (8-byte stores).
+    if (part >= 0) {
+        // partial tile: raw fp32 accumulators [pixel row of the tile][channel of the tile] into this (tile, part)'s slot of the workspace
+        float* __restrict__ wsp = a.sk_ws + ((size_t)tail * a.sk_parts + part) * (size_t)(256 * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int p = wm * (32 * MI) + 32 * i + r5;
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                for (int vg = 0; vg < 4; ++vg) {
+                    const int c = wn * 64 + 32 * jn + 8 * vg + 4 * kq;
+                    *(f32x4_t*)(wsp + (size_t)p * BN + c) = (f32x4_t){acc[i][jn][4 * vg], acc[i][jn][4 * vg + 1], acc[i][jn][4 * vg + 2], acc[i][jn][4 * vg + 3]};
+                }
+        }
+        return;
+    }
     T* __restrict__ yb = (T*)a.y + a.yoff;
     const int act = a.act;
 #pragma unroll
@@ -336,6 +364,63 @@ static void halo8_patch(int H, int W, int& PH, int& PW) {
     }
 }
 
+// Finishes the split tiles: y = act(sum of the parts + bias), stored at the patch's pixels.  One thread per (tile pixel row, 4 channels);
+// blockIdx.x = tail tile, blockIdx.y = strip of 32 pixel rows.
+template <typename T>
+__global__ __launch_bounds__(256) void halo8_splitk_fix_kernel(const ConvArgs a, int PH, int PW, int tiles_x, int tiles_y) {
+    constexpr int BN = 128;
+    int Lp = a.sk_full + blockIdx.x;
+    const int g = Lp / a.sk_tpg;
+    Lp -= g * a.sk_tpg;
+    const int nt = Lp % a.sk_gy, mt = Lp / a.sk_gy;
+    const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int y0 = ty * PH, x0 = tx * PW, n0 = nt * BN;
+    const int tc = threadIdx.x & 31, tr = threadIdx.x >> 5;              // 32 threads x 4 channels per row, 8 rows per pass
+    const int nb = n0 + tc * 4;
+    if (nb >= a.NgSt) return;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (nb + e < a.Ng) ? a.bias[g * a.Ng + nb + e] : 0.f;
+    const float* __restrict__ wsp = a.sk_ws + (size_t)blockIdx.x * a.sk_parts * (size_t)(256 * BN);
+    T* __restrict__ yb = (T*)a.y + a.yoff;
+    for (int p = blockIdx.y * 32 + tr; p < (int)(blockIdx.y + 1) * 32; p += 8) {
+        const int py = p / PW, px = p - py * PW;
+        const int oy = y0 + py, ox = x0 + px;
+        if (p >= PH * PW || oy >= a.H || ox >= a.W) continue;
+        f32x4_t v = *(const f32x4_t*)(wsp + (size_t)p * BN + tc * 4);
+        for (int q = 1; q < a.sk_parts; ++q) {
+            const f32x4_t u = *(const f32x4_t*)(wsp + (size_t)q * (256 * BN) + (size_t)p * BN + tc * 4);
+            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + bv[e], a.act);
+        T* dst = yb + (((size_t)b * a.H + oy) * a.W + ox) * a.ldy + g * a.Ng + nb;
+        if (a.vec_store && nb + 3 < a.Ng) *(uint2*)dst = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nb + e < a.NgSt) DT<T>::st(dst + e, nb + e < a.Ng ? o[e] : 0.f);
+        }
+    }
+}
+
+// How many parts the tiles behind the last full round are split into (1 = no split): halo8's stages are a (slice, tap) pair, a part
+// is a contiguous range of slices and should keep at least two of them (18 stages) to amortise its prologue
+static int halo8_parts(int tiles, int nsl) {
+    static const bool off = getenv("OCTA_NO_SPLITK") != nullptr;
+    if (off || !g_sk_ws) return 1;
+    const int ncu = octa_num_cus();
+    const int tail = tiles % ncu;
+    if (tail == 0 || tail > ncu / 2) return 1;
+    int parts = ncu / tail;
+    if (parts > 8) parts = 8;
+    if (parts > nsl / 2) parts = nsl / 2;
+    if (parts < 2) return 1;
+    if ((int64_t)tail * parts * 256 * 128 * 4 > g_sk_ws_bytes) return 1;
+    return parts;
+}
+
 // eligibility + launch.  Returns false when another kernel must run.
 template <typename T>
 static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
@@ -349,8 +434,18 @@ static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
     if (env_pw > 0 && env_ph > 0 && env_pw * env_ph <= 256 && (env_pw + 2) * (env_ph + 2) <= H8_AROWS) { PW = env_pw; PH = env_ph; }     // (experiments)
     const int tiles_y = cdiv(a.H, PH), tiles_x = cdiv(a.W, PW);
     dim3 grid(a.B * tiles_y * tiles_x, cdiv(a.Ng, 128), groups);
-    if (a.mode == 0) conv_halo8_kernel<T, 0><<<grid, 512, 0, st>>>(a, PH, PW, tiles_x, tiles_y);
-    else conv_halo8_kernel<T, 1><<<grid, 512, 0, st>>>(a, PH, PW, tiles_x, tiles_y);
+    ConvArgs b = a;
+    const int tiles = grid.x * grid.y * groups;
+    const int parts = (groups == 1 || a.NgSt == a.Ng) ? halo8_parts(tiles, a.Cg / 64) : 1;
+    const int ntail = tiles % octa_num_cus();
+    if (parts > 1) {
+        b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
+        grid = dim3(b.sk_full + ntail * parts, 1, 1);
+    }
+    if (a.mode == 0) conv_halo8_kernel<T, 0><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
+    else conv_halo8_kernel<T, 1><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
+    if (parts > 1) halo8_splitk_fix_kernel<T><<<dim3(ntail, 8), 256, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
     note_kernel<T>("conv_halo8_kernel", 256, 128);
+    if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", ntail, parts); }
     return true;
 }

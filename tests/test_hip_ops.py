@@ -645,6 +645,42 @@ def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     check(f"halo8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 256, 20, 20, 136, 1), (1, 512, 25, 25, 256, 2), (3, 384, 9, 30, 128, 1)])
+def test_halo8_tail_split_vs_torch(dev, case, dtype):
+    """halo8 with the tail-split scratch registered (octa_conv_splitk_workspace): a handful of tiles on 256 CUs, so every tile is
+    split over the 64-channel slices into 2-3 parts of raw fp32 partial tiles that halo8_splitk_fix_kernel sums, biases, activates
+    and stores at the patch's pixels; forward and data gradient against torch's CPU conv."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, g = case
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, 3, 3, generator=gen) * 0.05).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, 1, 1, g))
+    t = TOL[dtype]
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+    F_.set_splitk_workspace(ws)
+    F_._ALGO_OVERRIDE = 12
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
+        name = lib().octa_last_conv_kernel().decode()
+        assert "conv_halo8_kernel" in name and "+tail" in name, name
+        check(f"halo8 split fwd {case}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+        dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
+        dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)
+        dname = lib().octa_last_conv_kernel().decode()
+    finally:
+        F_._ALGO_OVERRIDE = 0
+        F_.set_splitk_workspace(None)
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
+    check(f"halo8 split dgrad {case} [{dname}]", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
 ADD_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, groups
     (2, 256, 13, 11, 64, 1, 1, 0, 1),      # a bottleneck's conv1 (1x1): dx has 256 channels

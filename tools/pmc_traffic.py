@@ -25,6 +25,12 @@ def short(name):
     if mr:      # <T, TAPS, NCH, TN, MODE> -> the name launch_res() reports (256 pixels x TN*16 channels)
         fam = "conv_res3x3_kernel" if int(mr.group(2)) == 9 else "conv_res1x1_kernel"
         return f"{fam}<{'bf16' if mr.group(1) == 'unsigned short' else 'f16'},256x{int(mr.group(4)) * 16}>"
+    mh = re.match(r"void conv_halo8_kernel<(unsigned short|f16_t), (\d+)>", name)
+    if mh:
+        return f"conv_halo8_kernel<{'bf16' if mh.group(1) == 'unsigned short' else 'f16'},256x128>"
+    mp = re.match(r"void pwgemm_kernel<(unsigned short|f16_t), (\d+), (\d+)>", name)
+    if mp:
+        return f"pwgemm_kernel<{'bf16' if mp.group(1) == 'unsigned short' else 'f16'},{int(mp.group(2)) * 64}x{int(mp.group(3)) * 64}>"
     m9 = re.match(r"void wgrad9_kernel<(\d+), (\d+), (\d+)>", name)
     if m9:
         return f"wgrad9_kernel<{'f16' if int(m9.group(1)) else 'bf16'},256x256>"
@@ -58,7 +64,16 @@ if __name__ == "__main__":
         write = e["write_kib"] / max(e["wl"], 1) * 1024.0
         res[s] = {"launches_profiled": e["launches"], "fetch_size_bytes_per_launch": fetch, "write_size_bytes_per_launch": write,
                   "hbm_bytes_per_launch": 2.0 * fetch + write}
-    json.dump({"note": "hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests as 64 B); averages per launch over "
+    import datetime
+    import os
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except Exception:
+        commit = None
+    commit = os.environ.get("OCTA_COMMIT", commit)      # the GPU box has no .git: tools/profile_round.sh passes the commit in
+    json.dump({"commit": commit, "date": datetime.date.today().isoformat(),
+               "note": "hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests as 64 B); averages per launch over "
                        "bench.py --no-graph, B=16, 400x400, bf16; separate --pmc passes",
                "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print("wrote", sys.argv[3], len(res), "kernels")

@@ -6,7 +6,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT; rm -rf $OUT/*
 export TMPDIR=/tmp
-cp profiles/r03_algo_cache.json $OUT/algo_cache.json 2>/dev/null || true      # measured kernel choices of an earlier run: no autotune launches in the traces
+# (the first bench run measures the per-shape kernel choices and writes them to $OUT/algo_cache.json: no autotune launches in the traces)
 python3 bench.py --steps 20 --warmup 3 --algo-cache $OUT/algo_cache.json > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.log
 # wall clock on the shared boxes varies run to run (other tenants): two more plain runs for the spread
