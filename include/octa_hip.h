@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 305
+#define OCTA_HIP_ABI_VERSION 306
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -338,6 +338,17 @@ int octa_splat_bn_bwd_dx(const void* dout, const void* x, const float* mean, con
                          const float* beta, const float* logits, const void* out, const float* dgap, void* dx,
                          float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int dtype, int relu,
                          octa_stream_t stream);
+/* Round 4: the same backward in TWO passes over (dout, out, x) instead of three.  octa_splat_bn_bwd_logits2 also accumulates, per
+ * (sample, channel) and radix half, aux[b][8][C] = {P, Px, M, Mx} x 2 (sums over the pixels of [y > 0] dout', [y > 0] dout' xhat,
+ * [y > 0], [y > 0] xhat; zero-filled by the caller or here when prezeroed = 0); after the micro-net's backward octa_splat_bn_bwd_dx2
+ * assembles bn0's backward sums from them (a_r P + (dgap / HW) M, ...), folds them and runs the dx pass: no statistics pass. */
+int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* logits, const void* out, float* dlogits, float* aux, int B, int HW, int C,
+                              int dtype, int relu, int prezeroed, octa_stream_t stream);
+int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, const float* logits, const void* out, const float* dgap, const float* aux, void* dx,
+                          float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int dtype, int relu, octa_stream_t stream);
+
 
 /* The attention micro-net on (B, C) vectors (resnest.py:118-125), exact fp32, 2 <= B <= 32:
  * h1 = fc1(gap) [grouped 1x1, + bias]; h2 = relu(bn1(h1)) [batch statistics when training, running stats

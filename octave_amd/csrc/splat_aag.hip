@@ -520,6 +520,108 @@ __global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__
         partial[((size_t)by * 2 + 1) * C2 + C + c] = a[3];
     }
 }
+// ---- round 4: bn0's backward sums WITHOUT a pass of their own.  The gradient that reaches y_r is dy_r = a_r dout' + dgap / HW, and
+// a_r, dgap are constants of a (sample, channel): with m_r = [y_r > 0]
+//     sum_hw m_r dy_r        = a_r P_r  + (dgap / HW) M_r          P_r  = sum_hw m_r dout'        M_r  = sum_hw m_r
+//     sum_hw m_r dy_r xhat_r = a_r Px_r + (dgap / HW) Mx_r         Px_r = sum_hw m_r dout' xhat_r   Mx_r = sum_hw m_r xhat_r
+// P, Px, M, Mx do not depend on the micro-net's backward, so the pass that computes the logit gradients (it reads dout, out and x
+// anyway) takes them along: aux[b][k][c], k = 0..3 for the first radix half (P, Px, M, Mx), 4..7 for the second.  After the
+// micro-net's backward a tiny kernel assembles the per-sample sums (splat_bn_assemble_kernel) in the layout of the BatchNorm
+// backward partials, bn_bwd_finalize folds them, and the dx pass follows: three passes over (dout, out, x) become two
+// (tools/bn_ledger.py: 8.2 GB -> 5.9 GB per step at B = 16, 400 x 400).
+template <typename T>
+__global__ __launch_bounds__(256) void splat_bwd_reduce_bn2_kernel(const T* __restrict__ dout, const T* __restrict__ x, SplatBn bn, const T* __restrict__ outp,
+                                                                   float* __restrict__ da, float* __restrict__ aux, int HW, int C, int TX, int rpb, int relu) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ float red[];   // [RY][TX*EPC][5], used twice
+    const int RY = 256 / TX;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    float s[10][EPC];                // 0: da_u, 1..4: P Px M Mx (u); 5: da_v, 6..9: P Px M Mx (v)
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[k][e] = 0.f;
+    if (col < cpr) {
+        const int cu = col * EPC, cv = C + col * EPC;
+        float scu[EPC], shu[EPC], scv[EPC], shv[EPC], muu[EPC], isu[EPC], muv[EPC], isv[EPC];
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, cu, scu, shu);
+        bn_co<EPC>(bn.mean, bn.invstd, bn.gamma, bn.beta, cv, scv, shv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { muu[e] = bn.mean[cu + e]; isu[e] = bn.invstd[cu + e]; muv[e] = bn.mean[cv + e]; isv[e] = bn.invstd[cv + e]; }
+        auto row = [&](const uint4& qd, const uint4& qo, const uint4& qu, const uint4& qv) {
+            float d[EPC], o[EPC], u[EPC], v[EPC];
+            unpack16<T>(qd, d); unpack16<T>(qu, u); unpack16<T>(qv, v);
+            if (relu) unpack16<T>(qo, o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dd = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                const float yu = fmaf(u[e], scu[e], shu[e]), yv = fmaf(v[e], scv[e], shv[e]);
+                const float mu_ = yu > 0.f ? 1.f : 0.f, mv_ = yv > 0.f ? 1.f : 0.f;
+                const float xu = (u[e] - muu[e]) * isu[e], xv = (v[e] - muv[e]) * isv[e];
+                const float du = mu_ * dd, dv = mv_ * dd;
+                s[0][e] += du * yu;                       // = dd * max(yu, 0)
+                s[1][e] += du; s[2][e] += du * xu; s[3][e] += mu_; s[4][e] += mu_ * xu;
+                s[5][e] += dv * yv;
+                s[6][e] += dv; s[7][e] += dv * xv; s[8][e] += mv_; s[9][e] += mv_ * xv;
+            }
+        };
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        int r = r0 + ry;
+        for (; r + RY < r1; r += 2 * RY) {                 // two rows per iteration, loads first
+            const int64_t pa = ((int64_t)b * HW + r) * C + cu, pb = ((int64_t)b * HW + r + RY) * C + cu;
+            const T* xa = x + ((int64_t)b * HW + r) * 2 * C + cu;
+            const T* xb = x + ((int64_t)b * HW + r + RY) * 2 * C + cu;
+            const uint4 qd0 = *(const uint4*)(dout + pa), qd1 = *(const uint4*)(dout + pb);
+            const uint4 qo0 = relu ? *(const uint4*)(outp + pa) : z4, qo1 = relu ? *(const uint4*)(outp + pb) : z4;
+            const uint4 qu0 = *(const uint4*)xa, qv0 = *(const uint4*)(xa + C), qu1 = *(const uint4*)xb, qv1 = *(const uint4*)(xb + C);
+            row(qd0, qo0, qu0, qv0);
+            row(qd1, qo1, qu1, qv1);
+        }
+        for (; r < r1; r += RY) {
+            const int64_t po = ((int64_t)b * HW + r) * C + cu;
+            const T* px = x + ((int64_t)b * HW + r) * 2 * C + cu;
+            row(*(const uint4*)(dout + po), relu ? *(const uint4*)(outp + po) : z4, *(const uint4*)px, *(const uint4*)(px + C));
+        }
+    }
+    // block reduction over the RY row groups, five sums at a time (one radix half per round)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) red[(((size_t)ry * TX + cx) * EPC + e) * 5 + k] = s[half * 5 + k][e];
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
+            const int c = blockIdx.x * TX * EPC + ch;
+            if (c >= C) continue;
+            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int yy = 0; yy < RY; ++yy)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a[k] += red[((size_t)yy * TX * EPC + ch) * 5 + k];
+            atomicAdd(da + (int64_t)b * 2 * C + half * C + c, a[0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(aux + ((int64_t)b * 8 + half * 4 + k) * C + c, a[1 + k]);
+        }
+    }
+}
+// partial[b][0][ch] = sum_hw m dy, partial[b][1][ch] = sum_hw m dy xhat of sample b (the layout bn_bwd_finalize folds over b)
+__global__ __launch_bounds__(256) void splat_bn_assemble_kernel(const float* __restrict__ aux, const float* __restrict__ logits, const float* __restrict__ dgap,
+                                                                float* __restrict__ partial, int B, int C, float inv_hw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, C2 = 2 * C;
+    const float l0 = logits[(int64_t)b * C2 + c], l1 = logits[(int64_t)b * C2 + C + c];
+    const float a0 = 1.f / (1.f + expf(l1 - l0)), dg = dgap[i] * inv_hw;
+    const float* au = aux + (int64_t)b * 8 * C + c;
+    partial[((size_t)b * 2 + 0) * C2 + c] = fmaf(a0, au[0], dg * au[2 * (int64_t)C]);
+    partial[((size_t)b * 2 + 1) * C2 + c] = fmaf(a0, au[(int64_t)C], dg * au[3 * (int64_t)C]);
+    partial[((size_t)b * 2 + 0) * C2 + C + c] = fmaf(1.f - a0, au[4 * (int64_t)C], dg * au[6 * (int64_t)C]);
+    partial[((size_t)b * 2 + 1) * C2 + C + c] = fmaf(1.f - a0, au[5 * (int64_t)C], dg * au[7 * (int64_t)C]);
+}
 int octa_bn_bwd_finalize_launch(const float* partial, int nby, int C, int64_t rows, float* fin, float* dgamma, float* dbeta, hipStream_t st);   // norm.hip
 
 #define OCTA_SPLAT_BN_ARGS                                                                                                             \
@@ -581,6 +683,60 @@ extern "C" int octa_splat_bn_bwd_logits(const void* dout, const void* x, const f
     OCTA_CHECK_LAUNCH("splat_bwd_reduce_bn");
     splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
     OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    return OCTA_OK;
+}
+extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         const float* logits, const void* out, float* dlogits, float* aux, int B, int HW, int C, int dtype, int relu,
+                                         int prezeroed, octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(dout && logits && dlogits && aux && (!relu || out), "octa_splat_bn_bwd_logits2: null pointer (relu needs the forward output)");
+    if (!prezeroed) {
+        if (octa_zero_async(dlogits, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess || octa_zero_async(aux, (size_t)B * 8 * C * sizeof(float), st) != hipSuccess)
+            OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_bn_bwd_logits2: memset failed");
+    }
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int rpb = cdiv(HW, 64);
+    if (rpb < RY * 8) rpb = RY * 8;
+    dim3 grid(gx, cdiv(HW, rpb), B);
+    const size_t sh = (size_t)256 * epc * 5 * sizeof(float);
+    if (dtype == OCTA_F32) splat_bwd_reduce_bn2_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, aux, HW, C, TX, rpb, relu);
+    else if (dtype == OCTA_BF16) splat_bwd_reduce_bn2_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, bn, (const bf16_t*)out, dlogits, aux, HW, C, TX, rpb, relu);
+    else splat_bwd_reduce_bn2_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, bn, (const f16_t*)out, dlogits, aux, HW, C, TX, rpb, relu);
+    OCTA_CHECK_LAUNCH("splat_bwd_reduce_bn2");
+    splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
+    OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    return OCTA_OK;
+}
+extern "C" int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     const float* logits, const void* out, const float* dgap, const float* aux, void* dx, float* dgamma, float* dbeta,
+                                     float* ws, int B, int HW, int C, int dtype, int relu, octa_stream_t stream) {
+    OCTA_SPLAT_BN_ARGS;
+    OCTA_REQUIRE(dout && logits && dgap && aux && dx && ws && (!relu || out), "octa_splat_bn_bwd_dx2: null pointer (relu needs the forward output)");
+    OCTA_REQUIRE(B <= 1024, "octa_splat_bn_bwd_dx2: batch %d too large for the partial-sum workspace", B);
+    int TX, gx;
+    splat_map(C / epc, TX, gx);
+    const int RY = 256 / TX;
+    int nslab = 1024 / B;
+    if (nslab < 1) nslab = 1;
+    int rpb = cdiv(HW, nslab);
+    if (rpb < RY * 8) rpb = RY * 8;
+    nslab = cdiv(HW, rpb);
+    dim3 grid(gx, nslab, B);
+    const int C2 = 2 * C;
+    float* fin = ws + (size_t)1026 * 2 * C2;
+    splat_bn_assemble_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(aux, logits, dgap, ws, B, C, 1.f / (float)HW);
+    OCTA_CHECK_LAUNCH("splat_bn_assemble");
+    const int rc = octa_bn_bwd_finalize_launch(ws, B, C2, (int64_t)B * HW, fin, dgamma, dbeta, st);
+    if (rc != OCTA_OK) return rc;
+#define OCTA_SPLAT_BN_BWD1(TT)                                                                                                                   \
+    splat_bn_bwd_kernel<TT, 1><<<grid, 256, 0, st>>>((const TT*)dout, (const TT*)out, (const TT*)x, bn, logits, dgap, fin, ws, (TT*)dx, HW, C, TX, rpb, relu)
+    if (dtype == OCTA_F32) { OCTA_SPLAT_BN_BWD1(float); }
+    else if (dtype == OCTA_BF16) { OCTA_SPLAT_BN_BWD1(bf16_t); }
+    else { OCTA_SPLAT_BN_BWD1(f16_t); }
+#undef OCTA_SPLAT_BN_BWD1
+    OCTA_CHECK_LAUNCH("splat_bn_bwd(dx)");
     return OCTA_OK;
 }
 extern "C" int octa_splat_bn_bwd_dx(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,

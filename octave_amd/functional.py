@@ -1194,6 +1194,9 @@ def _grad_buf(p: Optional[Tensor], dense2d: bool = False):
     return z, z
 
 
+_SPLAT_BWD_MERGE = os.environ.get("OCTA_SPLAT_BWD_MERGE", "1") != "0"      # bn0's backward sums ride along the logits pass (2 passes instead of 3)
+
+
 class SplatTailFn(Function):
     """Everything of SplAtConv2d.forward after bn0+relu (extra/resnest.py:106-138), radix 2:
     radix-sum GAP -> fc1 -> bn1 -> relu -> fc2 -> radix softmax -> weighted sum [-> relu].
@@ -1269,7 +1272,19 @@ class SplatTailFn(Function):
         dev = xr.device
         dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
         dlogits, pz = _zeroed_f32((B, 2 * C), dev)
-        if fused:
+        aux = None
+        if fused and _SPLAT_BWD_MERGE:
+            # two passes over (dout, out, x) instead of three: the logits pass also takes bn0's backward sums along (aux), see splat_aag.hip
+            aux, pza = _zeroed_f32((B, 8, C), dev)
+            if pz and pza:
+                L.octa_splat_bn_bwd_logits2(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
+                                            B, HW, C, _dt(xr), int(relu), 1, _st())
+            else:
+                if pz:
+                    dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)      # (both buffers are cleared by the entry point)
+                L.octa_splat_bn_bwd_logits2(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
+                                            B, HW, C, _dt(xr), int(relu), 0, _st())
+        elif fused:
             L.octa_splat_bn_bwd_logits(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), B, HW, C,
                                        _dt(xr), int(relu), pz, _st())
         else:
@@ -1289,8 +1304,12 @@ class SplatTailFn(Function):
         if fused:
             dg0, r_g0 = _grad_buf(g0)
             db0, r_b0 = _grad_buf(b0)
-            L.octa_splat_bn_bwd_dx(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dgap), _p(dx), _p(dg0),
-                                   _p(db0), _p(_bn_ws(B * HW, 2 * C, dev)), B, HW, C, _dt(xr), int(relu), _st())
+            if aux is not None:
+                L.octa_splat_bn_bwd_dx2(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dgap), _p(aux), _p(dx),
+                                        _p(dg0), _p(db0), _p(_bn_ws(B * HW, 2 * C, dev)), B, HW, C, _dt(xr), int(relu), _st())
+            else:
+                L.octa_splat_bn_bwd_dx(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dgap), _p(dx), _p(dg0),
+                                       _p(db0), _p(_bn_ws(B * HW, 2 * C, dev)), B, HW, C, _dt(xr), int(relu), _st())
         else:
             L.octa_splat_bwd(_p(dout), None, _p(logits), _p(out), _p(dgap), _p(dx), None, B, HW, C, _dt(xr), int(relu), 1, 0, _st())
         return dx, r_w1, r_b1f, r_g1, r_be1, None, None, r_w2, r_b2, None, None, None, None, None, r_g0, r_b0, None, None, None, None
