@@ -526,8 +526,8 @@ __global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__
 //     sum_hw m_r dy_r xhat_r = a_r Px_r + (dgap / HW) Mx_r         Px_r = sum_hw m_r dout' xhat_r   Mx_r = sum_hw m_r xhat_r
 // P, Px, M, Mx do not depend on the micro-net's backward, so the pass that computes the logit gradients (it reads dout, out and x
 // anyway) takes them along: aux[b][k][c], k = 0..3 for the first radix half (P, Px, M, Mx), 4..7 for the second.  After the
-// micro-net's backward a tiny kernel assembles the per-sample sums (splat_bn_assemble_kernel) in the layout of the BatchNorm
-// backward partials, bn_bwd_finalize folds them, and the dx pass follows: three passes over (dout, out, x) become two
+// micro-net's backward ONE tiny kernel assembles the per-sample sums and folds them over the batch (splat_bn_assemble_finalize_kernel),
+// and the dx pass follows: three passes over (dout, out, x) become two
 // (tools/bn_ledger.py: 8.2 GB -> 5.9 GB per step at B = 16, 400 x 400).
 template <typename T>
 __global__ __launch_bounds__(256) void splat_bwd_reduce_bn2_kernel(const T* __restrict__ dout, const T* __restrict__ x, SplatBn bn, const T* __restrict__ outp,
@@ -608,19 +608,27 @@ __global__ __launch_bounds__(256) void splat_bwd_reduce_bn2_kernel(const T* __re
         }
     }
 }
-// partial[b][0][ch] = sum_hw m dy, partial[b][1][ch] = sum_hw m dy xhat of sample b (the layout bn_bwd_finalize folds over b)
-__global__ __launch_bounds__(256) void splat_bn_assemble_kernel(const float* __restrict__ aux, const float* __restrict__ logits, const float* __restrict__ dgap,
-                                                                float* __restrict__ partial, int B, int C, float inv_hw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C, C2 = 2 * C;
-    const float l0 = logits[(int64_t)b * C2 + c], l1 = logits[(int64_t)b * C2 + C + c];
-    const float a0 = 1.f / (1.f + expf(l1 - l0)), dg = dgap[i] * inv_hw;
-    const float* au = aux + (int64_t)b * 8 * C + c;
-    partial[((size_t)b * 2 + 0) * C2 + c] = fmaf(a0, au[0], dg * au[2 * (int64_t)C]);
-    partial[((size_t)b * 2 + 1) * C2 + c] = fmaf(a0, au[(int64_t)C], dg * au[3 * (int64_t)C]);
-    partial[((size_t)b * 2 + 0) * C2 + C + c] = fmaf(1.f - a0, au[4 * (int64_t)C], dg * au[6 * (int64_t)C]);
-    partial[((size_t)b * 2 + 1) * C2 + C + c] = fmaf(1.f - a0, au[5 * (int64_t)C], dg * au[7 * (int64_t)C]);
+// bn0's backward sums assembled from aux and folded over the samples in ONE launch (the assemble + bn_bwd_finalize pair was two
+// 5-6 us launches on the critical path of every split-attention block): thread = channel ch of the 2C tensor, loop over b <= 32,
+// double accumulation like bn_bwd_finalize_kernel.  fin[0][ch] = sum m dy / N, fin[1][ch] = sum m dy xhat / N, dbeta / dgamma +=.
+__global__ __launch_bounds__(256) void splat_bn_assemble_finalize_kernel(const float* __restrict__ aux, const float* __restrict__ logits,
+                                                                         const float* __restrict__ dgap, float* __restrict__ fin, float* __restrict__ dgamma,
+                                                                         float* __restrict__ dbeta, int B, int C, float inv_hw, double inv_rows) {
+    const int ch = blockIdx.x * 256 + threadIdx.x, C2 = 2 * C;
+    if (ch >= C2) return;
+    const int half = ch >= C ? 1 : 0, c = ch - half * C;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float l0 = logits[(int64_t)b * C2 + c], l1 = logits[(int64_t)b * C2 + C + c];
+        const float a0 = 1.f / (1.f + expf(l1 - l0)), a = half ? 1.f - a0 : a0, dg = dgap[(int64_t)b * C + c] * inv_hw;
+        const float* au = aux + ((int64_t)b * 8 + half * 4) * C + c;
+        s += (double)fmaf(a, au[0], dg * au[2 * (int64_t)C]);
+        ss += (double)fmaf(a, au[(int64_t)C], dg * au[3 * (int64_t)C]);
+    }
+    if (dbeta) dbeta[ch] += (float)s;
+    if (dgamma) dgamma[ch] += (float)ss;
+    fin[ch] = (float)(s * inv_rows);
+    fin[C2 + ch] = (float)(ss * inv_rows);
 }
 int octa_bn_bwd_finalize_launch(const float* partial, int nby, int C, int64_t rows, float* fin, float* dgamma, float* dbeta, hipStream_t st);   // norm.hip
 
@@ -726,10 +734,8 @@ extern "C" int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const floa
     dim3 grid(gx, nslab, B);
     const int C2 = 2 * C;
     float* fin = ws + (size_t)1026 * 2 * C2;
-    splat_bn_assemble_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(aux, logits, dgap, ws, B, C, 1.f / (float)HW);
-    OCTA_CHECK_LAUNCH("splat_bn_assemble");
-    const int rc = octa_bn_bwd_finalize_launch(ws, B, C2, (int64_t)B * HW, fin, dgamma, dbeta, st);
-    if (rc != OCTA_OK) return rc;
+    splat_bn_assemble_finalize_kernel<<<cdiv(C2, 256), 256, 0, st>>>(aux, logits, dgap, fin, dgamma, dbeta, B, C, 1.f / (float)HW, 1.0 / ((double)B * HW));
+    OCTA_CHECK_LAUNCH("splat_bn_assemble_finalize");
 #define OCTA_SPLAT_BN_BWD1(TT)                                                                                                                   \
     splat_bn_bwd_kernel<TT, 1><<<grid, 256, 0, st>>>((const TT*)dout, (const TT*)out, (const TT*)x, bn, logits, dgap, fin, ws, (TT*)dx, HW, C, TX, rpb, relu)
     if (dtype == OCTA_F32) { OCTA_SPLAT_BN_BWD1(float); }
