@@ -69,8 +69,10 @@ def splat_bwd(ctx, dout):
     Bn, C, Hh, Ww = dout.shape
     t = Bn * C * Hh * Ww * dout.element_size()
     t2 = 2 * t
-    # as implemented: logit gradients (dout, x, out), bn0's sums (dout, x, out), dx (dout, x, out; writes the 2C gradient)
-    moved, minimum = 3 * (t + t2 + t) + t2, (t + t2 + t) + t2
+    # as implemented: logit gradients (dout, x, out) [+ bn0's sums in a pass of their own with OCTA_SPLAT_BWD_MERGE=0], dx (dout, x, out;
+    # writes the 2C gradient)
+    passes = 2 if F_._SPLAT_BWD_MERGE else 3
+    moved, minimum = passes * (t + t2 + t) + t2, (t + t2 + t) + t2
     return timed("splat bwd", f"C={C} {Hh}x{Ww}", moved, minimum, _sb, ctx, dout)
 
 
