@@ -19,6 +19,11 @@ from octave_amd.layers import BatchNorm2d, Conv2d, ConvTranspose2d, ReLU, bump_c
 BN_MOMENTUM = 0.1
 _FUSE_FANOUT = os.environ.get("OCTA_FUSE_FANOUT", "1") != "0"     # Bottleneck: shortcut gradient added in conv1's data-gradient epilogue
 _FUSE_SPLAT_BN0 = os.environ.get("OCTA_FUSE_SPLAT_BN0", "1") != "0"    # SplAtConv2d (training): bn0 + ReLU recomputed inside the split-attention kernels
+# Shortcut branches on a second stream (functional.SideBranch): built and parity-tested in round 4, measured on one box alternating
+# (profiles/r04_ab_env.txt): encoder shortcuts 26.05 -> 26.0-26.3 ms per step (no gain: HBM-bound kernels beside HBM-bound kernels),
+# decoder shortcut 1x1s 26.05 -> 27.4 (the 1x1 competes with the one-workgroup-per-CU 3x3 kernel for CUs) -- OFF by default.
+_SIDE_SHORTCUT = os.environ.get("OCTA_SIDE_SHORTCUT", "0") == "1"          # Bottleneck: avg-down shortcut on a second stream
+_SIDE_SHORTCUT_DEC = os.environ.get("OCTA_SIDE_SHORTCUT_DEC", "0") == "1"  # ResNestDecoder: shortcut 1x1 on a second stream
 _FUSE_FANOUT_DEC = os.environ.get("OCTA_FUSE_FANOUT_DEC", "1") != "0"     # ResNestDecoder: 3x3 gradient added in the shortcut conv's data gradient
 
 
@@ -107,12 +112,24 @@ class Bottleneck(nn.Module):
         # x feeds conv1 AND the shortcut: the shortcut's gradient is parked in `h` and conv1's data gradient adds it in its
         # epilogue (one read) instead of autograd summing the two in a separate kernel (three passes over the tensor)
         h = F_.GradHolder() if (_FUSE_FANOUT and torch.is_grad_enabled() and x.requires_grad) else None
+        side = self.downsample is not None and _SIDE_SHORTCUT and self.training and F_.side_branch_ok(x)
+        ev = F_.fork_point() if side else None          # x is ready here: the shortcut branch depends on nothing later
         out = conv_bn(self.conv1, self.bn1, x, relu=True, grad_holder=h)
+        # (the stash node is created AFTER conv1's: autograd runs it first in the backward pass, so conv1 finds the parked gradient)
+        xs = F_.stash_grad(x, h) if h is not None else x
+        br = None
+        if side:
+            # the shortcut (avg-pool -> 1x1 -> BatchNorm) on the second stream, beside conv1 .. conv3 (functional.SideBranch)
+            br = F_.SideBranch(after=ev)
+            with br:
+                residual = self.downsample(xs)
         out = self.conv2(out)
         if self.avd:
             out = F_.avg_pool(out, 3, self.avd_stride, 1)
-        xs = F_.stash_grad(x, h) if h is not None else x
-        residual = self.downsample(xs) if self.downsample is not None else xs
+        if br is not None:
+            br.join(residual)
+        else:
+            residual = self.downsample(xs) if self.downsample is not None else xs
         return conv_bn(self.conv3, self.bn3, out, relu=True, residual=residual)
 
 
@@ -234,6 +251,15 @@ class ResNestDecoder(nn.Module):
             # x feeds the 3x3 AND the 1x1 shortcut conv.  The 1x1 runs first here, so its backward runs last and its data
             # gradient adds the 3x3's (parked by stash_grad) in its epilogue: no separate gradient-sum kernel
             h = F_.GradHolder()
+            if _SIDE_SHORTCUT_DEC and F_.side_branch_ok(x):
+                # the shortcut 1x1 on the second stream, beside the 3x3 -> BatchNorm -> split-attention chain
+                br = F_.SideBranch()
+                with br:
+                    ds = self.downsample[0](x, h)
+                out = conv_bn(c[0], c[1], F_.stash_grad(x, h), relu=True)
+                out = c[3](out, relu_after=True)
+                br.join(ds)
+                return self.downsample[1](ds, relu=True, residual=out)
             ds = self.downsample[0](x, h)
             out = conv_bn(c[0], c[1], F_.stash_grad(x, h), relu=True)
             out = c[3](out, relu_after=True)

@@ -205,6 +205,96 @@ def set_splitk_workspace(ws: Optional[Tensor]):
     _SPLITK_WS = ws
 
 
+# ----------------------------------------------------------------------------- side branches (second stream)
+# A block's shortcut branch (avg-pool -> 1x1 -> BatchNorm of a strided bottleneck; the 1x1 of a decoder block) does not depend on the
+# main branch until the final add.  Issued on a second stream between a fork and a join, it runs BESIDE the main branch: eagerly as a
+# second HIP queue, inside a captured step as a parallel branch of the hipGraph.  autograd replays the stream of every node's forward in
+# its backward and inserts the cross-stream waits itself; what it cannot see is handled here: the tail-split scratch of the conv kernels
+# is process-wide (side-branch launches never split), and a gradient parked in a GradHolder travels by event.
+_SIDE_BRANCH = os.environ.get("OCTA_SIDE_BRANCH", "1") != "0"
+_SIDE_STREAMS = {}
+_IN_SIDE = False
+_NO_SPLIT = 0
+
+
+class no_splitk:
+    """Conv launches inside this context never use the tail-split scratch (they may run beside launches that do)."""
+
+    def __enter__(self):
+        global _NO_SPLIT
+        _NO_SPLIT += 1
+        return self
+
+    def __exit__(self, *a):
+        global _NO_SPLIT
+        _NO_SPLIT -= 1
+
+
+def _launch_unsplit(fn):
+    """Run the conv launch `fn` with the tail-split scratch withdrawn when a side branch asked for it."""
+    if _NO_SPLIT and _SPLITK_WS is not None:
+        lib().octa_conv_splitk_workspace(None, 0)
+        try:
+            fn()
+        finally:
+            lib().octa_conv_splitk_workspace(_p(_SPLITK_WS), _SPLITK_WS.numel() * 4)
+    else:
+        fn()
+
+
+class SideBranch:
+    """with SideBranch(x) as br: y = shortcut(x)   # on the second stream, behind everything the current stream has enqueued so far
+       ... main branch on the current stream ...
+       br.join(y)                                   # the current stream waits for the branch before y is used"""
+
+    def __init__(self, after=None):
+        # after: an event recorded earlier on the current stream (fork_point()): the branch then waits for THAT point only, not for
+        # what the current stream enqueued since (the main branch's first kernels)
+        self.after = after
+        self.cur = torch.cuda.current_stream()
+        key = self.cur.device.index
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.cur.device)
+        self.side = _SIDE_STREAMS[key]
+        if self.side == self.cur:                          # (a caller that already runs on the side stream: take another one)
+            self.side = torch.cuda.Stream(device=self.cur.device)
+
+    def __enter__(self):
+        global _IN_SIDE
+        if self.after is not None:
+            self.side.wait_event(self.after)
+        else:
+            self.side.wait_stream(self.cur)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        self._prev, _IN_SIDE = _IN_SIDE, True
+        self._ns = no_splitk().__enter__()
+        return self
+
+    def __exit__(self, *a):
+        global _IN_SIDE
+        self._ns.__exit__(*a)
+        _IN_SIDE = self._prev
+        return self._ctx.__exit__(*a)
+
+    def join(self, *tensors):
+        self.cur.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.cur)                  # allocated on the side stream, consumed (and possibly freed) on this one
+
+
+def fork_point():
+    """An event on the current stream, for SideBranch(after=...)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def side_branch_ok(x) -> bool:
+    return _SIDE_BRANCH and x.is_cuda and not _IN_SIDE
+
+
 # ----------------------------------------------------------------------------- packed weights
 _WEIGHT_EPOCH = 0
 _PARAM_EPOCH = 0          # bumped whenever a kernel writes parameters or BatchNorm running statistics through raw pointers
@@ -490,7 +580,7 @@ def _launch_fwd(d, x, wp, bias, y, stats: Optional["ConvStats"] = None):
         L.octa_conv2d_fwd_stats(ctypes.byref(d), px, pw, pb, py, _p(stats.sums), _p(stats.shift), stats.replicas, ctypes.byref(flag), st)
         stats.fused = bool(flag.value)
         return
-    L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
+    _launch_unsplit(lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
 
 
 def _launch_dgrad(d, dy, wt, dx, addend=None):
@@ -500,10 +590,10 @@ def _launch_dgrad(d, dy, wt, dx, addend=None):
         # dx = conv^T(dy) + addend in the kernel's epilogue (the generic / LDS-DMA kernels; tuned as its own shape class)
         pa, lda = _p(addend), nhwc_ld(addend)
         d.algo = _choose_algo("dgrad_add", d, lambda: L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st))
-        L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st)
+        _launch_unsplit(lambda: L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st))
         return
     d.algo = _choose_algo("dgrad", d, lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
-    L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st)
+    _launch_unsplit(lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
 
 
 def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dtype, act=ACT_NONE, upshuffle=0) -> ConvDesc:
@@ -899,11 +989,12 @@ def _ret(p: Tensor, buf: Tensor) -> Optional[Tensor]:
 class GradHolder:
     """Carries the gradient of one consumer of a tensor to the conv that consumes the same tensor, so that the conv's data
     gradient can add it in its epilogue (fan-out gradient sum without autograd's separate add kernel)."""
-    __slots__ = ("grad", "consumed")
+    __slots__ = ("grad", "consumed", "event")
 
     def __init__(self):
         self.grad = None
         self.consumed = False
+        self.event = None           # recorded behind the parked gradient: the consumer may run on another stream (side branches)
 
 
 class StashGradFn(Function):
@@ -922,6 +1013,9 @@ class StashGradFn(Function):
         if h.consumed:
             return g, None
         h.grad = g if h.grad is None else h.grad + g
+        if _SIDE_BRANCH and g.is_cuda:
+            h.event = torch.cuda.Event()
+            h.event.record()
         return None, None
 
 
@@ -937,6 +1031,7 @@ class Conv2dFn(Function):
         _require_gpu(x)
         y = raw_conv_fwd(x, w, bias, stride, pad, groups, act, stats=stats)
         ctx.holder = holder
+        ctx.side = _IN_SIDE              # a side-branch conv: its backward launches must not use the tail-split scratch either
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -954,7 +1049,13 @@ class Conv2dFn(Function):
         if ctx.holder is not None:
             ctx.holder.consumed = True
             addend, ctx.holder.grad = ctx.holder.grad, None
-        dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
+            if addend is not None and ctx.holder.event is not None:
+                torch.cuda.current_stream().wait_event(ctx.holder.event)      # parked on another stream (side branches)
+        if ctx.side:
+            with no_splitk():
+                dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
+        else:
+            dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         b = ctx.bias_ref
