@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 306
+#define OCTA_HIP_ABI_VERSION 307
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -85,9 +85,11 @@ int octa_pack_weight_dgrad(const float* w, int64_t s_o, int64_t s_i, int64_t s_h
 
 /* One launch for many packs (all operands of a network after the optimiser step).  kind 0: forward
  * operand, 1: data-gradient operand, 2: ConvTranspose up-shuffle operand (Cout_g = Cout_t, Cin_g = Cin_t,
- * strides = (s_ci, s_co, s_h, s_w)), 3 / 4: a GROUPED weight laid out as the dense block-diagonal forward
- * operand [Cout][KH][KW][pad_to >= Cin] / data-gradient operand [Cin][KH][KW][pad_to >= Cout] (zeros off the
- * diagonal blocks), for small-channel grouped 3x3 layers that run faster as one dense conv on the halo kernel;
+ * strides = (s_ci, s_co, s_h, s_w)), 3 / 4: a GROUPED weight with SETS of adjacent groups merged into dense
+ * block-diagonal blocks: forward operand [Cout][KH][KW][pad_to = set * Cin_g] / data-gradient operand
+ * [Cin][KH][KW][pad_to = set * Cout_g] (zeros off the diagonal blocks; set = groups: one dense conv, set < groups:
+ * a conv with groups / set wider groups), for small-channel grouped 3x3 layers that run faster on the halo /
+ * resident-weight kernels with 32 or 64 channels per group;
  * 5: the tap-major data-gradient operand of octa_pack_weight_dgrad_taps ([KH*KW][round8(Cin_g)][pad_to >= Cout_g], groups 1).
  * `prefix` = exclusive prefix sum of the operands' TILE counts (octa_pack_tile_count; `total` = their sum): 2048
  * consecutive elements per tile for kinds 0/3/4/5, one 32x32 LDS-transposed tile for kinds 1/2. */

@@ -1219,7 +1219,9 @@ __device__ __forceinline__ void pack_tile_linear(const octa_pack_desc& d, unsign
     if (d.kind == 0 || d.kind == 3) {
         const int co = (int)tq;                              // global output channel (groups are consecutive row blocks)
         const int g = co / d.Cout_g;
-        const int shift = d.kind == 3 ? g * d.Cin_g : 0;     // kind 3: dense inner axis, this group's block starts at g*Cin_g
+        // kind 3: dense inner axis over a SET of pad_to / Cin_g merged groups (all of them = one dense conv, or pairs .. = a conv
+        // with fewer, wider groups); this group's block starts at (g % set) * Cin_g
+        const int shift = d.kind == 3 ? (g % (d.pad_to / d.Cin_g)) * d.Cin_g : 0;
         const float* src = d.src + (int64_t)co * d.s_o + toff;
         const int c0 = (int)inner - shift;
         if (d.s_i == 1 && c0 >= 0 && c0 + 7 < d.Cin_g && (((size_t)(src + c0)) & 15) == 0) {
@@ -1229,12 +1231,13 @@ __device__ __forceinline__ void pack_tile_linear(const octa_pack_desc& d, unsign
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const int c = c0 + e; v[e] = (c >= 0 && c < d.Cin_g) ? src[(int64_t)c * d.s_i] : 0.f; }
         }
-    } else {                                                 // kind 4: [Cin_total][tap][Cout_total <= pad_to], block diagonal
+    } else {                                                 // kind 4: [Cin_total][tap][pad_to = the merged set's output channels], block diagonal
         const int cin = (int)tq, g = cin / d.Cin_g, ci = cin - g * d.Cin_g;
+        const int set = d.pad_to / d.Cout_g;                 // groups merged into one dense block (all of them when pad_to = Cout_total)
         const float* src = d.src + (int64_t)ci * d.s_i + toff;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int co = (int)inner + e, cog = co - g * d.Cout_g;
+            const int co = (g / set) * d.pad_to + (int)inner + e, cog = co - g * d.Cout_g;
             v[e] = (cog >= 0 && cog < d.Cout_g) ? src[(int64_t)co * d.s_o] : 0.f;
         }
     }
@@ -1609,8 +1612,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(const WgradArgs
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-    const bf16_t* __restrict__ xg = (const bf16_t*)a.x + a.xoff + cbase;
-    const bf16_t* __restrict__ dyg = (const bf16_t*)a.dy + a.yoff;
+    // blockIdx.z = channel SET of a grouped layer (a group, or a pair of groups run densely: diagNg/diagCg then count inside the set):
+    // Ctot input and Ntot output channels per set
+    const int zs = blockIdx.z;
+    const bf16_t* __restrict__ xg = (const bf16_t*)a.x + a.xoff + zs * Ctot + cbase;
+    const bf16_t* __restrict__ dyg = (const bf16_t*)a.dy + a.yoff + zs * Ntot;
     const bool do_bias = a.dbias != nullptr && blockIdx.y == 0;
     float bacc = 0.f;
 
@@ -1729,38 +1735,43 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(const WgradArgs
                     if (cg / diagCg != g) continue;
                     ci = cg - g * diagCg;
                 }
-                atomicAdd(a.dw + (int64_t)n * a.s_o + (int64_t)ci * a.s_i + kh * a.s_h + kw * a.s_w, acc[c][tp][e]);
+                atomicAdd(a.dw + (int64_t)(zs * Ntot + n) * a.s_o + (int64_t)ci * a.s_i + kh * a.s_h + kw * a.s_w, acc[c][tp][e]);
             }
         }
     }
-    if (do_bias && t < NT * 16 && t < Ntot) atomicAdd(a.dbias + t, bacc);
+    if (do_bias && t < NT * 16 && t < Ntot) atomicAdd(a.dbias + zs * Ntot + t, bacc);
 }
 
 // eligibility + launch of the halo weight-gradient kernel; returns false when the generic kernel should run
 static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout, hipStream_t st) {
     if (getenv("OCTA_NO_WGRAD_HALO")) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW) return false;
-    int diagNg = 0, diagCg = 0;
-    if (groups > 1) {                                  // only the small-channel grouped layers that also run densified forward
-        if (Cin / groups > 8 || Cout / groups > 16) return false;
-        diagNg = Cout / groups; diagCg = Cin / groups;
+    int diagNg = 0, diagCg = 0, sets = 1, setC = Cin, setN = Cout;
+    if (groups > 1) {
+        const int cg = Cin / groups, ng = Cout / groups;
+        if (cg <= 8 && ng <= 16) { diagNg = ng; diagCg = cg; }               // the small-channel grouped layers that also run densified forward: one dense set
+        else if (getenv("OCTA_NO_WGRAD_SETS")) return false;                   // A/B switch: grouped layers beyond the one-dense-set form take the generic kernel
+        else if (cg == 16 && ng == 32 && groups % 2 == 0) { diagNg = 32; diagCg = 16; sets = groups / 2; setC = 32; setN = 64; }   // pairs of groups (decoder_1's split-attention conv)
+        else if (cg % 32 == 0 && ng <= 64) { sets = groups; setC = cg; setN = ng; }   // one set per group
+        else return false;
     }
-    if (Cout > 64 || Cout % 8 != 0 || Cin % 32 != 0 || Cin > 128) return false;
-    const int NT = (Cout > 32 || Cin % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
+    if (setN > 64 || setN % 8 != 0 || setC % 32 != 0 || setC > 128) return false;
+    const int NT = (setN > 32 || setC % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
     if ((int64_t)a.H * a.W < 128 * 128) return false;  // small images: the generic kernel's split-M has enough reuse per byte
     const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
     if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
     if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;
     const int ntiles = a.B * th * tw;
-    const int ychunks = Cin / (32 * (4 / NT));
-    int nblk = 512 / ychunks;                          // 2 blocks per CU are resident (178 registers): one full round; each block ends
+    const int ychunks = setC / (32 * (4 / NT));
+    int nblk = 512 / (ychunks * sets);                 // 2 blocks per CU are resident (178 registers): one full round; each block ends
                                                        // with up to 18432 atomics (512 beat 1024 / 2048 / 4096 by 6 / 25 / 50 %)
+    if (nblk < 1) nblk = 1;
     if (nblk > ntiles) nblk = ntiles;
     const int tpb = cdiv(ntiles, nblk);
     nblk = cdiv(ntiles, tpb);
-    dim3 grid(nblk, ychunks);
-    if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
-    else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, Cin, Cout, diagNg, diagCg);
+    dim3 grid(nblk, ychunks, sets);
+    if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
+    else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>", NT);
     return true;
 }

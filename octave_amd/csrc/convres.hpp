@@ -48,10 +48,14 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const T* __restrict__ xg = (const T*)a.x + a.xoff;
-    const T* __restrict__ wg = (const T*)a.w;
-    const T* zero = (const T*)octa_zero_page;
+    // grouped layers (round 4): blockIdx.y = group, every group its own set of gridDim.x persistent workgroups with its own resident
+    // operand; workgroup x of every group walks the same tile range and sits on the same XCD (gridDim.x % 8 == 0), so the
+    // groups' slices of one activation line are fetched into that L2 once
+    const int grp = blockIdx.y;
     const int Kelem = TAPS * a.Cg;
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + grp * a.CgStride;
+    const T* __restrict__ wg = (const T*)a.w + (size_t)grp * a.Ng * Kelem;
+    const T* zero = (const T*)octa_zero_page;
 
     // this workgroup's contiguous tile range
     const int G = gridDim.x;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     };
 
     // ---- prologue: bias -> LDS, weights -> LDS (once), the first NST-1 patches
-    if (t < BNR) sBias[t] = (a.bias && t < (a.upshuffle ? a.CoutT : a.Ng)) ? a.bias[t] : 0.f;    // upshuffle: one bias per transposed-conv channel
+    if (t < BNR) sBias[t] = (a.bias && t < (a.upshuffle ? a.CoutT : a.Ng)) ? a.bias[grp * a.Ng + t] : 0.f;    // upshuffle (never grouped): one bias per transposed-conv channel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         const unsigned sW_base = lds_addr(sW);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
 #pragma unroll
     for (int j = 0; j < TM; ++j) prow0[j] = (wave * TM + j) * PW + r;
     const uint4* const pB0 = sW + q * BNR + r;
-    T* __restrict__ yb = (T*)a.y + a.yoff;
+    T* __restrict__ yb = (T*)a.y + a.yoff + grp * a.Ng;
 
     const int dbg = exact >> 8;                    // tools/convres_micro.py ablations: 1 no stores, 2 no MFMA loop, 4 no patch DMA
     exact &= 255;
@@ -359,13 +363,14 @@ static inline int res_lds_bytes(int taps, int nch, int tn) {
 }
 
 template <typename T, int TAPS, int NCH, int TN, int MODE, int NH = 1>
-static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int exact, hipStream_t st) {
+static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int exact, hipStream_t st, int groups = 1) {
     const int per_cu = res_lds_bytes(TAPS, NCH, TN * NH) * 2 <= 160 * 1024 ? 2 : 1;
-    int grid = 256 * per_cu;
+    int grid = octa_num_cus() * per_cu / groups;      // per group; launch_res keeps groups to the divisors of 8 * per_cu
+    if (grid < 8) grid = 8;
     if (const char* e = getenv("OCTA_CONVRES_GRID")) { const int g = atoi(e); if (g > 0) grid = g; }    // tests: many tiles per workgroup
     if (grid > ntiles) grid = ntiles;
     if (const char* e = getenv("OCTA_CONVRES_DBG")) exact |= atoi(e) << 8;
-    conv_res_kernel<T, TAPS, NCH, TN, MODE, NH><<<grid, 512, 0, st>>>(a, ntiles, tx, ty, exact);
+    conv_res_kernel<T, TAPS, NCH, TN, MODE, NH><<<dim3(grid, groups), 512, 0, st>>>(a, ntiles, tx, ty, exact);
 }
 
 // eligibility + launch.  Returns false when another kernel must run.
@@ -373,7 +378,11 @@ template <typename T>
 static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool forced = true) {
     if constexpr (sizeof(T) != 2) return false;
     else {
-        if (groups != 1 || (a.Cg != 32 && a.Cg != 64)) return false;
+        if (a.Cg != 32 && a.Cg != 64) return false;
+        // grouped: whole 64 / 128-byte channel slices per group (the DMA rows and the 16-byte stores stay aligned), 2 / 4 / 8 groups
+        static const bool no_grouped = getenv("OCTA_NO_GROUPED_RES") != nullptr;      // A/B switch
+        if (groups != 1 && no_grouped) return false;
+        if (groups != 1 && (a.upshuffle || a.CgStride != a.Cg || a.Ng % 8 != 0 || a.NgSt != a.Ng || (groups != 2 && groups != 4 && groups != 8))) return false;
         if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 31)) return false;
         if ((int64_t)a.M * (a.upshuffle ? 4 : 1) * (int64_t)a.ldy >= (1ll << 31)) return false;      // 32-bit byte offsets of the deferred stores
         const bool k3 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.upshuffle && a.H == a.OH && a.W == a.OW;
@@ -397,23 +406,23 @@ static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool force
         else ntiles = cdiv(a.M, 256);
         if (k3) {
             if (a.mode == 0) {
-                if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 0>(a, ntiles, tx, ty, exact, st);
-                else if (nch == 1) launch_res_one<T, 9, 1, 2, 0>(a, ntiles, tx, ty, exact, st);
-                else launch_res_one<T, 9, 2, 2, 0>(a, ntiles, tx, ty, exact, st);
+                if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 0>(a, ntiles, tx, ty, exact, st, groups);
+                else if (nch == 1) launch_res_one<T, 9, 1, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
+                else launch_res_one<T, 9, 2, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
             } else {
-                if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 1>(a, ntiles, tx, ty, exact, st);
-                else if (nch == 1) launch_res_one<T, 9, 1, 2, 1>(a, ntiles, tx, ty, exact, st);
-                else launch_res_one<T, 9, 2, 2, 1>(a, ntiles, tx, ty, exact, st);
+                if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 1>(a, ntiles, tx, ty, exact, st, groups);
+                else if (nch == 1) launch_res_one<T, 9, 1, 2, 1>(a, ntiles, tx, ty, exact, st, groups);
+                else launch_res_one<T, 9, 2, 2, 1>(a, ntiles, tx, ty, exact, st, groups);
             }
         } else if (nch == 2) {
-            if (tn == 1) launch_res_one<T, 1, 2, 1, 0>(a, ntiles, tx, ty, exact, st);
-            else if (tn == 2) launch_res_one<T, 1, 2, 2, 0>(a, ntiles, tx, ty, exact, st);
-            else if (tn == 4) launch_res_one<T, 1, 2, 4, 0>(a, ntiles, tx, ty, exact, st);
-            else if (tn == 8) launch_res_one<T, 1, 2, 8, 0>(a, ntiles, tx, ty, exact, st);
-            else launch_res_one<T, 1, 2, 8, 0, 2>(a, ntiles, tx, ty, exact, st);      // 16 n-tiles as two passes of 8 (no spills)
+            if (tn == 1) launch_res_one<T, 1, 2, 1, 0>(a, ntiles, tx, ty, exact, st, groups);
+            else if (tn == 2) launch_res_one<T, 1, 2, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
+            else if (tn == 4) launch_res_one<T, 1, 2, 4, 0>(a, ntiles, tx, ty, exact, st, groups);
+            else if (tn == 8) launch_res_one<T, 1, 2, 8, 0>(a, ntiles, tx, ty, exact, st, groups);
+            else launch_res_one<T, 1, 2, 8, 0, 2>(a, ntiles, tx, ty, exact, st, groups);      // 16 n-tiles as two passes of 8 (no spills)
         } else {
-            if (tn == 2) launch_res_one<T, 1, 1, 2, 0>(a, ntiles, tx, ty, exact, st);
-            else launch_res_one<T, 1, 1, 4, 0>(a, ntiles, tx, ty, exact, st);
+            if (tn == 2) launch_res_one<T, 1, 1, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
+            else launch_res_one<T, 1, 1, 4, 0>(a, ntiles, tx, ty, exact, st, groups);
         }
         note_kernel<T>(k3 ? "conv_res3x3_kernel" : "conv_res1x1_kernel", 256, tn * 16);
         return true;

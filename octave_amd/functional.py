@@ -536,7 +536,7 @@ def _choose_algo(kind: str, d, launch) -> int:
     cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
     if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
         cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
-    if kind != "dgrad_add" and cg in (32, 64) and d.groups == 1 and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
+    if kind != "dgrad_add" and cg in (32, 64) and d.groups in (1, 2, 4, 8) and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
     if cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
         cands += [9, 10, 11]        # persistent pointwise GEMM (pwgemm.hpp): 256x128, 128x256, 128x128 tiles, cross-tile pipelined
@@ -627,15 +627,25 @@ def _conv_input(x: Tensor, cin_g_pad: int, groups: int) -> Tuple[Tensor, int]:
     return x, ld
 
 
-def _densify(groups: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int, H: int, W: int, dtype) -> bool:
-    """Small-channel grouped 3x3/s1/p1 layers at high resolution (decoder_0's split-attention conv: 32 -> 64, groups 4,
-    400x400) are loader-bound on the grouped gather kernel: each group re-reads its 16-byte slice of every pixel for 9
-    taps.  Run as ONE dense conv with block-diagonal weights they go through the halo-reuse kernel (pixel patch loaded
-    once, 4x the MFMA work, which is free here) - 2-3x faster.  Algorithmic FLOPs are still counted with the groups."""
+def _densify(groups: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int, H: int, W: int, dtype) -> int:
+    """Small-channel grouped 3x3/s1/p1 layers at high resolution are loader-bound on the grouped gather kernel: each group
+    re-reads its 16/32-byte slice of every pixel for 9 taps (and the groups' workgroups fetch every activation line once each).
+    Returns the number of adjacent groups to MERGE into one dense block with block-diagonal weights (0 = run as is), so that
+    a merged group has 32 input channels and the halo-reuse / resident-weight kernels take the layer (pixel patch loaded once;
+    the extra MFMA work is free on these HBM-bound layers): decoder_0's split-attention conv (32 -> 64, groups 4, 400x400)
+    becomes ONE dense conv (2-3x faster), decoder_1's (64 -> 128, groups 4, 200x200: 16 -> 32 per group) a conv with two
+    groups of 32 -> 64 (round 4).  Algorithmic FLOPs are still counted with the real groups."""
     if groups == 1 or (KH, KW, stride, pad) != (3, 3, 1, 1) or os.environ.get("OCTA_NO_DENSIFY") == "1":
-        return False
+        return 0
     ck = 16 if dtype == torch.float32 else 32
-    return Cin // groups <= 8 and Cout // groups <= 16 and Cin % ck == 0 and Cout % ck == 0 and H * W >= 128 * 128
+    cg, ng = Cin // groups, Cout // groups
+    if not (Cin % ck == 0 and Cout % ck == 0 and H * W >= 128 * 128):
+        return 0
+    if cg <= 8 and ng <= 16:
+        return groups                                   # everything into one dense conv
+    if cg == 16 and ng == 32 and groups % 2 == 0 and dtype != torch.float32 and os.environ.get("OCTA_NO_DENSIFY_PAIRS") != "1":
+        return 2                                        # pairs: groups / 2 groups of 32 -> 64
+    return 0
 
 
 def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, groups: int, act: int = ACT_NONE,
@@ -647,10 +657,11 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
     zp = out is None and groups == 1 and Cout % 8 != 0       # the kernel zero-fills the padding channels itself
     y = out if out is not None else nhwc_empty(B, Cout, OH, OW, x.dtype, x.device, pad_written=zp)
     ldy = nhwc_ld(y)
-    if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, x.dtype):
-        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, ldx, ldy, x.dtype, act)
+    merge = _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, x.dtype)
+    if merge:
+        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups // merge, ldx, ldy, x.dtype, act)
         d.alg_groups = groups
-        wp = _packed(w, "fwd_dense", x.dtype, groups, d.cin_g_pad)
+        wp = _packed(w, "fwd_dense", x.dtype, groups, d.cin_g_pad)       # pad_to = merge * Cin/groups: the merged set's dense inner axis
     else:
         d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, x.dtype, act)
         d.zero_pad = int(zp)
@@ -688,8 +699,9 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
     col2im = stride > 1 and groups == 1 and (Cin * KH * KW) % 8 == 0
     zp = groups == 1 and Cin % 8 != 0 and not col2im
     dx = nhwc_empty(B, Cin, H, W, dy.dtype, dy.device, pad_written=zp or col2im)      # octa_col2im stores the pad channels too
-    if _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, dy.dtype):
-        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, 1, nhwc_ld(dx), ldy, dy.dtype)
+    merge = _densify(groups, Cin, Cout, KH, KW, stride, pad, H, W, dy.dtype)
+    if merge:
+        d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups // merge, nhwc_ld(dx), ldy, dy.dtype)
         d.alg_groups = groups
         wt = _packed(w, "dgrad_dense", dy.dtype, groups, d.cout_g_pad)
         _launch_dgrad(d, dy, wt, dx)

@@ -86,6 +86,8 @@ CONV_CASES = [
     (256, 512, 1, 1, 0, 1, 8, 6, 6),     # shortcut 1x1 after the 2x2 average pool
     (128, 256, 3, 1, 1, 2, 8, 12, 12),   # its split-attention conv
     (32, 64, 3, 1, 1, 4, 1, 130, 140),   # decoder_0 SplAt conv at high resolution: densified (block-diagonal) halo path
+    (64, 128, 3, 1, 1, 4, 1, 130, 140),  # decoder_1 SplAt conv at high resolution: pairs of groups merged (two groups of 32 -> 64), halo wgrad with channel sets
+    (128, 128, 3, 1, 1, 2, 1, 128, 144), # grouped halo weight gradient, one channel set per group (64 -> 64 per group)
     (64, 32, 3, 1, 1, 1, 1, 130, 140),   # halo weight-gradient kernel, N <= 32 (two channel chunks per block), partial tiles
     (128, 64, 3, 1, 1, 1, 1, 128, 136),  # halo weight-gradient kernel, N <= 64, four channel-chunk blocks
     (32, 48, 3, 1, 1, 1, 2, 128, 128),   # halo weight-gradient kernel, N = 48 (partial n-tile), batch 2
@@ -379,6 +381,7 @@ FULL_SIZE_CONVS = [
     # Cin, Cout, k, s, p, g, B, H, W                     the kernels this shape goes through
     (64, 32, 3, 1, 1, 1, 16, 400, 400),    # decoder_0 3x3: halo fwd/dgrad 128x32 / 128x64, halo weight-gradient kernel <2>
     (32, 64, 3, 1, 1, 4, 16, 400, 400),    # decoder_0 split-attention conv: densified block-diagonal fwd/dgrad, halo wgrad <4> (diagonal)
+    (64, 128, 3, 1, 1, 4, 16, 200, 200),   # decoder_1 split-attention conv: pair-merged grouped resident-weight fwd/dgrad, halo wgrad <4> over two channel sets
     (2, 64, 4, 2, 1, 1, 16, 400, 400),     # discriminator stack_0: generic 256x64, strided dgrad = GEMM + col2im
     (64, 32, 1, 1, 0, 1, 16, 400, 400),    # decoder_0 shortcut 1x1
 ]
@@ -827,6 +830,62 @@ def test_resident_weight_conv_vs_torch(dev, case, grid, dtype, monkeypatch):
         xr = x.clone().requires_grad_(True)
         torch.nn.functional.conv2d(xr, w, None, 1, p).backward(dy)
         check(f"res dgrad {case}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
+GROUPED_RES_CASES = [
+    # B, Cin, H, W, Cout, k, pad, groups : grouped layers on the resident-weight kernel (blockIdx.y = group; round 4)
+    (2, 64, 100, 97, 128, 3, 1, 2),     # encoder_2's split-attention conv: 32 -> 64 per group; its data gradient gathers 64 -> 32
+    (2, 128, 70, 90, 128, 3, 1, 4),     # 32 -> 32 per group, four groups
+    (2, 128, 90, 110, 64, 1, 0, 2),     # pointwise, 64 -> 32 per group
+    (1, 64, 130, 140, 128, 3, 1, 4),    # decoder_1's split-attention conv (16 -> 32 per group): pairs of groups merged into 32 -> 64 blocks
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("grid", [0, 3])
+@pytest.mark.parametrize("case", GROUPED_RES_CASES)
+def test_grouped_resident_weight_conv_vs_torch(dev, case, grid, dtype, monkeypatch):
+    """Grouped forward (+bias) / data gradient on convres.hpp (algo 7) against torch's CPU conv on the same rounded operands,
+    and -- for the 16 -> 32-per-group layer -- the weight gradient of the pair-merged layer (conv3x3_wgrad_halo with channel sets)."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, k, p, g = case
+    if grid:
+        monkeypatch.setenv("OCTA_CONVRES_GRID", str(grid))
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    dy = torch.randn(B, Cout, H, W, generator=gen).to(dtype).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = torch.nn.functional.conv2d(xr, wr, bias, 1, p, 1, g)
+    want.backward(dy)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    dyd = F_.to_nhwc(dy.to(dev), dtype=dtype)
+    t = TOL[dtype]
+    merged = Cin // g == 16
+    assert bool(F_._densify(g, Cin, Cout, k, k, 1, p, H, W, dtype)) == merged
+    F_._ALGO_OVERRIDE = 7
+    try:
+        y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, p, g)
+        assert "conv_res" in lib().octa_last_conv_kernel().decode(), lib().octa_last_conv_kernel().decode()
+        dx = F_.raw_conv_dgrad(dyd, wd, (B, Cin, H, W), 1, p, g)
+        assert "conv_res" in lib().octa_last_conv_kernel().decode(), lib().octa_last_conv_kernel().decode()
+    finally:
+        F_._ALGO_OVERRIDE = 0
+    check(f"grouped res fwd {case}", y, want.detach(), t["rtol"], t["atol"] * float(want.detach().abs().max()))
+    check(f"grouped res dgrad {case}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+    if merged:
+        # the same layer through the library's own kernel choice (no override), and its weight gradient
+        y0 = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, p, g)
+        dx0 = F_.raw_conv_dgrad(dyd, wd, (B, Cin, H, W), 1, p, g)
+        check(f"merged fwd {case}", y0, want.detach(), t["rtol"], t["atol"] * float(want.detach().abs().max()))
+        check(f"merged dgrad {case}", dx0, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+        dw = F_.raw_conv_wgrad(xd, dyd, wd, 1, p, g)
+        if dtype == torch.bfloat16:
+            assert "wgrad_halo" in lib().octa_last_conv_kernel().decode(), lib().octa_last_conv_kernel().decode()
+        check(f"merged wgrad {case}", dw, wr.grad, t["rtol"], t["atol"] * float(wr.grad.abs().max()) * 4)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16])
