@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 307
+#define OCTA_HIP_ABI_VERSION 308
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -178,6 +178,16 @@ int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, octa_stream_
  * that one call = one family).
  * Not a status code. */
 size_t octa_wgrad_job_class(const octa_wgrad_job* job_host);
+/* Optional scratch for the single-problem weight-gradient kernel (round 4): with `ws` (caller-owned, `bytes` long, 16-byte
+ * aligned; 128 MB covers a batch of every layer of the path) registered, the M-splits of a 16-bit job store raw fp32 tiles into
+ * private slices of `ws` instead of adding into dw with float atomics (384-512 workgroups adding into the same few KB were
+ * half of the few-channel layers' time), and ONE fold launch per octa_conv2d_wgrad_batch call (per octa_conv2d_wgrad call
+ * outside a batch) sums the slices in a fixed order and adds the result to dw / dbias: same += semantics, deterministic.  A
+ * job whose slices do not fit what is left of `ws` in the current batch keeps the atomic epilogue.  NULL / 0 withdraws it.
+ * Like octa_conv_splitk_workspace the registration is process-wide and read when a weight gradient is LAUNCHED: launches
+ * that may run concurrently on different streams need different scratch buffers (register the other one around them)
+ * (discriminator/blocks.py:46,97, extra/resnest.py:325-334: the few-channel layers this is for). */
+int octa_wgrad_fold_workspace(float* ws, int64_t bytes);
 /* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
  * call dispatched, e.g. "conv_igemm_kernel<bf16,128x128>", "conv3x3_halo_kernel<bf16,128x64>",
  * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline

@@ -15,6 +15,8 @@ void octa_set_error(const char* fmt, ...);
 #define OCTA_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
     octa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return OCTA_ERR_LAUNCH; } } while (0)
 
+bool octa_wgrad_fold_begin(hipStream_t st);      // conv.hip: fold session of the partial-store weight gradients (true: this call opened it)
+int octa_wgrad_fold_end();
 void octa_note_conv_kernel(const char* name);   // conv.hip: name reported by octa_last_conv_kernel()
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

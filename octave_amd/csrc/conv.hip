@@ -1361,6 +1361,12 @@ struct WgradArgs {
     int64_t s_o, s_i, s_h, s_w; // strides of the fp32 gradient tensor, OIHW-logical
     int splitM, mPerSplit;
     float* dbias;               // optional: dbias[cout] += column sums of dy (fused bias gradient)
+    // partial-store mode (round 4): part != NULL -> every M-split writes its raw fp32 tile to its own slice
+    // part[sp * part_slice + (g*Ng + n) * Kpad + k] (bias column sums behind the Ntot*Kpad block) with plain stores instead of adding
+    // into dw with float atomics; wgrad_fold_kernel sums the slices in a fixed order (octa_wgrad_fold_workspace)
+    float* part;
+    int64_t part_slice;
+    int NtotPart;               // groups * Ng
 };
 
 template <typename T> struct WgLds;
@@ -1559,8 +1565,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         if (t < BNn && n0 + t < a.Ng) {
             float v = 0.f;
             for (int rr = 0; rr < 256 / PCPR; ++rr) v += red[rr * BNn + t];
-            atomicAdd(a.dbias + g * a.Ng + n0 + t, v);
+            if (a.part) a.part[(int64_t)sp * a.part_slice + (int64_t)a.NtotPart * a.Kpad + g * a.Ng + n0 + t] = v;
+            else atomicAdd(a.dbias + g * a.Ng + n0 + t, v);
         }
+    }
+    if (a.part) {
+        // raw partial tile -> this split's slice: 16 lanes (r) write 64 contiguous bytes of row n
+        float* const ps = a.part + (int64_t)sp * a.part_slice;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + (wk * TK + j) * 16 + r;
+            if (k >= a.Kpad) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + (wn * TN + i) * 16 + q * 4 + e;
+                    if (n < a.Ng) ps[(int64_t)(g * a.Ng + n) * a.Kpad + k] = acc[i][j][e];
+                }
+            }
+        }
+        return;
     }
     // D[row = n (q*4+e)][col = k (r)]
 #pragma unroll
@@ -1776,6 +1801,106 @@ static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout,
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fold of the partial-store weight gradients (round 4).  The few-channel layers' whole gradient is a few KB..MB and every one of
+// the 384-512 M-split workgroups used to add its tile into the SAME addresses with float atomics -- half of those kernels' time
+// (DESIGN.md 9.2(b)).  With a caller-owned scratch registered (octa_wgrad_fold_workspace) the splits store raw
+// tiles into private slices and ONE fold launch per batch of layers (octa_conv2d_wgrad_batch; a lone octa_conv2d_wgrad: one per
+// call) sums the slices in a fixed order and adds the result to dw / dbias: no atomics, deterministic.
+// ------------------------------------------------------------------------------------------
+struct WgFoldJob {
+    const float* part; float* dw; float* dbias;
+    int64_t slice, s_o, s_i, s_h, s_w;
+    int split, Ntot, Kpad, Cg, CgReal, KW, blockStart, nblocks;
+};
+#define OCTA_WGFOLD_MAX 16
+struct WgFoldBatch { int n; WgFoldJob j[OCTA_WGFOLD_MAX]; };
+
+// block = 64 elements x 4 split lanes; element e of slice sp: part[sp * slice + e]
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgFoldBatch fb) {
+    __shared__ float red[4][64];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < fb.n; ++i) if ((int)blockIdx.x >= fb.j[i].blockStart) ji = i;
+    const WgFoldJob& J = fb.j[ji];
+    const int el = (blockIdx.x - J.blockStart) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int nW = J.Ntot * J.Kpad, total = nW + (J.dbias ? J.Ntot : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (el < total) {
+        const float* p = J.part + el;
+        int sp = sl;
+        for (; sp + 12 < J.split; sp += 16) {
+            s0 += p[(int64_t)sp * J.slice]; s1 += p[(int64_t)(sp + 4) * J.slice];
+            s2 += p[(int64_t)(sp + 8) * J.slice]; s3 += p[(int64_t)(sp + 12) * J.slice];
+        }
+        for (; sp < J.split; sp += 4) s0 += p[(int64_t)sp * J.slice];
+    }
+    red[sl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || el >= total) return;
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (el >= nW) { J.dbias[el - nW] += v; return; }
+    const int n = el / J.Kpad, k = el - n * J.Kpad;
+    const int tap = k / J.Cg, ci = k - tap * J.Cg;
+    if (ci >= J.CgReal) return;
+    const int kh = tap / J.KW, kw = tap - kh * J.KW;
+    J.dw[(int64_t)n * J.s_o + (int64_t)ci * J.s_i + kh * J.s_h + kw * J.s_w] += v;
+}
+
+// the registered scratch (process-wide, read when a session opens) + the open fold session of the calling host thread
+static float* g_fold_ws = nullptr;
+static int64_t g_fold_ws_floats = 0;
+static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; } g_fold = {};
+
+extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
+    OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_wgrad_fold_workspace: 16-byte aligned buffer, or NULL / 0");
+    g_fold_ws = bytes > 0 ? ws : nullptr;
+    g_fold_ws_floats = g_fold_ws ? bytes / 4 : 0;
+    return OCTA_OK;
+}
+static int wgrad_fold_flush() {
+    if (g_fold.fb.n > 0) {
+        wgrad_fold_kernel<<<g_fold.nblk, 256, 0, g_fold.st>>>(g_fold.fb);
+        OCTA_CHECK_LAUNCH("wgrad_fold");
+        g_fold.fb.n = 0; g_fold.nblk = 0;
+    }
+    return OCTA_OK;
+}
+// open a session on `st` (nested opens are counted as the outer one); returns true when this call opened it
+bool octa_wgrad_fold_begin(hipStream_t st) {
+    if (g_fold.open) return false;
+    static const bool off = getenv("OCTA_NO_WGRAD_FOLD") != nullptr;
+    g_fold.ws = nullptr; g_fold.cap = 0;
+    if (!off) { g_fold.ws = g_fold_ws; g_fold.cap = g_fold_ws_floats; }
+    g_fold.open = true; g_fold.st = st; g_fold.used = 0; g_fold.fb.n = 0; g_fold.nblk = 0;
+    return true;
+}
+int octa_wgrad_fold_end() {
+    g_fold.open = false;
+    return wgrad_fold_flush();
+}
+// scratch for `split` slices of (Ntot*Kpad + Ntot) floats, or NULL (no session / no room: the atomic epilogue runs)
+static float* wgrad_fold_take(const WgradArgs& a, int groups, int split, int64_t& slice) {
+    if (!g_fold.open || !g_fold.ws || split < 2) return nullptr;
+    slice = ((int64_t)groups * a.Ng * (a.Kpad + 1) + 3) / 4 * 4;
+    const int64_t need = slice * split;
+    if (need > g_fold.cap - g_fold.used || need * 4 > (48ll << 20)) return nullptr;      // (a job beyond 48 MB of partials keeps its atomics)
+    float* p = g_fold.ws + g_fold.used;
+    g_fold.used += need;
+    return p;
+}
+static int wgrad_fold_add(const WgradArgs& a, int groups, int split) {
+    if (g_fold.fb.n == OCTA_WGFOLD_MAX) { const int rc = wgrad_fold_flush(); if (rc) return rc; }
+    WgFoldJob& J = g_fold.fb.j[g_fold.fb.n++];
+    J.part = a.part; J.dw = a.dw; J.dbias = a.dbias; J.slice = a.part_slice;
+    J.s_o = a.s_o; J.s_i = a.s_i; J.s_h = a.s_h; J.s_w = a.s_w;
+    J.split = split; J.Ntot = groups * a.Ng; J.Kpad = a.Kpad; J.Cg = a.Cg; J.CgReal = a.CgReal; J.KW = a.KW;
+    J.blockStart = g_fold.nblk;
+    J.nblocks = cdiv(J.Ntot * (J.Kpad + (a.dbias ? 1 : 0)), 64);
+    g_fold.nblk += J.nblocks;
+    return OCTA_OK;
+}
+
 template <typename T>
 static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     constexpr int MT = WgLds<T>::MT;
@@ -1799,6 +1924,11 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     mps = cdiv(mps, MT) * MT;
     split = cdiv(a.M, mps);
     a.splitM = split; a.mPerSplit = mps;
+    a.part = nullptr; a.part_slice = 0; a.NtotPart = groups * a.Ng;
+    if (sizeof(T) == 2 && g_fold.open && g_fold.st == st) {
+        a.part = wgrad_fold_take(a, groups, split, a.part_slice);
+        if (a.part) { const int rc = wgrad_fold_add(a, groups, split); if (rc) return rc; }
+    }
     dim3 grid(tilesK, tilesN, groups * split), block(256);
     static const int sub_env = getenv("OCTA_WGRAD_SUB") ? atoi(getenv("OCTA_WGRAD_SUB")) : 2;
     const bool sub2 = sizeof(T) == 2 && sub_env == 2 && mps >= 8 * MT;      // two sub-tiles per barrier (64 KB of LDS: two workgroups per CU)
@@ -1815,6 +1945,7 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
         else conv_wgrad_kernel<T, 1, 4, 2, 2><<<grid, block, 0, st>>>(a);
     }
     note_kernel<T>("conv_wgrad_kernel", bnn, 0);
+    if (a.part) strncat(g_last_kernel, "+fold", sizeof(g_last_kernel) - strlen(g_last_kernel) - 1);
     OCTA_CHECK_LAUNCH("conv_wgrad");
     return OCTA_OK;
 }
@@ -1843,9 +1974,12 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
         OCTA_CHECK_LAUNCH("conv3x3_wgrad_halo");
         return OCTA_OK;
     }
-    return d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
-         : d->dtype == OCTA_BF16 ? launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream)
-                                 : launch_wgrad<f16_t>(a, d->groups, (hipStream_t)stream);
+    const bool mine = octa_wgrad_fold_begin((hipStream_t)stream);     // a lone call folds by itself; inside octa_conv2d_wgrad_batch the batch does
+    rc = d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
+       : d->dtype == OCTA_BF16 ? launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream)
+                               : launch_wgrad<f16_t>(a, d->groups, (hipStream_t)stream);
+    if (mine) { const int rc2 = octa_wgrad_fold_end(); if (!rc) rc = rc2; }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -773,6 +773,13 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
     static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
     hipStream_t st = (hipStream_t)stream;
     std::vector<WgPlan> plans[2][3];   // [f16][variant]
+    // the per-layer jobs of the batch share one fold session: their partial tiles are summed by ONE fold launch (conv.hip)
+    struct FoldSession {
+        bool mine;
+        explicit FoldSession(hipStream_t s) : mine(octa_wgrad_fold_begin(s)) {}
+        ~FoldSession() { if (mine) octa_wgrad_fold_end(); }
+        int close() { const bool m = mine; mine = false; return m ? octa_wgrad_fold_end() : OCTA_OK; }
+    } fold(st);
     for (int i = 0; i < n; ++i) {
         const octa_wgrad_job& j = jobs[i];
         if (off || !wg8_eligible(j)) {
@@ -799,6 +806,7 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
         p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0;
         plans[d.dtype == OCTA_F16 ? 1 : 0][pl.variant].push_back(pl);
     }
+    { const int rc = fold.close(); if (rc) return rc; }
     for (int v = 0; v < 2; ++v) {
         if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
         if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }

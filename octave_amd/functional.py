@@ -192,6 +192,25 @@ def _zeroed_f32(shape, device):
 _SPLITK_WS = None
 
 
+_WGRAD_FOLD_WS = None
+
+
+def set_wgrad_fold_workspace(ws: Optional[Tensor]):
+    """Register (None: withdraw) the fp32 scratch of octa_wgrad_fold_workspace: the single-problem weight-gradient kernels then
+    store private partial tiles and one fold launch per batch adds them to the gradient -- no float atomics, deterministic.
+    Read when a weight gradient is launched; phases that run concurrently on two streams register different buffers."""
+    global _WGRAD_FOLD_WS
+    if ws is None:
+        if _WGRAD_FOLD_WS is not None:
+            lib().octa_wgrad_fold_workspace(None, 0)
+        _WGRAD_FOLD_WS = None
+        return
+    if ws.dtype != torch.float32 or not ws.is_contiguous():
+        raise OctaError("set_wgrad_fold_workspace: contiguous fp32 tensor")
+    lib().octa_wgrad_fold_workspace(_p(ws), ws.numel() * 4)
+    _WGRAD_FOLD_WS = ws
+
+
 def set_splitk_workspace(ws: Optional[Tensor]):
     """Register (None: withdraw) the fp32 scratch octa_conv_splitk_workspace describes.  Read when a conv is launched: a training
     step registers it around the segmentor's launches and withdraws it around launches issued for another stream."""

@@ -425,6 +425,12 @@ class TrainStep:
         # 64 MB of fp32 scratch for the 8-wave conv kernel's tail split (octa_conv_splitk_workspace): the 25 x 25 / 50 x 50 decoder
         # layers launch 316 / 626 tiles on 256 CUs
         self._sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=next(net.parameters()).device) if os.environ.get("OCTA_SPLITK", "1") != "0" else None
+        # scratch of the partial-store weight gradients (octa_wgrad_fold_workspace): one per phase, because the discriminator's step
+        # replays on a second stream beside the segmentor's backward pass.  The largest batch of single-problem jobs needs ~90 MB.
+        fold_on = os.environ.get("OCTA_WGRAD_FOLD", "1") != "0"
+        dev0 = next(net.parameters()).device
+        self._fold_ws = torch.empty(32 << 20, dtype=torch.float32, device=dev0) if fold_on else None
+        self._fold_ws_disc = torch.empty(32 << 20, dtype=torch.float32, device=dev0) if (fold_on and self.adversarial) else None
         self._disc_slab = F_._ZeroSlab(2 << 20)
         # replay mode: the discriminator's own step (it needs the attention maps, not the segmentor's gradients) on a second stream
         # beside the segmentor's backward pass -- a chain of ~200 launch-latency-bound kernels that otherwise costs 3 ms on its own
@@ -514,10 +520,12 @@ class TrainStep:
         # phase only (withdrawn in the finally below), so that a conv launched on another stream between steps -- a validation
         # forward, a second TrainStep -- never shares the partial-tile workspace
         F_.set_splitk_workspace(self._sk_ws)
+        F_.set_wgrad_fold_workspace(self._fold_ws)
         try:
             return self._phase_segmentor_body(x, ys, out, disc, hooks, between)
         finally:
             F_.set_splitk_workspace(None)
+            F_.set_wgrad_fold_workspace(None)
 
     def _phase_segmentor_body(self, x, ys, out, disc, hooks, between):
         self.seg_arena.zero_grad()
@@ -578,12 +586,14 @@ class TrainStep:
                 F_.ZERO_SLAB.begin(self.disc_arena.g.device)
                 began = True
                 F_.set_splitk_workspace(None)          # (same reason: one scratch, two streams)
+                F_.set_wgrad_fold_workspace(self._fold_ws_disc)
                 d_real = disc(real_pyramid)
                 d_fake = disc(att)
                 l_d = F_.lsgan_discriminator(d_real, d_fake)
                 self._scaled(l_d).backward()
                 F_.flush_wgrads()
             finally:
+                F_.set_wgrad_fold_workspace(None)
                 if began:
                     F_.ZERO_SLAB.end()
                 F_.ZERO_SLAB = seg_slab
@@ -961,6 +971,7 @@ class TrainStep:
         F_.set_grad_sink(False)
         F_.defer_wgrads(False)
         F_.set_splitk_workspace(None)
+        F_.set_wgrad_fold_workspace(None)
         F_.clear_mark_hooks()
         defer_bn_counters(False)
         for d in self.discs.values():

@@ -832,6 +832,62 @@ def test_resident_weight_conv_vs_torch(dev, case, grid, dtype, monkeypatch):
         check(f"res dgrad {case}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
+FOLD_CASES = [
+    # Cin, Cout, k, s, p, g, B, H, W, bias : the few-channel weight gradients (partial tiles + fold, octa_wgrad_fold_workspace)
+    (2, 64, 4, 2, 1, 1, 2, 96, 96, True),       # discriminator stack_0
+    (3, 32, 3, 2, 1, 1, 2, 80, 72, False),      # stem
+    (64, 13, 1, 1, 0, 1, 2, 50, 44, True),      # squeeze conv (13 output channels)
+    (15, 128, 4, 2, 1, 1, 2, 48, 48, True),     # spectral conv, padded input channels
+    (64, 128, 3, 1, 1, 2, 2, 40, 36, False),    # grouped (encoder_2's split-attention conv)
+    (64, 32, 1, 1, 0, 1, 1, 120, 100, False),   # decoder_0 shortcut
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_wgrad_partial_tiles_and_fold_vs_torch(dev, case, dtype):
+    """conv_wgrad_kernel in partial-store mode + wgrad_fold_kernel against torch's CPU gradient on the same rounded operands:
+    += semantics (the gradient buffer starts non-zero), bias gradient, padded channels, groups; bit-identical from run to run
+    (fixed summation order), and within rounding of the float-atomic epilogue it replaces."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    Cin, Cout, k, s_, p_, g, B, H, W, with_bias = case
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, k, k, generator=gen) * 0.1)
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    br = torch.zeros(Cout, requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, wr, br, s_, p_, 1, g)
+    dy = torch.randn(tuple(y.shape), generator=gen).to(dtype).float()
+    y.backward(dy)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    dyd = F_.to_nhwc(dy.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+
+    def run(fold):
+        F_.set_wgrad_fold_workspace(ws if fold else None)
+        try:
+            dw = torch.full((Cout, k, k, Cin // g), 0.25, dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+            db = torch.full((Cout,), -0.5, dtype=torch.float32, device=dev) if with_bias else None
+            F_.raw_conv_wgrad(xd, dyd, wd, s_, p_, g, dw=dw, dbias=db)
+            name = lib().octa_last_conv_kernel().decode()
+        finally:
+            F_.set_wgrad_fold_workspace(None)
+        return dw, db, name
+    dw1, db1, n1 = run(True)
+    dw2, db2, n2 = run(True)
+    dw0, db0, n0 = run(False)
+    assert n1.endswith("+fold") and "conv_wgrad_kernel" in n1 and not n0.endswith("+fold"), (n1, n0)
+    assert torch.equal(dw1, dw2) and (db1 is None or torch.equal(db1, db2)), "fold is not deterministic"
+    t = TOL[dtype]
+    sc = float(wr.grad.abs().max())
+    check(f"fold wgrad {case}", dw1 - 0.25, wr.grad, t["rtol"], t["atol"] * sc * 4)
+    check(f"fold vs atomics {case}", dw1, dw0, 1e-4, 1e-4 * sc)
+    if with_bias:
+        check(f"fold bias grad {case}", db1 + 0.5, br.grad, t["rtol"], t["atol"] * float(br.grad.abs().max()) * 4)
+
+
 GROUPED_RES_CASES = [
     # B, Cin, H, W, Cout, k, pad, groups : grouped layers on the resident-weight kernel (blockIdx.y = group; round 4)
     (2, 64, 100, 97, 128, 3, 1, 2),     # encoder_2's split-attention conv: 32 -> 64 per group; its data gradient gathers 64 -> 32
