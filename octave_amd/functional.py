@@ -794,7 +794,9 @@ def flush_wgrads(min_jobs: int = 1) -> int:
     st = _st()
     for cls in sorted(groups):
         jobs = groups[cls]
-        if cls == 0:
+        if cls == 0 and (_RECORD is not None or len(jobs) == 1):
+            # (recording tools want one entry per layer; otherwise the single-problem jobs travel as one batch too, so that their
+            # partial tiles are folded by ONE launch: octa_wgrad_fold_workspace)
             for j, keep in jobs:
                 L.octa_conv2d_wgrad(ctypes.byref(j.d), j.x, j.dy, j.dw, j.dw_strides, j.dbias, st)
                 _record("wgrad", j.d, (j.x, j.dy, keep[2], keep[3]), keep)
