@@ -1742,6 +1742,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(const WgradArgs
         }
     }
     if (t0 >= t1) return;
+    // partial-store mode (wgrad_fold_kernel): slice blockIdx.x, element (n_global, k = tap * Cg + ci) with ci counted inside the conv's group
+    float* const ps = a.part ? a.part + (int64_t)blockIdx.x * a.part_slice : nullptr;
     // D[row = n (q*4+e)][col = c (r)]
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1760,45 +1762,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(const WgradArgs
                     if (cg / diagCg != g) continue;
                     ci = cg - g * diagCg;
                 }
-                atomicAdd(a.dw + (int64_t)(zs * Ntot + n) * a.s_o + (int64_t)ci * a.s_i + kh * a.s_h + kw * a.s_w, acc[c][tp][e]);
+                if (ps) ps[(int64_t)(zs * Ntot + n) * a.Kpad + tp * a.Cg + ci] = acc[c][tp][e];
+                else atomicAdd(a.dw + (int64_t)(zs * Ntot + n) * a.s_o + (int64_t)ci * a.s_i + kh * a.s_h + kw * a.s_w, acc[c][tp][e]);
             }
         }
     }
-    if (do_bias && t < NT * 16 && t < Ntot) atomicAdd(a.dbias + zs * Ntot + t, bacc);
-}
-
-// eligibility + launch of the halo weight-gradient kernel; returns false when the generic kernel should run
-static bool launch_wgrad_halo(const WgradArgs& a, int groups, int Cin, int Cout, hipStream_t st) {
-    if (getenv("OCTA_NO_WGRAD_HALO")) return false;
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW) return false;
-    int diagNg = 0, diagCg = 0, sets = 1, setC = Cin, setN = Cout;
-    if (groups > 1) {
-        const int cg = Cin / groups, ng = Cout / groups;
-        if (cg <= 8 && ng <= 16) { diagNg = ng; diagCg = cg; }               // the small-channel grouped layers that also run densified forward: one dense set
-        else if (getenv("OCTA_NO_WGRAD_SETS")) return false;                   // A/B switch: grouped layers beyond the one-dense-set form take the generic kernel
-        else if (cg == 16 && ng == 32 && groups % 2 == 0) { diagNg = 32; diagCg = 16; sets = groups / 2; setC = 32; setN = 64; }   // pairs of groups (decoder_1's split-attention conv)
-        else if (cg % 32 == 0 && ng <= 64) { sets = groups; setC = cg; setN = ng; }   // one set per group
-        else return false;
+    if (do_bias && t < NT * 16 && t < Ntot) {
+        if (ps) ps[(int64_t)a.NtotPart * a.Kpad + zs * Ntot + t] = bacc;
+        else atomicAdd(a.dbias + zs * Ntot + t, bacc);
     }
-    if (setN > 64 || setN % 8 != 0 || setC % 32 != 0 || setC > 128) return false;
-    const int NT = (setN > 32 || setC % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
-    if ((int64_t)a.H * a.W < 128 * 128) return false;  // small images: the generic kernel's split-M has enough reuse per byte
-    const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
-    if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
-    if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;
-    const int ntiles = a.B * th * tw;
-    const int ychunks = setC / (32 * (4 / NT));
-    int nblk = 512 / (ychunks * sets);                 // 2 blocks per CU are resident (178 registers): one full round; each block ends
-                                                       // with up to 18432 atomics (512 beat 1024 / 2048 / 4096 by 6 / 25 / 50 %)
-    if (nblk < 1) nblk = 1;
-    if (nblk > ntiles) nblk = ntiles;
-    const int tpb = cdiv(ntiles, nblk);
-    nblk = cdiv(ntiles, tpb);
-    dim3 grid(nblk, ychunks, sets);
-    if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
-    else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>", NT);
-    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1901,6 +1873,47 @@ static int wgrad_fold_add(const WgradArgs& a, int groups, int split) {
     return OCTA_OK;
 }
 
+// eligibility + launch of the halo weight-gradient kernel; returns false when the generic kernel should run
+static bool launch_wgrad_halo(WgradArgs& a, int groups, int Cin, int Cout, hipStream_t st) {
+    if (getenv("OCTA_NO_WGRAD_HALO")) return false;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW) return false;
+    int diagNg = 0, diagCg = 0, sets = 1, setC = Cin, setN = Cout;
+    if (groups > 1) {
+        const int cg = Cin / groups, ng = Cout / groups;
+        if (cg <= 8 && ng <= 16) { diagNg = ng; diagCg = cg; }               // the small-channel grouped layers that also run densified forward: one dense set
+        else if (getenv("OCTA_NO_WGRAD_SETS")) return false;                   // A/B switch: grouped layers beyond the one-dense-set form take the generic kernel
+        else if (cg == 16 && ng == 32 && groups % 2 == 0) { diagNg = 32; diagCg = 16; sets = groups / 2; setC = 32; setN = 64; }   // pairs of groups (decoder_1's split-attention conv)
+        else if (cg % 32 == 0 && ng <= 64) { sets = groups; setC = cg; setN = ng; }   // one set per group
+        else return false;
+    }
+    if (setN > 64 || setN % 8 != 0 || setC % 32 != 0 || setC > 128) return false;
+    const int NT = (setN > 32 || setC % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
+    if ((int64_t)a.H * a.W < 128 * 128) return false;  // small images: the generic kernel's split-M has enough reuse per byte
+    const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
+    if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
+    if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;
+    const int ntiles = a.B * th * tw;
+    const int ychunks = setC / (32 * (4 / NT));
+    int nblk = 512 / (ychunks * sets);                 // 2 blocks per CU are resident (178 registers): one full round; each block ends
+                                                       // with up to 18432 atomics (512 beat 1024 / 2048 / 4096 by 6 / 25 / 50 %)
+    if (nblk < 1) nblk = 1;
+    if (nblk > ntiles) nblk = ntiles;
+    const int tpb = cdiv(ntiles, nblk);
+    nblk = cdiv(ntiles, tpb);
+    dim3 grid(nblk, ychunks, sets);
+    // every block used to end with up to 18432 float atomics into the same slab (38 MB per launch): with a fold session open the
+    // blocks of one tile range (blockIdx.x) write their slabs into that range's private slice instead
+    a.part = nullptr; a.part_slice = 0; a.NtotPart = groups * a.Ng;
+    if (g_fold.open && g_fold.st == st && a.Cg == a.CgReal && a.Kpad == 9 * a.Cg) {
+        a.part = wgrad_fold_take(a, groups, nblk, a.part_slice);
+        if (a.part && wgrad_fold_add(a, groups, nblk) != OCTA_OK) return false;
+    }
+    if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
+    else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>%s", NT, a.part ? "+fold" : "");
+    return true;
+}
+
 template <typename T>
 static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     constexpr int MT = WgLds<T>::MT;
@@ -1970,11 +1983,14 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
     a.M = d->B * d->OH * d->OW; a.Kpad = d->KH * d->KW * a.Cg;
     a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
     a.dbias = dbias;
-    if (d->dtype == OCTA_BF16 && launch_wgrad_halo(a, d->groups, d->Cin, d->Cout, (hipStream_t)stream)) {
-        OCTA_CHECK_LAUNCH("conv3x3_wgrad_halo");
-        return OCTA_OK;
-    }
+    a.part = nullptr; a.part_slice = 0; a.NtotPart = d->Cout;
     const bool mine = octa_wgrad_fold_begin((hipStream_t)stream);     // a lone call folds by itself; inside octa_conv2d_wgrad_batch the batch does
+    if (d->dtype == OCTA_BF16 && launch_wgrad_halo(a, d->groups, d->Cin, d->Cout, (hipStream_t)stream)) {
+        rc = OCTA_OK;
+        if (hipGetLastError() != hipSuccess) { octa_set_error("conv3x3_wgrad_halo: launch failed"); rc = OCTA_ERR_LAUNCH; }
+        if (mine) { const int rc2 = octa_wgrad_fold_end(); if (!rc) rc = rc2; }
+        return rc;
+    }
     rc = d->dtype == OCTA_F32 ? launch_wgrad<float>(a, d->groups, (hipStream_t)stream)
        : d->dtype == OCTA_BF16 ? launch_wgrad<bf16_t>(a, d->groups, (hipStream_t)stream)
                                : launch_wgrad<f16_t>(a, d->groups, (hipStream_t)stream);

@@ -840,6 +840,10 @@ FOLD_CASES = [
     (15, 128, 4, 2, 1, 1, 2, 48, 48, True),     # spectral conv, padded input channels
     (64, 128, 3, 1, 1, 2, 2, 40, 36, False),    # grouped (encoder_2's split-attention conv)
     (64, 32, 1, 1, 0, 1, 1, 120, 100, False),   # decoder_0 shortcut
+    (64, 32, 3, 1, 1, 1, 1, 130, 140, True),    # halo weight-gradient kernel <2> (bf16): one slice per tile range
+    (32, 64, 3, 1, 1, 4, 1, 130, 140, False),   # halo kernel, one dense set of four groups (block diagonal)
+    (64, 128, 3, 1, 1, 4, 1, 130, 140, True),   # halo kernel, two channel sets of paired groups
+    (128, 64, 3, 1, 1, 1, 1, 128, 136, False),  # halo kernel <4>, four channel-chunk blocks per tile range
 ]
 
 
@@ -878,7 +882,9 @@ def test_wgrad_partial_tiles_and_fold_vs_torch(dev, case, dtype):
     dw1, db1, n1 = run(True)
     dw2, db2, n2 = run(True)
     dw0, db0, n0 = run(False)
-    assert n1.endswith("+fold") and "conv_wgrad_kernel" in n1 and not n0.endswith("+fold"), (n1, n0)
+    assert n1.endswith("+fold") and "wgrad" in n1 and not n0.endswith("+fold"), (n1, n0)
+    if k == 3 and H * W >= 128 * 128 and dtype == torch.bfloat16:
+        assert "wgrad_halo" in n1, n1
     assert torch.equal(dw1, dw2) and (db1 is None or torch.equal(db1, db2)), "fold is not deterministic"
     t = TOL[dtype]
     sc = float(wr.grad.abs().max())
