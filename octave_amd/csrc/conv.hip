@@ -1811,12 +1811,14 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgFoldBatch fb) {
     __syncthreads();
     if (sl != 0 || el >= total) return;
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (el >= nW) { J.dbias[el - nW] += v; return; }
+    // (atomic adds, one per element: two jobs of a batch may share a gradient buffer -- tied weights -- as they could with the atomic
+    // epilogue; with distinct buffers every element receives exactly one add, so the result is still run-to-run identical)
+    if (el >= nW) { atomicAdd(J.dbias + (el - nW), v); return; }
     const int n = el / J.Kpad, k = el - n * J.Kpad;
     const int tap = k / J.Cg, ci = k - tap * J.Cg;
     if (ci >= J.CgReal) return;
     const int kh = tap / J.KW, kw = tap - kh * J.KW;
-    J.dw[(int64_t)n * J.s_o + (int64_t)ci * J.s_i + kh * J.s_h + kw * J.s_w] += v;
+    atomicAdd(J.dw + ((int64_t)n * J.s_o + (int64_t)ci * J.s_i + kh * J.s_h + kw * J.s_w), v);
 }
 
 // the registered scratch (process-wide, read when a session opens) + the open fold session of the calling host thread
