@@ -1890,7 +1890,8 @@ static bool launch_wgrad_halo(WgradArgs& a, int groups, int Cin, int Cout, hipSt
     }
     if (setN > 64 || setN % 8 != 0 || setC % 32 != 0 || setC > 128) return false;
     const int NT = (setN > 32 || setC % 64 != 0) ? 4 : 2;    // N <= 32 with a single 32-channel chunk: the NT = 4 shape with idle n-tiles
-    if ((int64_t)a.H * a.W < 128 * 128) return false;  // small images: the generic kernel's split-M has enough reuse per byte
+    static const int minpix = getenv("OCTA_WGRAD_HALO_MINPIX") ? atoi(getenv("OCTA_WGRAD_HALO_MINPIX")) : 96 * 96;    // (128 x 128 while the blocks ended in 18432 float atomics each; 100 x 100 wins with the fold: 47 -> 36 us for encoder_2's grouped layers)
+    if ((int64_t)a.H * a.W < minpix) return false;     // small images: the generic kernel's split-M has enough reuse per byte
     const int th = (a.H + 7) / 8, tw = (a.W + 15) / 16;
     if ((double)a.H * a.W < 0.8 * (double)(th * 8) * (tw * 16)) return false;
     if ((int64_t)a.B * a.H * a.W * (int64_t)(a.ldx > a.ldy ? a.ldx : a.ldy) >= (1ll << 31)) return false;

@@ -19,6 +19,7 @@ step.capture(*batch); step._caps = {}      # capture() autotunes the kernel choi
 F_.start_recording(); step(*batch); rec = F_.stop_recording()
 torch.cuda.synchronize()
 F_.set_splitk_workspace(step._sk_ws if os.environ.get("LAYER_TIMES_SPLITK", "1") != "0" else None)     # as during the segmentor phase of a step
+F_.set_wgrad_fold_workspace(getattr(step, "_fold_ws", None) if os.environ.get("LAYER_TIMES_FOLD", "1") != "0" else None)   # as during a step's backward pass
 L = lib(); st = torch.cuda.current_stream().cuda_stream
 rows = []
 excess = []
