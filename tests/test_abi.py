@@ -80,3 +80,29 @@ def test_module_state_dict_matches_reference_layout():
     assert sum(p.numel() for p in net.segmentor.parameters()) == 73056784
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1))
+
+
+def test_group_merge_factor_host_logic():
+    """functional._densify: which grouped 3x3 layers run with merged groups, and with how many per dense block (host logic only)."""
+    import torch
+    from octave_amd import functional as F_
+    bf = torch.bfloat16
+    assert F_._densify(4, 32, 64, 3, 3, 1, 1, 400, 400, bf) == 4        # decoder_0: 8 -> 16 per group: one dense conv
+    assert F_._densify(4, 64, 128, 3, 3, 1, 1, 200, 200, bf) == 2       # decoder_1: 16 -> 32 per group: pairs (two groups of 32 -> 64)
+    assert F_._densify(4, 64, 128, 3, 3, 1, 1, 200, 200, torch.float32) == 0      # fp32 keeps the grouped kernels
+    assert F_._densify(2, 64, 128, 3, 3, 1, 1, 100, 100, bf) == 0       # encoder_2: 32 -> 64 per group is already a resident-weight shape
+    assert F_._densify(4, 64, 128, 3, 3, 1, 1, 100, 100, bf) == 0       # small images stay grouped
+    assert F_._densify(1, 64, 128, 3, 3, 1, 1, 200, 200, bf) == 0
+    assert F_._densify(4, 64, 128, 1, 1, 1, 0, 200, 200, bf) == 0       # 3x3 / stride 1 / pad 1 only
+    assert F_._densify(4, 64, 128, 3, 3, 2, 1, 200, 200, bf) == 0
+
+
+def test_wgrad_fold_workspace_argument_checks(L):
+    """octa_wgrad_fold_workspace: NULL / 0 withdraws, a misaligned or negative-size buffer is refused (no launch involved)."""
+    from octave_amd._lib import OctaError
+    L.octa_wgrad_fold_workspace(None, 0)                     # (the binding raises on a non-zero status)
+    with pytest.raises(OctaError, match="aligned"):
+        L.octa_wgrad_fold_workspace(ctypes.c_void_p(8), 1 << 20)
+    with pytest.raises(OctaError, match="aligned|NULL"):
+        L.octa_wgrad_fold_workspace(None, 1 << 20)
+    L.octa_wgrad_fold_workspace(None, 0)
