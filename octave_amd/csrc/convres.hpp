@@ -30,7 +30,12 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     constexpr int PW = TAPS == 9 ? 18 : 16;
     constexpr int PROWS = TAPS == 9 ? 18 * 18 : 256;
     constexpr int LP = (PROWS + RPI * 8 - 1) / (RPI * 8);   // DMA instructions per wave per patch
-    constexpr int SROWS = LP * 8 * RPI;           // rows of one ring stage
+    // COMPACT (3x3, 64 input channels, 64 output channels: 72 KB of weights): a ring stage holds only the NINSTR instructions that carry
+    // patch rows (41 KB instead of 48 KB, so that two stages + the weights fit the 160 KB); the other instructions of the fixed
+    // per-wave count land in a scratch KiB (the vmcnt waits count instructions), and the outputs leave by direct stores (no strips)
+    constexpr bool COMPACT = TAPS == 9 && NCH == 2 && TN == 4;
+    constexpr int NINSTR = (PROWS + RPI - 1) / RPI;
+    constexpr int SROWS = COMPACT ? NINSTR * RPI : LP * 8 * RPI;           // rows of one ring stage
     constexpr int NST = NCH == 1 ? (TAPS == 9 ? 3 : 4) : 2;
     constexpr int BNR = TN * NH * 16;             // all output channels of the tile (every pass)
     constexpr int NSTEP = TAPS * NCH;
@@ -43,7 +48,8 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     __shared__ uint4 sW[NSTEP * 4 * BNR];         // [step][plane q][n]
     __shared__ uint4 sP[NST * SROWS * SPR];       // [stage][row][slot]
     __shared__ float sBias[BNR];
-    __shared__ uint4 sT[(TN >= 2 && TN <= 4) ? 8 * TM * 16 * (TN / 2) * 4 : 1];   // output transpose strips, one per wave
+    __shared__ uint4 sT[(TN >= 2 && TN <= 4 && !COMPACT) ? 8 * TM * 16 * (TN / 2) * 4 : 1];   // output transpose strips, one per wave
+    __shared__ uint4 sScr[COMPACT ? 64 : 1];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -51,9 +57,11 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     // grouped layers (round 4): blockIdx.y = group, every group its own set of gridDim.x persistent workgroups with its own resident
     // operand; workgroup x of every group walks the same tile range and sits on the same XCD (gridDim.x % 8 == 0), so the
     // groups' slices of one activation line are fetched into that L2 once
+    // (an output-channel SPLIT of a group -- a.Ng = 64 of its 128 / 256 channels per pseudo-group, launch_res -- shares the group's input
+    // slice: bits 16.. of `exact` = log2 of the pseudo-groups per group)
     const int grp = blockIdx.y;
     const int Kelem = TAPS * a.Cg;
-    const T* __restrict__ xg = (const T*)a.x + a.xoff + grp * a.CgStride;
+    const T* __restrict__ xg = (const T*)a.x + a.xoff + (grp >> ((exact >> 16) & 7)) * a.CgStride;
     const T* __restrict__ wg = (const T*)a.w + (size_t)grp * a.Ng * Kelem;
     const T* zero = (const T*)octa_zero_page;
 
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     const int G = gridDim.x;
     // tile sequence of this workgroup: contiguous range, or (strided) every G-th tile so that the chip works on one compact
     // window of G consecutive tiles at a time
-    const bool strided = (exact >> 8) & 8;
+    const bool strided = ((exact >> 8) & 255) & 8;
     const int t0 = strided ? (int)blockIdx.x : (int)((int64_t)blockIdx.x * ntiles / G);
     const int tstep = strided ? G : 1;
     const int nmine = strided ? (ntiles - (int)blockIdx.x + G - 1) / G : (int)((int64_t)(blockIdx.x + 1) * ntiles / G) - t0;
@@ -104,7 +112,8 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
                 off = m * a.ldx + dsl[i];
             }
             const T* src = ok ? (xg + off) : zero;
-            glds16_fast(src, __builtin_amdgcn_readfirstlane(base + (unsigned)((i * 8 + wave) * 1024)));
+            const unsigned dst = (COMPACT && i * 8 + wave >= NINSTR) ? lds_addr(sScr) : base + (unsigned)((i * 8 + wave) * 1024);
+            glds16_fast(src, __builtin_amdgcn_readfirstlane(dst));
         }
     };
 
@@ -136,13 +145,13 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
     const uint4* const pB0 = sW + q * BNR + r;
     T* __restrict__ yb = (T*)a.y + a.yoff + grp * a.Ng;
 
-    const int dbg = exact >> 8;                    // tools/convres_micro.py ablations: 1 no stores, 2 no MFMA loop, 4 no patch DMA
+    const int dbg = (exact >> 8) & 255;            // tools/convres_micro.py ablations: 1 no stores, 2 no MFMA loop, 4 no patch DMA
     exact &= 255;
     int hist = 0;                                  // bit k: tile (current - 1 - k) issued an unknown number of stores
     // Deferred output stores.  A burst of stores at the end of a tile blocks the wave at store ISSUE until the write path
     // has drained it (measured: store time and MFMA time simply added up).  The packed outputs of tile k-1 therefore stay
     // in registers and go out one instruction at a time between the MFMA steps of tile k.
-    constexpr bool DEFER = TN >= 2 && TN <= 4;       // NS <= 4 deferred stores (RES_FLUSH below is written out for 4)
+    constexpr bool DEFER = TN >= 2 && TN <= 4 && !COMPACT;       // NS <= 4 deferred stores (RES_FLUSH below is written out for 4)
     const bool defer = DEFER && a.vec16 && a.Ng % 8 == 0 && a.NgSt == a.Ng && !a.upshuffle;
     // Named scalars, not arrays: anything the optimiser cannot prove constant-indexed is demoted to scratch memory, whose
     // loads come with s_waitcnt vmcnt(0) and drain the whole prefetch ring (measured: 3 us per tile).  Slot n = 2 * row + half.
@@ -358,14 +367,15 @@ __global__ __launch_bounds__(512) void conv_res_kernel(const ConvArgs a, int nti
 // LDS bytes of one instantiation (host mirror of the constants above)
 static inline int res_lds_bytes(int taps, int nch, int tn) {
     const int rpi = 64 / (4 * nch), prows = taps == 9 ? 324 : 256;
-    const int lp = (prows + rpi * 8 - 1) / (rpi * 8), srows = lp * 8 * rpi, nst = nch == 1 ? (taps == 9 ? 3 : 4) : 2;
-    return taps * nch * 4 * tn * 16 * 16 + nst * srows * 64 * nch + tn * 16 * 4 + ((tn == 2 || tn == 4) ? 8 * 2 * 16 * (tn / 2) * 4 * 16 : 0);
+    const bool compact = taps == 9 && nch == 2 && tn == 4;
+    const int lp = (prows + rpi * 8 - 1) / (rpi * 8), srows = compact ? (prows + rpi - 1) / rpi * rpi : lp * 8 * rpi, nst = nch == 1 ? (taps == 9 ? 3 : 4) : 2;
+    return taps * nch * 4 * tn * 16 * 16 + nst * srows * 64 * nch + tn * 16 * 4 + (((tn == 2 || tn == 4) && !compact) ? 8 * 2 * 16 * (tn / 2) * 4 * 16 : 16) + (compact ? 1024 : 16);
 }
 
 template <typename T, int TAPS, int NCH, int TN, int MODE, int NH = 1>
 static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int exact, hipStream_t st, int groups = 1) {
     const int per_cu = res_lds_bytes(TAPS, NCH, TN * NH) * 2 <= 160 * 1024 ? 2 : 1;
-    int grid = octa_num_cus() * per_cu / groups;      // per group; launch_res keeps groups to the divisors of 8 * per_cu
+    int grid = octa_num_cus() * per_cu / groups / 8 * 8;      // per (pseudo-)group, a multiple of 8: workgroup x of every group on the same XCD
     if (grid < 8) grid = 8;
     if (const char* e = getenv("OCTA_CONVRES_GRID")) { const int g = atoi(e); if (g > 0) grid = g; }    // tests: many tiles per workgroup
     if (grid > ntiles) grid = ntiles;
@@ -375,32 +385,43 @@ static void launch_res_one(const ConvArgs& a, int ntiles, int tx, int ty, int ex
 
 // eligibility + launch.  Returns false when another kernel must run.
 template <typename T>
-static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool forced = true) {
+static bool launch_res(const ConvArgs& a_in, int groups, hipStream_t st, bool forced = true) {
     if constexpr (sizeof(T) != 2) return false;
     else {
+        ConvArgs a = a_in;
         if (a.Cg != 32 && a.Cg != 64) return false;
-        // grouped: whole 64 / 128-byte channel slices per group (the DMA rows and the 16-byte stores stay aligned), 2 / 4 / 8 groups
-        static const bool no_grouped = getenv("OCTA_NO_GROUPED_RES") != nullptr;      // A/B switch
-        if (groups != 1 && no_grouped) return false;
-        if (groups != 1 && (a.upshuffle || a.CgStride != a.Cg || a.Ng % 8 != 0 || a.NgSt != a.Ng || (groups != 2 && groups != 4 && groups != 8))) return false;
-        if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 31)) return false;
-        if ((int64_t)a.M * (a.upshuffle ? 4 : 1) * (int64_t)a.ldy >= (1ll << 31)) return false;      // 32-bit byte offsets of the deferred stores
         const bool k3 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.upshuffle && a.H == a.OH && a.W == a.OW;
         const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
         if (!k3 && !k1) return false;
+        // 3x3 with 128 / 256 output channels per group: every 64-channel slice of the outputs is a pseudo-group of its own (own resident
+        // operand, the group's input slice shared): the packed rows, the bias and the output channels of pseudo-group p start at p * 64
+        int nsh = 0;
+        if (k3 && a.Ng > 64 && (a.Ng == 128 || a.Ng == 256) && a.NgSt == a.Ng && (groups == 1 || a.CgStride == a.Cg)) {
+            nsh = a.Ng == 128 ? 1 : 2;
+            groups <<= nsh;
+            a.Ng = a.NgSt = 64;
+        }
+        static const bool no_grouped = getenv("OCTA_NO_GROUPED_RES") != nullptr;      // A/B switch
+        if (groups != 1 && no_grouped) return false;
+        // grouped: whole 64 / 128-byte channel slices per group (the DMA rows and the 16-byte stores stay aligned), 2 .. 32 (pseudo-)groups
+        if (groups != 1 && (a.upshuffle || (nsh == 0 && a.CgStride != a.Cg) || a.Ng % 8 != 0 || a.NgSt != a.Ng || groups > 32 || (groups & (groups - 1)) != 0)) return false;
+        if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 31)) return false;
+        if ((int64_t)a.M * (a.upshuffle ? 4 : 1) * (int64_t)a.ldy >= (1ll << 31)) return false;      // 32-bit byte offsets of the deferred stores
         if (a.upshuffle && a.CoutT % 8 != 0) return false;
         const int nch = a.Cg / 32;
         const int need = a.NgSt;                    // channels the epilogue must cover
         int tn;
         if (k3) {
             tn = need <= 32 ? 2 : 4;
-            if (need > 64 || (nch == 2 && tn == 4)) return false;      // 72 KB of weights + two 48 KB patches do not fit
+            if (need > 64) return false;
+            static const bool no_compact = getenv("OCTA_NO_RES_COMPACT") != nullptr;      // A/B switch
+            if (nch == 2 && tn == 4 && (no_compact || !a.vec16)) return false;      // 72 KB of weights + two compact 41 KB patches: the COMPACT instantiation
         } else {
             tn = need <= 16 ? 1 : need <= 32 ? 2 : need <= 64 ? 4 : need <= 128 ? 8 : 16;
             if (need > 256 || (nch == 1 && (tn == 1 || tn >= 8))) return false;
             if (tn >= 8 && !forced) return false;      // (two passes of 8 n-tiles, NH = 2) only when asked for: the autotuner decides
         }
-        const int exact = a.vec16 && a.Ng == tn * 16 && a.NgSt == a.Ng;
+        const int exact = (a.vec16 && a.Ng == tn * 16 && a.NgSt == a.Ng) | (nsh << 16);
         int ntiles, tx = 0, ty = 0;
         if (k3) { tx = cdiv(a.W, 16); ty = cdiv(a.H, 16); ntiles = a.B * tx * ty; }
         else ntiles = cdiv(a.M, 256);
@@ -408,10 +429,12 @@ static bool launch_res(const ConvArgs& a, int groups, hipStream_t st, bool force
             if (a.mode == 0) {
                 if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 0>(a, ntiles, tx, ty, exact, st, groups);
                 else if (nch == 1) launch_res_one<T, 9, 1, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
+                else if (tn == 4) launch_res_one<T, 9, 2, 4, 0>(a, ntiles, tx, ty, exact, st, groups);
                 else launch_res_one<T, 9, 2, 2, 0>(a, ntiles, tx, ty, exact, st, groups);
             } else {
                 if (nch == 1 && tn == 4) launch_res_one<T, 9, 1, 4, 1>(a, ntiles, tx, ty, exact, st, groups);
                 else if (nch == 1) launch_res_one<T, 9, 1, 2, 1>(a, ntiles, tx, ty, exact, st, groups);
+                else if (tn == 4) launch_res_one<T, 9, 2, 4, 1>(a, ntiles, tx, ty, exact, st, groups);
                 else launch_res_one<T, 9, 2, 2, 1>(a, ntiles, tx, ty, exact, st, groups);
             }
         } else if (nch == 2) {
