@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 308
+#define OCTA_HIP_ABI_VERSION 309
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -521,7 +521,9 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
                   int32_t* step_dev1, int32_t* tick_dev, int32_t* tick_host, octa_stream_t stream);
 
 /* Tuning switches (process-wide; benchmarks and A/B tests).  key 1: which tile families octa_conv2d_wgrad_batch may use,
- * bit 0 = 256x128 / 128x256 (wgrad8), bit 1 = 256x256 (wgrad9); default 3. */
+ * bit 0 = 256x128 / 128x256 (wgrad8), bit 1 = 256x256 (wgrad9); default 3.  key 2: timing-only ablation builds of wgrad9.
+ * key 3: smallest Cout / groups the batched kernels accept (default 128).  key 4: 1 = the batched kernels' M-splits also store
+ * partial tiles for the fold launch of octa_wgrad_fold_workspace (default 0: their atomics are not contended, measured). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -17,6 +17,8 @@ void octa_set_error(const char* fmt, ...);
 
 bool octa_wgrad_fold_begin(hipStream_t st);      // conv.hip: fold session of the partial-store weight gradients (true: this call opened it)
 int octa_wgrad_fold_end();
+float* octa_wgrad_fold_reserve(hipStream_t st, float* dw, float* dbias, const int64_t* strides, int Ntot, int Kpad, int Cg, int CgReal, int KW,
+                               int split, int64_t* slice_out);
 void octa_note_conv_kernel(const char* name);   // conv.hip: name reported by octa_last_conv_kernel()
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -9,6 +9,8 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
+#include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -1824,7 +1826,9 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgFoldBatch fb) {
 // the registered scratch (process-wide, read when a session opens) + the open fold session of the calling host thread
 static float* g_fold_ws = nullptr;
 static int64_t g_fold_ws_floats = 0;
-static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; } g_fold = {};
+// (full batches wait in `done` until the session closes: a fold launch must follow the LAST kernel that writes its slices, and the
+// batched kernels of wgrad8.hip reserve the slices of up to 20 problems before their one launch)
+static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; std::vector<std::pair<WgFoldBatch, int>>* done; } g_fold = {};
 
 extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
     OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_wgrad_fold_workspace: 16-byte aligned buffer, or NULL / 0");
@@ -1832,7 +1836,19 @@ extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
     g_fold_ws_floats = g_fold_ws ? bytes / 4 : 0;
     return OCTA_OK;
 }
+static void wgrad_fold_park() {          // the current batch is full: keep it for the end of the session
+    if (!g_fold.done) g_fold.done = new std::vector<std::pair<WgFoldBatch, int>>();
+    g_fold.done->emplace_back(g_fold.fb, g_fold.nblk);
+    g_fold.fb.n = 0; g_fold.nblk = 0;
+}
 static int wgrad_fold_flush() {
+    if (g_fold.done) {
+        for (auto& b : *g_fold.done) {
+            wgrad_fold_kernel<<<b.second, 256, 0, g_fold.st>>>(b.first);
+            OCTA_CHECK_LAUNCH("wgrad_fold");
+        }
+        g_fold.done->clear();
+    }
     if (g_fold.fb.n > 0) {
         wgrad_fold_kernel<<<g_fold.nblk, 256, 0, g_fold.st>>>(g_fold.fb);
         OCTA_CHECK_LAUNCH("wgrad_fold");
@@ -1847,6 +1863,7 @@ bool octa_wgrad_fold_begin(hipStream_t st) {
     g_fold.ws = nullptr; g_fold.cap = 0;
     if (!off) { g_fold.ws = g_fold_ws; g_fold.cap = g_fold_ws_floats; }
     g_fold.open = true; g_fold.st = st; g_fold.used = 0; g_fold.fb.n = 0; g_fold.nblk = 0;
+    if (g_fold.done) g_fold.done->clear();
     return true;
 }
 int octa_wgrad_fold_end() {
@@ -1864,7 +1881,7 @@ static float* wgrad_fold_take(const WgradArgs& a, int groups, int split, int64_t
     return p;
 }
 static int wgrad_fold_add(const WgradArgs& a, int groups, int split) {
-    if (g_fold.fb.n == OCTA_WGFOLD_MAX) { const int rc = wgrad_fold_flush(); if (rc) return rc; }
+    if (g_fold.fb.n == OCTA_WGFOLD_MAX) wgrad_fold_park();
     WgFoldJob& J = g_fold.fb.j[g_fold.fb.n++];
     J.part = a.part; J.dw = a.dw; J.dbias = a.dbias; J.slice = a.part_slice;
     J.s_o = a.s_o; J.s_i = a.s_i; J.s_h = a.s_h; J.s_w = a.s_w;
@@ -1915,6 +1932,29 @@ static bool launch_wgrad_halo(WgradArgs& a, int groups, int Cin, int Cout, hipSt
     else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>%s", NT, a.part ? "+fold" : "");
     return true;
+}
+
+// The batched kernels of wgrad8.hip reserve their slices through this: `split` slices of Ntot * (Kpad + 1) floats (rounded to 4) for a
+// job of the open session on `st`, registered with the session's fold launch; NULL when there is no session / no room (atomics then).
+float* octa_wgrad_fold_reserve(hipStream_t st, float* dw, float* dbias, const int64_t* strides, int Ntot, int Kpad, int Cg, int CgReal, int KW,
+                               int split, int64_t* slice_out) {
+    if (!g_fold.open || g_fold.st != st || !g_fold.ws || split < 2) return nullptr;
+    const int64_t slice = ((int64_t)Ntot * (Kpad + 1) + 3) / 4 * 4;
+    const int64_t need = slice * split;
+    static const int64_t cap_mb = getenv("OCTA_WGRAD_FOLD_JOB_MB") ? atoll(getenv("OCTA_WGRAD_FOLD_JOB_MB")) : 512;
+    if (need > g_fold.cap - g_fold.used || need * 4 > (cap_mb << 20) || (int64_t)Ntot * (Kpad + 1) >= (1ll << 31)) return nullptr;
+    if (g_fold.fb.n == OCTA_WGFOLD_MAX) wgrad_fold_park();
+    float* p = g_fold.ws + g_fold.used;
+    g_fold.used += need;
+    WgFoldJob& J = g_fold.fb.j[g_fold.fb.n++];
+    J.part = p; J.dw = dw; J.dbias = dbias; J.slice = slice;
+    J.s_o = strides[0]; J.s_i = strides[1]; J.s_h = strides[2]; J.s_w = strides[3];
+    J.split = split; J.Ntot = Ntot; J.Kpad = Kpad; J.Cg = Cg; J.CgReal = CgReal; J.KW = KW;
+    J.blockStart = g_fold.nblk;
+    J.nblocks = (int)(((int64_t)Ntot * (Kpad + (dbias ? 1 : 0)) + 63) / 64);
+    g_fold.nblk += J.nblocks;
+    *slice_out = slice;
+    return p;
 }
 
 template <typename T>

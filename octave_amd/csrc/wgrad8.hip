@@ -37,6 +37,10 @@ struct WgProb {
     unsigned magicOW, magicOH;      // floor(2^32 / d) + 1: exact quotient for n * d < 2^32
     int tilesN, tilesK, groups, splitM, mPerSplit;
     int blockStart;
+    // partial-store mode (round 4, conv.hip: wgrad_fold_kernel): part != NULL -> M-split sp stores its raw tile to
+    // part[sp * part_slice + (g * Ng + n) * Kpad + k] (bias sums behind the groups * Ng * Kpad block) instead of float atomics into dw
+    float* part;
+    long part_slice;
 };
 #define WG_MAXP 20
 struct WgBatch { WgProb p[WG_MAXP]; int n; };
@@ -289,11 +293,31 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgBatch batch) {
         if (late && it + 2 < nsteps) issue((it + 2) % STAGES, mbeg + (it + 2) * MT);
     }
 
+    float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
     if (do_bias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
         __syncthreads();
-        if (t < BN && n0 + t < Ng) atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        if (t < BN && n0 + t < Ng) {
+            if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
+            else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + (wk * 4 + j) * 16 + r;
+            if (k >= Kpad) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + (wn * 4 + i) * 16 + q * 4 + e;
+                    if (n < Ng) part[(long)(g * Ng + n) * Kpad + k] = acc[i][j][e];
+                }
+            }
+        }
+        return;
     }
     // ---- epilogue: D[row = n (4q + e)][col = k (r)], fp32 atomics into the (channels-last) gradient tensor
     float* const dw = Pk.dw;
@@ -576,11 +600,31 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 #undef WG9_TR
 #undef WG9_SB
 
+    float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
     if (do_bias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
         __syncthreads();
-        if (t < BN && n0 + t < Ng) atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        if (t < BN && n0 + t < Ng) {
+            if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
+            else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+            if (k >= Kpad) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (n < Ng) part[(long)(g * Ng + n) * Kpad + k] = acc[i][j][e];
+                }
+            }
+        }
+        return;
     }
     // ---- epilogue: 32x32 accumulator block (i, j): column c = lane & 31, row n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5); one register
     // of all lanes = two 128-byte runs along Cin of the channels-last gradient tensor (full-rate float atomics)
@@ -609,6 +653,21 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 
 // ------------------------------------------------------------------------------------------ host side
 static unsigned wg_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+static int g_wg8_fold = 0;            // octa_tuning_set(4, 0 / 1)
+
+// a problem whose M axis is split takes private slices for its partial tiles when the batch's fold session has room (conv.hip)
+static void wg_take_fold(WgProb& p, hipStream_t st) {
+    p.part = nullptr; p.part_slice = 0;
+    // Off by default: measured +0.1 ms per step (profiles/r04_ab_wgrad8_fold.txt).  Unlike the few-channel layers, the M-splits of
+    // these kernels add into DIFFERENT tiles' addresses at the full atomic rate, and the slices cost a write and a read more.
+    // octa_tuning_set(4, 1) / OCTA_WGRAD8_FOLD=1 turns it on (tests, A/B runs).
+    static const bool env_on = getenv("OCTA_WGRAD8_FOLD") != nullptr && atoi(getenv("OCTA_WGRAD8_FOLD")) != 0;
+    if (!(env_on || g_wg8_fold) || p.splitM < 2) return;
+    const int64_t strides[4] = {p.s_o, p.s_i, p.s_h, p.s_w};
+    int64_t slice = 0;
+    float* ws = octa_wgrad_fold_reserve(st, p.dw, p.dbias, strides, p.groups * p.Ng, p.Kpad, p.Cg, p.CgReal, p.KW, p.splitM, &slice);
+    if (ws) { p.part = ws; p.part_slice = (long)slice; }
+}
 
 static int g_wg8_min_ng = 128;        // octa_tuning_set(3, n): smallest Cout / groups the batched kernels accept
 // can the batched kernel take this job?  (everything else goes to the single-problem kernels of conv.hip)
@@ -663,6 +722,7 @@ static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
             const int64_t sps = (plans[i].steps + split - 1) / split;      // balanced stages per split
             p.mPerSplit = (int)(sps * 64);
             p.splitM = (int)((p.M + p.mPerSplit - 1) / p.mPerSplit);
+            wg_take_fold(p, st);
             p.blockStart = (int)nblk;
             nblk += (int64_t)p.tilesN * p.tilesK * p.groups * p.splitM;
             batch.p[i - i0] = p;
@@ -714,6 +774,7 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
             const int64_t sps = (plans[i].steps + split - 1) / split;      // balanced stages per split
             p.mPerSplit = (int)(sps * 32);
             p.splitM = (int)((p.M + p.mPerSplit - 1) / p.mPerSplit);
+            wg_take_fold(p, st);
             p.blockStart = (int)nblk;
             nblk += (int64_t)p.tilesN * p.tilesK * p.groups * p.splitM;
             batch.p[i - i0] = p;
@@ -747,6 +808,7 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
 extern "C" int octa_tuning_set(int key, int value) {
     if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
+    if (key == 4) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 4 = partial tiles + fold for the batched weight-gradient kernels (0 / 1)"); g_wg8_fold = value; return OCTA_OK; }
     if (key == 3) { OCTA_REQUIRE(value >= 8 && value <= 4096, "octa_tuning_set: key 3 = minimum Cout / groups of the batched weight-gradient kernels"); g_wg8_min_ng = value; return OCTA_OK; }
     OCTA_REQUIRE(key == 1 && value >= 1 && value <= 3, "octa_tuning_set: key 1 = batched weight-gradient tile families (mask 1..3)");
     g_wgrad_families = value;
@@ -803,15 +865,14 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_s
         p.tilesN = cdiv(p.Ng, pl.variant == 1 ? 128 : 256);
         p.tilesK = cdiv(p.Kpad, pl.variant == 0 ? 128 : 256);
         pl.steps = pl.variant == 2 ? (p.M + 31) / 32 : (p.M + 63) / 64;
-        p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0;
+        p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0; p.part = nullptr; p.part_slice = 0;
         plans[d.dtype == OCTA_F16 ? 1 : 0][pl.variant].push_back(pl);
     }
-    { const int rc = fold.close(); if (rc) return rc; }
     for (int v = 0; v < 2; ++v) {
         if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
         if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }
     }
     if (!plans[0][2].empty()) { const int rc = wg9_launch<0>(plans[0][2], st); if (rc) return rc; }
     if (!plans[1][2].empty()) { const int rc = wg9_launch<1>(plans[1][2], st); if (rc) return rc; }
-    return OCTA_OK;
+    return fold.close();          // ONE fold launch (per 16 jobs) behind every kernel of the batch that stored partial tiles
 }

@@ -426,10 +426,11 @@ class TrainStep:
         # layers launch 316 / 626 tiles on 256 CUs
         self._sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=next(net.parameters()).device) if os.environ.get("OCTA_SPLITK", "1") != "0" else None
         # scratch of the partial-store weight gradients (octa_wgrad_fold_workspace): one per phase, because the discriminator's step
-        # replays on a second stream beside the segmentor's backward pass.  The largest batch of single-problem jobs (the four halo-kernel layers of decoder_0 / decoder_1: 38 MB each) needs ~170 MB.
+        # replays on a second stream beside the segmentor's backward pass.  The largest batch of single-problem jobs (the four halo-kernel layers of decoder_0 / decoder_1: 38 MB each) needs ~170 MB.  (The batched 8-wave kernels can use it too, octa_tuning_set(4, 1)
+        # with OCTA_WGRAD_FOLD_MB=1024: measured +0.1 ms per step, their atomics are not contended; off.)
         fold_on = os.environ.get("OCTA_WGRAD_FOLD", "1") != "0"
         dev0 = next(net.parameters()).device
-        self._fold_ws = torch.empty(48 << 20, dtype=torch.float32, device=dev0) if fold_on else None
+        self._fold_ws = torch.empty(int(os.environ.get("OCTA_WGRAD_FOLD_MB", "192")) << 18, dtype=torch.float32, device=dev0) if fold_on else None
         self._fold_ws_disc = torch.empty(32 << 20, dtype=torch.float32, device=dev0) if (fold_on and self.adversarial) else None
         self._disc_slab = F_._ZeroSlab(2 << 20)
         # replay mode: the discriminator's own step (it needs the attention maps, not the segmentor's gradients) on a second stream

@@ -976,11 +976,14 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
     check("res upshuffle", y, ref, t["rtol"], t["atol"] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_wgrad_batch_vs_torch(dev, dtype):
+def test_wgrad_batch_vs_torch(dev, dtype, fold):
     """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations of wgrad8, the 256 x 256 tiles of wgrad9, grouped convs,
     strided ones, a small-N job that falls through to the single-problem kernel, fused bias gradients) in ONE call against
-    torch's CPU gradients."""
+    torch's CPU gradients.  fold: with octa_wgrad_fold_workspace registered the M-split jobs of every kernel family store
+    partial tiles and the batch ends in fold launches (two of them: more than 16 jobs would need a third); the gradients must
+    also be bit-identical between two runs."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import WgradJob, lib
@@ -990,7 +993,11 @@ def test_wgrad_batch_vs_torch(dev, dtype):
              (2, 32, 10, 10, 48, 3, 1, 1, 1, True),
              # 256 x 256 tiles (wgrad9): exact fit, N tail, grouped, strided, 1x1 with a 5-stage pixel axis and a ragged tail
              (2, 256, 10, 12, 256, 3, 1, 1, 1, True), (3, 512, 7, 9, 500, 1, 1, 0, 1, True), (2, 512, 8, 8, 512, 3, 1, 1, 2, True),
-             (2, 256, 15, 17, 256, 3, 2, 1, 1, False), (1, 1024, 13, 11, 768, 1, 1, 0, 1, False)]
+             (2, 256, 15, 17, 256, 3, 2, 1, 1, False), (1, 1024, 13, 11, 768, 1, 1, 0, 1, False),
+             # enough pixels for an M-split of the 256 x 256 tiles (100 stages of 32 pixels over 9 / 4 tiles)
+             (2, 256, 40, 40, 256, 3, 1, 1, 1, True), (3, 512, 36, 30, 512, 1, 1, 0, 2, True)]
+    if fold:
+        cases = cases * 3         # > 16 jobs with partial tiles: their fold batches must all wait for the kernels that fill them
     gen = torch.Generator().manual_seed(3)
     jobs = (WgradJob * len(cases))()
     keep, want = [], []
@@ -1012,11 +1019,31 @@ def test_wgrad_batch_vs_torch(dev, dtype):
         want.append((wr.grad, dy.sum((0, 2, 3))))
     classes = [int(L.octa_wgrad_job_class(ctypes.byref(jobs[j]))) for j in range(len(cases))]
     assert set(classes) == {0, 1, 2, 3}, classes
-    L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev) if fold else None
+    F_.set_wgrad_fold_workspace(ws)
+    if fold:
+        L.octa_tuning_set(4, 1)       # the batched kernels too (off by default: no gain in situ)
+    try:
+        L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+        first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in keep]
+        if fold:
+            for _, _, dw, db in keep:
+                dw.zero_()
+                if db is not None:
+                    db.zero_()
+            L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+    finally:
+        F_.set_wgrad_fold_workspace(None)
+        L.octa_tuning_set(4, 0)
+    split_jobs = 0
     for j, ((xd, dyd, dw, db), (gw, gb)) in enumerate(zip(keep, want)):
         check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))
         if db is not None:
             check(f"wgrad batch bias {j}", db, gb, 0, 1e-3 * float(gb.abs().max()) + 1e-3)
+        if fold and not torch.equal(first[j][0], dw):
+            split_jobs += 1          # a job that kept its float atomics (single-split jobs add straight into dw: order-dependent only across tiles? no: one add per element)
+    if fold:
+        assert split_jobs == 0, f"{split_jobs} jobs differ between two runs with the fold scratch registered"
 
 
 # ----------------------------------------------------------------------------------------- round 3: BatchNorm statistics in the conv epilogue
