@@ -111,7 +111,7 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
     ref_dx = _ref_dgrad_pixels(dy64, w64, ib, ih, iw, s, p, g, Cin)
     seen = set()
     sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
-    for algo in (0, 2, 3, 8, 1, 102, 103, 12, 112, 9, 10):         # 12 / 112: the 2-D patch kernel (halo8.hpp) without / with the scratch; 9 / 10: pwgemm.hpp (1x1 layers)
+    for algo in (0, 2, 3, 8, 1, 102, 103, 12, 112, 9, 10, 7):      # 12 / 112: the 2-D patch kernel (halo8.hpp) without / with the scratch; 9 / 10: pwgemm.hpp (1x1 layers); 7: resident weights
         # 102 / 103: the 8-wave kernel with the tail-split scratch registered (octa_conv_splitk_workspace): the 316-tile (25 x 25)
         # and 626-tile (50 x 50) launches then run their last 60 / 114 tiles as 4 / 2 workgroups each + the fix-up launch
         split = algo >= 100
@@ -146,6 +146,8 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
             assert "conv_halo8_kernel" in kf and "conv_halo8_kernel" in kd, (kf, kd)
         if algo in (9, 10) and k == 1:
             assert "pwgemm_kernel" in kf and "pwgemm_kernel" in kd, (kf, kd)
+        if algo == 7 and k == 3 and Cin // g == 64:
+            assert "conv_res3x3" in kf, kf                           # 64 -> 128 per group: two 64-channel output slices per group, compact stages
         # adjoint identity fwd <-> dgrad over the WHOLE tensors (any wrong tile anywhere breaks it)
         t_f = (F_.to_nchw_f32(y).double() * dy64).sum().item()
         t_d = (F_.to_nchw_f32(dx).double() * x64).sum().item()
