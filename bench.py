@@ -334,7 +334,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  NOT bound to the device with device_id=: the eagerly created communicator of that form costs
+        # every replayed step +1.2 ms on this stack even when no collective runs (tools/dist_overhead_probe.py, one rank:
+        # 25.6 -> 26.9 ms; profiles/r04_dist_overhead.txt); the communicator is created by the first collective instead (the
+        # parameter broadcast of TrainStep), and every barrier names its device
+        dist.init_process_group(backend="nccl")
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the number of ranks must equal --gpus")
 
@@ -376,7 +380,7 @@ def main():
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)
     if use_dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -384,7 +388,7 @@ def main():
     t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (launch-bound if ~ the total)
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -399,14 +403,14 @@ def main():
     sustained = None
     if args.sustained > 0:
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.sustained):
             out = step(*batch)
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         ds = time.perf_counter() - t0
         if use_dist:
             t = torch.tensor([ds], device=dev, dtype=torch.float64)
@@ -452,7 +456,7 @@ def main():
             log("dice-vs-reference leg done")
         print(json.dumps(res), flush=True)
     if use_dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
