@@ -1828,7 +1828,8 @@ static float* g_fold_ws = nullptr;
 static int64_t g_fold_ws_floats = 0;
 // (full batches wait in `done` until the session closes: a fold launch must follow the LAST kernel that writes its slices, and the
 // batched kernels of wgrad8.hip reserve the slices of up to 20 problems before their one launch)
-static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; std::vector<std::pair<WgFoldBatch, int>>* done; } g_fold = {};
+static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; } g_fold = {};
+static thread_local std::vector<std::pair<WgFoldBatch, int>> g_fold_done;
 
 extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
     OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_wgrad_fold_workspace: 16-byte aligned buffer, or NULL / 0");
@@ -1837,18 +1838,15 @@ extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
     return OCTA_OK;
 }
 static void wgrad_fold_park() {          // the current batch is full: keep it for the end of the session
-    if (!g_fold.done) g_fold.done = new std::vector<std::pair<WgFoldBatch, int>>();
-    g_fold.done->emplace_back(g_fold.fb, g_fold.nblk);
+    g_fold_done.emplace_back(g_fold.fb, g_fold.nblk);
     g_fold.fb.n = 0; g_fold.nblk = 0;
 }
 static int wgrad_fold_flush() {
-    if (g_fold.done) {
-        for (auto& b : *g_fold.done) {
-            wgrad_fold_kernel<<<b.second, 256, 0, g_fold.st>>>(b.first);
-            OCTA_CHECK_LAUNCH("wgrad_fold");
-        }
-        g_fold.done->clear();
+    for (auto& b : g_fold_done) {
+        wgrad_fold_kernel<<<b.second, 256, 0, g_fold.st>>>(b.first);
+        if (hipGetLastError() != hipSuccess) { g_fold_done.clear(); g_fold.fb.n = 0; g_fold.nblk = 0; octa_set_error("wgrad_fold: launch failed"); return OCTA_ERR_LAUNCH; }
     }
+    g_fold_done.clear();
     if (g_fold.fb.n > 0) {
         wgrad_fold_kernel<<<g_fold.nblk, 256, 0, g_fold.st>>>(g_fold.fb);
         OCTA_CHECK_LAUNCH("wgrad_fold");
@@ -1863,7 +1861,7 @@ bool octa_wgrad_fold_begin(hipStream_t st) {
     g_fold.ws = nullptr; g_fold.cap = 0;
     if (!off) { g_fold.ws = g_fold_ws; g_fold.cap = g_fold_ws_floats; }
     g_fold.open = true; g_fold.st = st; g_fold.used = 0; g_fold.fb.n = 0; g_fold.nblk = 0;
-    if (g_fold.done) g_fold.done->clear();
+    g_fold_done.clear();
     return true;
 }
 int octa_wgrad_fold_end() {
