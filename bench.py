@@ -109,20 +109,29 @@ def conv_flops(d):
     return 2.0 * d.B * d.OH * d.OW * d.Cout * (d.Cin // getattr(d, "alg_groups", d.groups)) * d.KH * d.KW    # algorithmic (densified layers too)
 
 
-def roofline_leg(step, batch, dtype_name):
-    """Record one step's conv-engine launches, then replay them once, in order, each between two HIP events on the stream
-    it is launched on (torch's current stream), and aggregate per kernel instance (the name is the template instance the
-    library reports it dispatched: octa_last_conv_kernel)."""
+def roofline_record(step, batch):
+    """Record the conv-engine launches of one EAGER step.  With more than one rank EVERY rank must call this: the step it runs
+    exchanges gradients like any other (a recording on rank 0 alone would leave its all-reduces without partners)."""
+    from octave_amd import functional as F_
+    graphs, step._graphs = step._graphs, None      # record an EAGER step (a graph replay launches nothing from Python)
+    F_.start_recording()
+    try:
+        step(*batch)
+        rec = F_.stop_recording()
+    finally:
+        step._graphs = graphs
+    torch.cuda.synchronize()
+    return rec
+
+
+def roofline_leg(step, rec, batch, dtype_name):
+    """Replay the recorded conv-engine launches once, in order, each between two HIP events on the stream it is launched on
+    (torch's current stream), and aggregate per kernel instance (the name is the template instance the library reports it
+    dispatched: octa_last_conv_kernel).  No collective in here: rank 0 runs it alone."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import lib
     L = lib()
-    graphs, step._graphs = step._graphs, None      # record an EAGER step (a graph replay launches nothing from Python)
-    F_.start_recording()
-    step(*batch)
-    rec = F_.stop_recording()
-    step._graphs = graphs
-    torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
     agg = {}
     pending = []
@@ -419,6 +428,7 @@ def main():
         sustained = (ds / args.sustained * 1e3, all(math.isfinite(float(v.item())) for v in out.values()))
         log(f"sustained leg done: {sustained[0]:.2f} ms/step over {args.sustained} steps")
     dist_diag = step.comm_diagnosis(*batch) if use_dist else None
+    rec = roofline_record(step, batch) if not args.no_roofline else None        # every rank: the recorded step exchanges gradients
     if _l.PROFILE is not None and rank == 0:
         print(_l.profile_report(), file=sys.stderr, flush=True)
 
@@ -445,7 +455,7 @@ def main():
         if dist_diag is not None:
             res["dist"] = dist_diag
         if not args.no_roofline:
-            res["roofline"] = roofline_leg(step, batch, args.dtype)
+            res["roofline"] = roofline_leg(step, rec, batch, args.dtype)
             log("roofline leg done")
         if net_state is not None:
             res["cpu_baseline"] = cpu_baseline_leg(net_state)
