@@ -14,6 +14,26 @@ __global__ __launch_bounds__(256) void noise_clip_fwd_kernel(const float* __rest
         const int h = (int)((i / W) % H);
         const int b = (int)(i / ((int64_t)W * H));
         const float nz = noise ? noise[h * W + w] : 0.f;
+        if constexpr (sizeof(T) == 2) {
+            if (cpad == 8 && (ld & 7) == 0) {
+                // the usual shape (2 class maps padded to one 16-byte channel vector): ONE store per pixel instead of eight 2-byte ones
+                // (61 MB per call at 400 x 400: 34 -> 12 us)
+                float v8[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v = 0.f;
+                    if (c < C) {
+                        v = src[b * s.b + c * s.c + h * s.h + w * s.w] + nz;
+                        uint8_t m = 1;
+                        if (clip) { m = (v >= 0.f && v <= 1.f) ? 1 : 0; v = fminf(fmaxf(v, 0.f), 1.f); }
+                        if (mask) mask[(((int64_t)b * C + c) * H + h) * W + w] = m;
+                    }
+                    v8[c] = v;
+                }
+                *(uint4*)(dst + i * ld) = pack16<T>(v8);
+                continue;
+            }
+        }
         for (int c = 0; c < cpad; ++c) {
             float v = 0.f;
             if (c < C) {
