@@ -106,3 +106,23 @@ def test_wgrad_fold_workspace_argument_checks(L):
     with pytest.raises(OctaError, match="aligned|NULL"):
         L.octa_wgrad_fold_workspace(None, 1 << 20)
     L.octa_wgrad_fold_workspace(None, 0)
+
+
+def test_bench_rank0_block_issues_no_training_step():
+    """bench.py with N > 1: whatever runs on rank 0 ALONE must not run a training step (its gradient exchange would have no partners
+    and the run would hang -- the round-4 bug of the roofline leg).  Static check of main()'s `if rank == 0:` block."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    blocks = [n for n in ast.walk(main) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare) and isinstance(n.test.left, ast.Name)
+              and n.test.left.id == "rank" and isinstance(n.test.ops[0], ast.Eq) and getattr(n.test.comparators[0], "value", None) == 0]
+    assert blocks, "bench.py: no `if rank == 0:` block found in main()"
+    forbidden = {"step", "roofline_record", "autotune_launch", "comm_diagnosis", "capture"}
+    for blk in blocks:
+        for node in ast.walk(blk):
+            if isinstance(node, ast.Call):
+                f = node.func
+                name = f.id if isinstance(f, ast.Name) else (f.attr if isinstance(f, ast.Attribute) else "")
+                assert name not in forbidden, f"bench.py line {node.lineno}: `{name}(...)` inside a rank-0-only block would leave its collectives without partners"
