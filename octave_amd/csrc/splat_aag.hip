@@ -1276,6 +1276,9 @@ static int aag_fwd_launch(const void* x, const float* w, const float* bias, void
 }
 static int64_t aag_bwd_blocks(int64_t npix, int ppb) {
     int64_t nb = cdiv64(npix, (int64_t)ppb * 16);
+    // wide, low-resolution gates (1024 channels at 25 x 25: 4 pixels per block round) came out at 157 workgroups on 256 CUs with
+    // 16 dependent rounds each: at least one workgroup per CU while a workgroup still has two rounds (one loop iteration)
+    if (nb < 256) { const int64_t nb2 = cdiv64(npix, (int64_t)ppb * 2); nb = nb2 < 256 ? nb2 : 256; }
     if (nb > 1024) nb = 1024;
     return nb < 1 ? 1 : nb;
 }
