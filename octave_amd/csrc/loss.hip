@@ -181,23 +181,28 @@ struct KlMaps { const float* p[KL_MAX_MAPS]; float* d[KL_MAX_MAPS]; int shift[KL
 template <int K>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, float* __restrict__ partial) {
     __shared__ float red[16];
-    const int64_t total = (int64_t)B * H * W;
+    // 32-bit pixel decode (the host checks B*K*H*W < 2^31): the 64-bit divisions and the index chains of this loop were as
+    // expensive as its 12 logarithms per pixel (60 us for 16 x 2 x 400 x 400; the bytes would take 12)
+    const int total = B * H * W, HW = H * W;
     float acc[1] = {0.f};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const int b = (int)(i / ((int64_t)W * H));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / HW, r = i - b * HW;
+        const int h = r / W, w = r - h * W;
+        float m[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) m[k] = 0.f;
+        for (int j = 0; j < mp.n; ++j) {
+            const int s = mp.shift[j];
+            const int hs = H >> s, wsz = W >> s;
+            const float* q = mp.p[j] + ((size_t)b * K * hs + (h >> s)) * wsz + (w >> s);
+            const float wj = mp.w[j];
+#pragma unroll
+            for (int k = 0; k < K; ++k) m[k] += logf(q[(size_t)k * hs * wsz] * wj + 1e-12f);
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float P = basis[(((int64_t)b * K + k) * H + h) * W + w];
-            float m = 0.f;
-            for (int j = 0; j < mp.n; ++j) {
-                const int s = mp.shift[j];
-                const int hs = H >> s, wsz = W >> s;
-                const float Q = mp.p[j][(((int64_t)b * K + k) * hs + (h >> s)) * wsz + (w >> s)];
-                m += logf(Q * mp.w[j] + 1e-12f);
-            }
-            acc[0] += P * (logf(P + 1e-12f) - m / mp.wsum);
+            const float P = basis[((size_t)b * K + k) * HW + r];
+            acc[0] += P * (logf(P + 1e-12f) - m[k] / mp.wsum);
         }
     }
     block_sum<1>(acc, red);
@@ -224,6 +229,7 @@ extern "C" int octa_interlayer_kl_fwd(const float* basis, const float* const* ma
     }
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * W;
+    OCTA_REQUIRE(total * K < (1ll << 31), "octa_interlayer_kl_fwd: B*K*H*W must be below 2^31");
     int blocks = (int)(cdiv64(total, 256 * 4) > 1024 ? 1024 : cdiv64(total, 256 * 4));
     if (blocks < 1) blocks = 1;
     LOSS_K_SWITCH(K, kl_fwd_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, ws); OCTA_CHECK_LAUNCH("kl_fwd");)
@@ -236,17 +242,16 @@ extern "C" int octa_interlayer_kl_fwd(const float* basis, const float* const* ma
 template <int K>
 __global__ __launch_bounds__(256) void kl_bwd_basis_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, const float* __restrict__ g,
                                                            float* __restrict__ dbasis) {
-    const int64_t total = (int64_t)B * K * H * W;
+    const int total = B * K * H * W, HW = H * W;          // (< 2^31: checked by the host; 32-bit pixel decode as in kl_fwd_kernel)
     const float gs = g[0] / (float)((int64_t)B * H * W);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const int64_t bk = i / ((int64_t)W * H);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int bk = i / HW, r = i - bk * HW;
+        const int h = r / W, w = r - h * W;
         const float P = basis[i];
         float m = 0.f;
         for (int j = 0; j < mp.n; ++j) {
             const int s = mp.shift[j];
-            m += logf(mp.p[j][(bk * (H >> s) + (h >> s)) * (W >> s) + (w >> s)] * mp.w[j] + 1e-12f);
+            m += logf(mp.p[j][((size_t)bk * (H >> s) + (h >> s)) * (W >> s) + (w >> s)] * mp.w[j] + 1e-12f);
         }
         dbasis[i] = gs * (logf(P + 1e-12f) - m / mp.wsum + P / (P + 1e-12f));
     }
@@ -254,17 +259,23 @@ __global__ __launch_bounds__(256) void kl_bwd_basis_kernel(const float* __restri
 // d map j (gather form, one thread per source pixel): -g/N * w/(w Q + eps)/wsum * sum_{block} P
 __global__ __launch_bounds__(256) void kl_bwd_map_kernel(const float* __restrict__ basis, const float* __restrict__ q, float wgt, float wsum, int shift,
                                                          int64_t BK, int H, int W, int64_t npix, const float* __restrict__ g, float* __restrict__ dq) {
+    // f = 2^shift adjacent lanes per source pixel, one basis row of the f x f block each, then a butterfly over the f lanes (the
+    // coarse maps were 20 000 threads walking 256 strided values each: 30 us for the 25 x 25 map)
     const int hs = H >> shift, wsz = W >> shift, f = 1 << shift;
-    const int64_t total = BK * hs * wsz;
+    const int64_t total = BK * hs * wsz * f;
     const float gs = -g[0] / (float)npix / wsum;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < ((total + 255) / 256) * 256; t += (int64_t)gridDim.x * 256) {
+        const bool live = t < total;
+        const int64_t i = (live ? t : total - 1) >> shift;
+        const int dy = (int)((live ? t : total - 1) & (f - 1));
         const int w = (int)(i % wsz);
         const int h = (int)((i / wsz) % hs);
         const int64_t bk = i / ((int64_t)wsz * hs);
+        const float* row = basis + (bk * H + (h << shift) + dy) * W + (w << shift);
         float s = 0.f;
-        for (int dy = 0; dy < f; ++dy)
-            for (int dx = 0; dx < f; ++dx) s += basis[(bk * H + (h << shift) + dy) * W + (w << shift) + dx];
-        dq[i] = gs * s * wgt / (q[i] * wgt + 1e-12f);
+        for (int dx = 0; dx < f; ++dx) s += row[dx];
+        for (int o = 1; o < f; o <<= 1) s += __shfl_xor(s, o);          // f <= 64 divides the wave: the f lanes of a pixel are adjacent
+        if (live && dy == 0) dq[i] = gs * s * wgt / (q[i] * wgt + 1e-12f);
     }
 }
 extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
@@ -276,13 +287,15 @@ extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* ma
     for (int j = 0; j < n_maps; ++j) { mp.p[j] = maps[j]; mp.d[j] = dmaps[j]; mp.shift[j] = shifts[j]; mp.w[j] = weights[j]; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * K * H * W;
+    OCTA_REQUIRE(total < (1ll << 31), "octa_interlayer_kl_bwd: B*K*H*W must be below 2^31");
     if (dbasis) {
         int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
         LOSS_K_SWITCH(K, kl_bwd_basis_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, g, dbasis); OCTA_CHECK_LAUNCH("kl_bwd_basis");)
     }
     for (int j = 0; j < n_maps; ++j) {
         if (!dmaps[j]) continue;
-        const int64_t tj = total >> (2 * shifts[j]);
+        OCTA_REQUIRE(shifts[j] <= 6, "octa_interlayer_kl_bwd: maps down to 1/64 of the basis (2^shift lanes of one wave per source pixel)");
+        const int64_t tj = (total >> (2 * shifts[j])) << shifts[j];            // 2^shift lanes per source pixel
         int blocks = (int)(cdiv64(tj, 256) > 4096 ? 4096 : cdiv64(tj, 256));
         if (blocks < 1) blocks = 1;
         kl_bwd_map_kernel<<<blocks, 256, 0, st>>>(basis, maps[j], weights[j], wsum, shifts[j], (int64_t)B * K, H, W, (int64_t)B * H * W, g, dmaps[j]);
