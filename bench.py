@@ -137,6 +137,7 @@ def roofline_leg(step, rec, batch, dtype_name):
     pending = []
     # as during the segmentor phase of a step: the 8-wave conv kernel's tail split has its scratch (octa_conv_splitk_workspace)
     F_.set_splitk_workspace(getattr(step, "_sk_ws", None))
+    F_.set_wgrad_fold_workspace(getattr(step, "_fold_ws", None))      # ... and the weight gradients their fold scratch (octa_wgrad_fold_workspace)
     evict = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     dw_scratch = {}
     for kind, d, ptrs, keep in rec:
@@ -164,9 +165,10 @@ def roofline_leg(step, rec, batch, dtype_name):
         e1.record()
         fl = sum(conv_flops(d[i].d) for i in range(ptrs)) if kind == "wgrad_batch" else conv_flops(d)
         by = sum(conv_bytes(d[i].d, "wgrad") for i in range(ptrs)) if kind == "wgrad_batch" else conv_bytes(d, kind)
-        pending.append((e0, e1, L.octa_last_conv_kernel().decode().split("+tail")[0], fl, by))      # "+tailNxP": the same kernel with its tail split (incl. the fix-up launch)
+        pending.append((e0, e1, L.octa_last_conv_kernel().decode().split("+tail")[0].split("+fold")[0], fl, by))      # "+tailNxP" / "+fold": the same kernel with its tail split / partial tiles (incl. the fix-up / fold launch)
     torch.cuda.synchronize()
     F_.set_splitk_workspace(None)
+    F_.set_wgrad_fold_workspace(None)
     peak = PEAK_BF16_TFLOPS if dtype_name in ("bf16", "f16") else PEAK_F32_TFLOPS
     for e0, e1, kname, fl, by in pending:
         ms = e0.elapsed_time(e1)
