@@ -23,7 +23,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "halo8" in k or "igemm8" in k or "pwgemm" in k or "wgrad9" in k or "wgrad8" in k:
+        if "halo8" in k or "igemm8" in k or "pwgemm" in k or "wgrad9" in k or "wgrad8" in k or "conv_res" in k:
             agg[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
     for k, d in agg.items():
