@@ -135,15 +135,16 @@ def roofline_leg(step, rec, batch, dtype_name):
     st = torch.cuda.current_stream().cuda_stream
     agg = {}
     pending = []
-    # as during the segmentor phase of a step: the 8-wave conv kernel's tail split has its scratch (octa_conv_splitk_workspace)
-    F_.set_splitk_workspace(getattr(step, "_sk_ws", None))
-    F_.set_wgrad_fold_workspace(getattr(step, "_fold_ws", None))      # ... and the weight gradients their fold scratch (octa_wgrad_fold_workspace)
+    # as during the segmentor phase of a step: the recorded descriptors carry the tail-split scratch of their call (octa_conv_desc.ws);
+    # the batched weight gradients get the phase's fold scratch as an argument, as in the step
+    fold_ws = getattr(step, "_fold_ws", None)
+    fold_args = (None, 0) if fold_ws is None else (fold_ws.data_ptr(), fold_ws.numel() * 4)
     evict = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     dw_scratch = {}
     for kind, d, ptrs, keep in rec:
         def launch():
             if kind == "wgrad_batch":           # (job array, count): one batched weight-gradient flush, re-run into the same gradient slots
-                L.octa_conv2d_wgrad_batch(d, ptrs, st)
+                L.octa_conv2d_wgrad_batch(d, ptrs, fold_args[0], fold_args[1], st)
             elif kind == "fwd":
                 L.octa_conv2d_fwd(ctypes.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[3], st)
             elif kind == "dgrad":
@@ -167,8 +168,6 @@ def roofline_leg(step, rec, batch, dtype_name):
         by = sum(conv_bytes(d[i].d, "wgrad") for i in range(ptrs)) if kind == "wgrad_batch" else conv_bytes(d, kind)
         pending.append((e0, e1, L.octa_last_conv_kernel().decode().split("+tail")[0].split("+fold")[0], fl, by))      # "+tailNxP" / "+fold": the same kernel with its tail split / partial tiles (incl. the fix-up / fold launch)
     torch.cuda.synchronize()
-    F_.set_splitk_workspace(None)
-    F_.set_wgrad_fold_workspace(None)
     peak = PEAK_BF16_TFLOPS if dtype_name in ("bf16", "f16") else PEAK_F32_TFLOPS
     for e0, e1, kname, fl, by in pending:
         ms = e0.elapsed_time(e1)

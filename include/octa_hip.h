@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 309
+#define OCTA_HIP_ABI_VERSION 310
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -71,6 +71,18 @@ typedef struct octa_conv_desc {
     int32_t zero_pad;      /* 1 (groups == 1, no upshuffle): the kernel also stores zeros into the output's
                               padding channels [C, round8(C)) (C = Cout for fwd, Cin for dgrad), so the
                               caller need not pre-clear the buffer; needs off + round8(C) <= ld          */
+    void* ws;              /* optional fp32 scratch of THIS call (caller-owned, 16-byte aligned, ws_bytes long; NULL / 0 = none),
+                              used only by the launches the call issues and never remembered (the library retains no
+                              pointer past return, so calls on different streams simply pass different buffers):
+                              octa_conv2d_fwd / _dgrad / _dgrad_add: the 8-wave kernels' TAIL SPLIT (algo 2 / 3 / 12) -- a launch
+                              whose tile count leaves the last round of CUs at most half full runs those last tiles as 2..8
+                              workgroups each over disjoint input-channel ranges; the partial fp32 tiles go through ws and a second
+                              small launch finishes them (64 MB covers every layer of the path; same results up to fp32 summation
+                              order; without ws nothing splits).
+                              octa_conv2d_wgrad: the M-splits store raw fp32 tiles into private slices of ws instead of adding into
+                              dw with float atomics, and one fold launch sums the slices in a fixed order (see
+                              octa_conv2d_wgrad_batch, which takes the scratch of a whole batch as an argument).            */
+    int64_t ws_bytes;
 } octa_conv_desc;
 
 /* OIHW-logical fp32 weight (any strides, given in elements) -> packed forward operand
@@ -120,13 +132,6 @@ int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w_packed
  * weights): y is complete either way, stats untouched in the latter case and the caller runs the ordinary statistics pass. */
 int octa_conv2d_fwd_stats(const octa_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                           float* stats, const float* shift, int replicas, int* fused_host, octa_stream_t stream);
-/* Optional scratch for the 8-wave kernel's TAIL SPLIT (algo 2 / 3): a launch whose tile count leaves the last round of
- * 256 CUs at most half full runs those last tiles as 2..8 workgroups each over disjoint input-channel ranges; the partial fp32
- * tiles go through `ws` (caller-owned, `bytes` long, 16-byte aligned; 64 MB covers every layer of the path) and a second small
- * launch finishes them.  Same results up to fp32 summation order.  The registration is process-wide and read when a conv is
- * LAUNCHED: launches that may run concurrently on different streams must not both be issued while a workspace is registered
- * (register NULL / 0 around the launches of the other stream).  Default: none registered, nothing splits. */
-int octa_conv_splitk_workspace(float* ws, int64_t bytes);
 /* dx = conv^T(dy, w): dy has the forward OUTPUT geometry (OH,OW,Cout,ldy,yoff), dx the input's. */
 int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_packed_t, void* dx,
                       octa_stream_t stream);
@@ -172,22 +177,18 @@ typedef struct octa_wgrad_job {
     float* dbias;            /* optional */
     int64_t dw_strides[4];   /* o,i,h,w element strides of dw */
 } octa_wgrad_job;
-int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, octa_stream_t stream);
+/* ws / ws_bytes (optional; caller-owned fp32 scratch, 16-byte aligned, used by this call's launches only; 128 MB covers a batch of
+ * every layer of the path): the M-splits of the single-problem kernels (and, with octa_tuning_set(4, 1), of the batched ones) store
+ * raw fp32 tiles into private slices of ws instead of adding into dw with float atomics (384-512 workgroups adding into the same few
+ * KB were half of the few-channel layers' time), and ONE fold launch per call sums the slices in a fixed order and adds the result
+ * to dw / dbias: same += semantics, deterministic.  A job whose slices do not fit what is left of ws keeps the atomic epilogue
+ * (deterministic mode: runs unsplit instead).  The jobs' own d.ws fields are ignored here. */
+int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs_host, int n, float* ws, int64_t ws_bytes, octa_stream_t stream);
 /* Which kernel family octa_conv2d_wgrad_batch runs this job on: 1 = batched 256(N)x128(K) slabs, 2 = batched 128x256
  * slabs, 3 = batched 256x256 tiles (wgrad9), 0 = the single-problem kernels (host-side query; lets the caller group a queue so
  * that one call = one family).
  * Not a status code. */
 size_t octa_wgrad_job_class(const octa_wgrad_job* job_host);
-/* Optional scratch for the single-problem weight-gradient kernel (round 4): with `ws` (caller-owned, `bytes` long, 16-byte
- * aligned; 128 MB covers a batch of every layer of the path) registered, the M-splits of a 16-bit job store raw fp32 tiles into
- * private slices of `ws` instead of adding into dw with float atomics (384-512 workgroups adding into the same few KB were
- * half of the few-channel layers' time), and ONE fold launch per octa_conv2d_wgrad_batch call (per octa_conv2d_wgrad call
- * outside a batch) sums the slices in a fixed order and adds the result to dw / dbias: same += semantics, deterministic.  A
- * job whose slices do not fit what is left of `ws` in the current batch keeps the atomic epilogue.  NULL / 0 withdraws it.
- * Like octa_conv_splitk_workspace the registration is process-wide and read when a weight gradient is LAUNCHED: launches
- * that may run concurrently on different streams need different scratch buffers (register the other one around them)
- * (discriminator/blocks.py:46,97, extra/resnest.py:325-334: the few-channel layers this is for). */
-int octa_wgrad_fold_workspace(float* ws, int64_t bytes);
 /* Name of the kernel template instance the calling thread's last octa_conv2d_fwd / _dgrad / _wgrad
  * call dispatched, e.g. "conv_igemm_kernel<bf16,128x128>", "conv3x3_halo_kernel<bf16,128x64>",
  * "conv_wgrad_kernel<bf16,128>", "conv3x3_wgrad_halo_kernel<4>" (measurement aid: bench.py's roofline
@@ -523,7 +524,13 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
 /* Tuning switches (process-wide; benchmarks and A/B tests).  key 1: which tile families octa_conv2d_wgrad_batch may use,
  * bit 0 = 256x128 / 128x256 (wgrad8), bit 1 = 256x256 (wgrad9); default 3.  key 2: timing-only ablation builds of wgrad9.
  * key 3: smallest Cout / groups the batched kernels accept (default 128).  key 4: 1 = the batched kernels' M-splits also store
- * partial tiles for the fold launch of octa_wgrad_fold_workspace (default 0: their atomics are not contended, measured). */
+ * partial tiles for the fold launch of octa_conv2d_wgrad_batch's scratch (default 0: their atomics are not contended, measured).
+ * key 5: DETERMINISTIC MODE (0 / 1; also OCTA_DETERMINISTIC=1 in the environment; SURVEY 8b "deterministic variant required for parity
+ * tests"): every sum that crosses workgroups runs in a fixed order -- weight gradients through private partial tiles + the ordered fold
+ * (fp32 jobs too) or unsplit when no scratch was passed, the split-attention GAP / logit-gradient / dgap sums, the attention gate's
+ * dw, column sums, the spectral-norm power iteration and dot product and the full-extent conv as ONE workgroup per output address,
+ * no BatchNorm statistics in conv epilogues -- so two runs on the same inputs are bit-identical.  Slower (parity tests; never the
+ * benchmark). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -20,7 +20,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "H", "W", "OH", "OW", "Cin", "Cout", "KH", "KW", "stride", "pad", "groups",
-        "cin_g_pad", "cout_g_pad", "ldx", "xoff", "ldy", "yoff", "dtype", "act", "upshuffle", "algo", "zero_pad")]
+        "cin_g_pad", "cout_g_pad", "ldx", "xoff", "ldy", "yoff", "dtype", "act", "upshuffle", "algo", "zero_pad")] + \
+        [("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_int64)]      # the call's own scratch (tail split / weight-gradient fold)
 
 
 class WgradJob(ctypes.Structure):

@@ -1,6 +1,7 @@
 // Error reporting and version for the C ABI.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/octa_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -14,3 +15,13 @@ void octa_set_error(const char* fmt, ...) {
 
 extern "C" int octa_version(void) { return OCTA_HIP_ABI_VERSION; }
 extern "C" const char* octa_last_error(void) { return g_err; }
+
+// Deterministic mode ("deterministic variant required for parity tests"): every sum that crosses workgroups runs in a
+// fixed order -- private partial tiles + an ordered fold where a scratch is passed, one workgroup per output address otherwise.
+// Slower; parity tests run with it, the benchmark without.  octa_tuning_set(5, 0 / 1), or OCTA_DETERMINISTIC=1 in the environment.
+static int g_det = -1;
+bool octa_deterministic() {
+    if (g_det < 0) { const char* e = getenv("OCTA_DETERMINISTIC"); g_det = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_det == 1;
+}
+void octa_set_deterministic(int on) { g_det = on ? 1 : 0; }

@@ -40,7 +40,8 @@ struct ConvArgs {
     int stats_rep, stats_ctot;
     // tail split-K of the 8-wave kernel (igemm8.hpp): tiles [0, sk_full) run whole, every later tile as sk_parts workgroups over
     // disjoint channel-slice ranges that store raw fp32 partial tiles to sk_ws; igemm8_splitk_fix finishes them.  sk_parts <= 1: off
-    float* sk_ws;
+    float* sk_ws;         // the caller's scratch (octa_conv_desc.ws), sk_cap bytes; NULL = never split
+    int64_t sk_cap;
     int sk_full, sk_parts, sk_gy, sk_tpg;
 };
 
@@ -936,10 +937,11 @@ static int check_desc(const octa_conv_desc* d, const char* who) {
 
 static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats, const float* shift,
                            int replicas, int* fused, octa_stream_t stream);
-extern "C" int octa_conv_splitk_workspace(float* ws, int64_t bytes) {
-    OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_conv_splitk_workspace: 16-byte aligned buffer, or NULL / 0");
-    g_sk_ws = bytes > 0 ? ws : nullptr;
-    g_sk_ws_bytes = g_sk_ws ? bytes : 0;
+// the call's own scratch (octa_conv_desc.ws / ws_bytes): checked here, never kept past the launch
+static int desc_scratch(const octa_conv_desc* d, const char* who, float** ws, int64_t* bytes) {
+    OCTA_REQUIRE(d->ws_bytes >= 0 && (d->ws || d->ws_bytes == 0) && ((uintptr_t)d->ws & 15) == 0, "%s: desc.ws must be a 16-byte aligned buffer of ws_bytes, or NULL / 0", who);
+    *ws = d->ws_bytes > 0 ? (float*)d->ws : nullptr;
+    *bytes = *ws ? d->ws_bytes : 0;
     return OCTA_OK;
 }
 extern "C" int octa_conv2d_fwd(const octa_conv_desc* d, const void* x, const void* w, const float* bias, void* y, octa_stream_t stream) {
@@ -955,6 +957,7 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
                            int replicas, int* fused, octa_stream_t stream) {
     int rc = check_desc(d, "octa_conv2d_fwd");
     if (rc) return rc;
+    if (stats && octa_deterministic()) { stats = nullptr; shift = nullptr; replicas = 0; if (fused) *fused = 0; fused = nullptr; }   // (the epilogue statistics are float atomics: the caller runs the ordinary pass)
     OCTA_REQUIRE(x && w && y, "octa_conv2d_fwd: null pointer");
     const int epc = d->dtype == OCTA_F32 ? 4 : 8;
     ConvArgs a;
@@ -970,7 +973,9 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = stats; a.stats_shift = shift; a.stats_rep = replicas; a.stats_ctot = d->Cout;
-    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
+    rc = desc_scratch(d, "octa_conv2d_fwd", &a.sk_ws, &a.sk_cap);
+    if (rc) return rc;
+    a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && !d->upshuffle && d->yoff + (a.Ng + 7) / 8 * 8 <= d->ldy, "octa_conv2d_fwd: zero_pad needs groups == 1, no upshuffle and yoff + round8(Cout) <= ldy");
         a.NgSt = (a.Ng + 7) / 8 * 8;
@@ -1006,7 +1011,9 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = nullptr; a.stats_shift = nullptr; a.stats_rep = 0; a.stats_ctot = 0;
-    a.sk_ws = nullptr; a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
+    rc = desc_scratch(d, "octa_conv2d_dgrad", &a.sk_ws, &a.sk_cap);
+    if (rc) return rc;
+    a.sk_full = 0; a.sk_parts = 0; a.sk_gy = 0; a.sk_tpg = 1;
     if (d->zero_pad) {
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
         a.NgSt = (a.Ng + 7) / 8 * 8;
@@ -1823,20 +1830,13 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgFoldBatch fb) {
     atomicAdd(J.dw + ((int64_t)n * J.s_o + (int64_t)ci * J.s_i + kh * J.s_h + kw * J.s_w), v);
 }
 
-// the registered scratch (process-wide, read when a session opens) + the open fold session of the calling host thread
-static float* g_fold_ws = nullptr;
-static int64_t g_fold_ws_floats = 0;
+// the open fold session of the calling host thread (lives inside ONE entry-point call: octa_conv2d_wgrad or octa_conv2d_wgrad_batch
+// opens it with the scratch the CALLER passed and closes it before returning; nothing is kept across calls)
 // (full batches wait in `done` until the session closes: a fold launch must follow the LAST kernel that writes its slices, and the
 // batched kernels of wgrad8.hip reserve the slices of up to 20 problems before their one launch)
 static thread_local struct { bool open; hipStream_t st; float* ws; int64_t cap, used; WgFoldBatch fb; int nblk; } g_fold = {};
 static thread_local std::vector<std::pair<WgFoldBatch, int>> g_fold_done;
 
-extern "C" int octa_wgrad_fold_workspace(float* ws, int64_t bytes) {
-    OCTA_REQUIRE(bytes >= 0 && (ws || bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_wgrad_fold_workspace: 16-byte aligned buffer, or NULL / 0");
-    g_fold_ws = bytes > 0 ? ws : nullptr;
-    g_fold_ws_floats = g_fold_ws ? bytes / 4 : 0;
-    return OCTA_OK;
-}
 static void wgrad_fold_park() {          // the current batch is full: keep it for the end of the session
     g_fold_done.emplace_back(g_fold.fb, g_fold.nblk);
     g_fold.fb.n = 0; g_fold.nblk = 0;
@@ -1855,18 +1855,20 @@ static int wgrad_fold_flush() {
     return OCTA_OK;
 }
 // open a session on `st` (nested opens are counted as the outer one); returns true when this call opened it
-bool octa_wgrad_fold_begin(hipStream_t st) {
+bool octa_wgrad_fold_begin(hipStream_t st, float* ws, int64_t ws_floats) {
     if (g_fold.open) return false;
     static const bool off = getenv("OCTA_NO_WGRAD_FOLD") != nullptr;
     g_fold.ws = nullptr; g_fold.cap = 0;
-    if (!off) { g_fold.ws = g_fold_ws; g_fold.cap = g_fold_ws_floats; }
+    if (!off && ws && ws_floats > 0) { g_fold.ws = ws; g_fold.cap = ws_floats; }
     g_fold.open = true; g_fold.st = st; g_fold.used = 0; g_fold.fb.n = 0; g_fold.nblk = 0;
     g_fold_done.clear();
     return true;
 }
 int octa_wgrad_fold_end() {
     g_fold.open = false;
-    return wgrad_fold_flush();
+    const int rc = wgrad_fold_flush();
+    g_fold.ws = nullptr; g_fold.cap = 0;           // the caller's buffer is not remembered past the call
+    return rc;
 }
 // scratch for `split` slices of (Ntot*Kpad + Ntot) floats, or NULL (no session / no room: the atomic epilogue runs)
 static float* wgrad_fold_take(const WgradArgs& a, int groups, int split, int64_t& slice) {
@@ -1893,6 +1895,7 @@ static int wgrad_fold_add(const WgradArgs& a, int groups, int split) {
 // eligibility + launch of the halo weight-gradient kernel; returns false when the generic kernel should run
 static bool launch_wgrad_halo(WgradArgs& a, int groups, int Cin, int Cout, hipStream_t st) {
     if (getenv("OCTA_NO_WGRAD_HALO")) return false;
+    if (octa_deterministic() && !(g_fold.open && g_fold.st == st && g_fold.ws)) return false;     // its tile-range blocks add into one slab: needs the fold
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW) return false;
     int diagNg = 0, diagCg = 0, sets = 1, setC = Cin, setN = Cout;
     if (groups > 1) {
@@ -1926,6 +1929,7 @@ static bool launch_wgrad_halo(WgradArgs& a, int groups, int Cin, int Cout, hipSt
         a.part = wgrad_fold_take(a, groups, nblk, a.part_slice);
         if (a.part && wgrad_fold_add(a, groups, nblk) != OCTA_OK) return false;
     }
+    if (octa_deterministic() && !a.part && nblk > 1) return false;
     if (NT == 4) conv3x3_wgrad_halo_kernel<4><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
     else conv3x3_wgrad_halo_kernel<2><<<grid, 256, 0, st>>>(a, tpb, setC, setN, diagNg, diagCg);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv3x3_wgrad_halo_kernel<%d>%s", NT, a.part ? "+fold" : "");
@@ -1979,9 +1983,16 @@ static int launch_wgrad(WgradArgs& a, int groups, hipStream_t st) {
     split = cdiv(a.M, mps);
     a.splitM = split; a.mPerSplit = mps;
     a.part = nullptr; a.part_slice = 0; a.NtotPart = groups * a.Ng;
-    if (sizeof(T) == 2 && g_fold.open && g_fold.st == st) {
+    const bool det = octa_deterministic();
+    if ((sizeof(T) == 2 || det) && g_fold.open && g_fold.st == st) {
         a.part = wgrad_fold_take(a, groups, split, a.part_slice);
         if (a.part) { const int rc = wgrad_fold_add(a, groups, split); if (rc) return rc; }
+    }
+    if (det && !a.part && split > 1) {
+        // deterministic mode without room for private slices: ONE workgroup per output tile walks all the pixels, so every element of dw
+        // receives exactly one add (slow; parity tests only)
+        split = 1; mps = cdiv(a.M, MT) * MT;
+        a.splitM = 1; a.mPerSplit = mps;
     }
     dim3 grid(tilesK, tilesN, groups * split), block(256);
     static const int sub_env = getenv("OCTA_WGRAD_SUB") ? atoi(getenv("OCTA_WGRAD_SUB")) : 2;
@@ -2025,7 +2036,10 @@ extern "C" int octa_conv2d_wgrad(const octa_conv_desc* d, const void* x, const v
     a.s_o = dw_strides[0]; a.s_i = dw_strides[1]; a.s_h = dw_strides[2]; a.s_w = dw_strides[3];
     a.dbias = dbias;
     a.part = nullptr; a.part_slice = 0; a.NtotPart = d->Cout;
-    const bool mine = octa_wgrad_fold_begin((hipStream_t)stream);     // a lone call folds by itself; inside octa_conv2d_wgrad_batch the batch does
+    float* fws; int64_t fbytes;
+    rc = desc_scratch(d, "octa_conv2d_wgrad", &fws, &fbytes);
+    if (rc) return rc;
+    const bool mine = octa_wgrad_fold_begin((hipStream_t)stream, fws, fbytes / 4);     // a lone call folds by itself (desc.ws); inside octa_conv2d_wgrad_batch the batch's session is open
     if (d->dtype == OCTA_BF16 && launch_wgrad_halo(a, d->groups, d->Cin, d->Cout, (hipStream_t)stream)) {
         rc = OCTA_OK;
         if (hipGetLastError() != hipSuccess) { octa_set_error("conv3x3_wgrad_halo: launch failed"); rc = OCTA_ERR_LAUNCH; }
@@ -2164,10 +2178,12 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
         int TX = 1;
         while (TX < cpr && TX < 256) TX <<= 1;            // power of two >= cpr (<= 256): 256 / TX row lanes
         const int RY = 256 / TX;
+        const bool det = octa_deterministic();
         int64_t rpb = cdiv64(rows, 2048);
         if (rpb < (int64_t)RY * 8) rpb = (int64_t)RY * 8;
+        if (det && !part) rpb = rows;                     // deterministic without partials: one workgroup per column block, one add per address
         dim3 grid(cdiv(cpr, TX), (unsigned)cdiv64(rows, rpb));
-        if (grid.y < 64) part = nullptr;                  // few blocks: plain atomics are cheaper than a second launch
+        if (grid.y < 64 && !(det && grid.y > 1)) part = nullptr;   // few blocks: plain atomics are cheaper than a second launch
         if (dtype == OCTA_F32) colsum_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
         else if (dtype == OCTA_BF16) colsum_vec_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
         else colsum_vec_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)src, rows, cpr, TX, ld, off, out, (int)rpb, part);
@@ -2177,6 +2193,7 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
     }
     int rpb = (int)cdiv64(rows, 512);
     if (rpb < 64) rpb = 64;
+    if (octa_deterministic()) { OCTA_REQUIRE(rows < (1ll << 31), "octa_colsum: too many rows for the deterministic path"); rpb = (int)rows; }
     dim3 grid(cdiv(C, 64), (unsigned)cdiv64(rows, rpb)), block(64, 4);
     if (dtype == OCTA_F32) colsum_kernel<float><<<grid, block, 0, (hipStream_t)stream>>>((const float*)src, rows, C, ld, off, out, rpb);
     else if (dtype == OCTA_BF16) colsum_kernel<bf16_t><<<grid, block, 0, (hipStream_t)stream>>>((const bf16_t*)src, rows, C, ld, off, out, rpb);

@@ -107,8 +107,10 @@ __device__ float block_total(float v, float* red) {   // all threads get the blo
 //   C: u = wv / max(|wv|, eps); sigma = u . wv;  w_sn = W / sigma; block 0 stores u and sigma
 // Every block recomputes the tiny norms (K resp. Cout values) itself, so no grid-wide sync is needed.
 #define SN_ROWS 16
-__global__ __launch_bounds__(256) void spectral_A_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ vraw, int Cout, int K) {
-    const int r0 = blockIdx.x * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+__global__ __launch_bounds__(256) void spectral_A_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ vraw, int Cout, int K, int det) {
+    // det (deterministic mode): workgroup 0 walks all the rows, so every vraw[j] receives ONE add
+    if (det && blockIdx.x != 0) return;
+    const int r0 = det ? 0 : blockIdx.x * SN_ROWS, r1 = det ? Cout : min(Cout, r0 + SN_ROWS);
     for (int j = threadIdx.x; j < K; j += 256) {
         float s = 0.f;
         for (int i = r0; i < r1; ++i) s += w[(int64_t)i * K + j] * u[i];
@@ -179,7 +181,7 @@ extern "C" int octa_spectral_norm_fwd(const float* w, float* u, float* v, int Co
     const int nb = cdiv(Cout, SN_ROWS);
     if (do_power_iter) {
         if (!ws_prezeroed && octa_zero_async(vraw, (size_t)K * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd: memset failed");
-        spectral_A_kernel<<<nb, 256, 0, st>>>(w, u, vraw, Cout, K);
+        spectral_A_kernel<<<nb, 256, 0, st>>>(w, u, vraw, Cout, K, octa_deterministic() ? 1 : 0);
         OCTA_CHECK_LAUNCH("spectral_A");
     }
     spectral_B_kernel<<<nb, 256, (size_t)(K + 4) * sizeof(float), st>>>(w, vraw, v, wv, Cout, K, do_power_iter, eps, uv_saved ? uv_saved + Cout : nullptr);
@@ -221,7 +223,7 @@ extern "C" int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, con
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Cout * K;
     int nb = (int)cdiv64(n, 256 * 8);
-    if (nb < 1) nb = 1;
+    if (nb < 1 || octa_deterministic()) nb = 1;            // (deterministic mode: one workgroup, one add into the dot product)
     if (!ws_prezeroed && octa_zero_async(ws, sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_bwd: memset failed");
     spectral_bwd_dot_kernel<<<nb, 256, 0, st>>>(dw_sn, w_sn, n, ws, K, dwsn_khw);
     OCTA_CHECK_LAUNCH("spectral_bwd_dot");
@@ -249,14 +251,15 @@ __device__ __forceinline__ int sn_job_of(const SnBatch& b, int blk, int& local) 
     local = blk - b.first[j];
     return j;
 }
-__global__ __launch_bounds__(256) void spectral_A_batch_kernel(const SnBatch b) {
+__global__ __launch_bounds__(256) void spectral_A_batch_kernel(const SnBatch b, int det) {
     int lb;
     const int j = sn_job_of(b, blockIdx.x, lb);
+    if (det && lb != 0) return;                // deterministic mode: the job's first workgroup walks all its rows
     const float* __restrict__ w = b.w[j];
     const float* __restrict__ u = b.u[j];
     float* __restrict__ vraw = b.ws[j];
     const int Cout = b.Cout[j], K = b.K[j];
-    const int r0 = lb * SN_ROWS, r1 = min(Cout, r0 + SN_ROWS);
+    const int r0 = det ? 0 : lb * SN_ROWS, r1 = det ? Cout : min(Cout, r0 + SN_ROWS);
     for (int c = threadIdx.x; c < K; c += 256) {
         float s = 0.f;
         for (int i = r0; i < r1; ++i) s += w[(int64_t)i * K + c] * u[i];
@@ -351,7 +354,7 @@ extern "C" int octa_spectral_norm_fwd_batch(const octa_sn_job* jobs, int n, int 
     }
     rb.first[n] = rtot; cb.first[n] = ctot;
     if (do_power_iter) {
-        spectral_A_batch_kernel<<<rtot, 256, 0, st>>>(rb);
+        spectral_A_batch_kernel<<<rtot, 256, 0, st>>>(rb, octa_deterministic() ? 1 : 0);
         OCTA_CHECK_LAUNCH("spectral_A(batch)");
     }
     spectral_B_batch_kernel<<<rtot, 256, (size_t)(kmax + 4) * sizeof(float), st>>>(rb, do_power_iter, eps);
@@ -412,6 +415,7 @@ extern "C" int octa_spectral_norm_bwd_batch(const octa_sn_bwd_job* jobs, int n, 
         b.first[j] = tot;
         const int64_t nel = (int64_t)q.Cout * q.K;
         int nb = (int)cdiv64(nel, 256 * 8);
+        if (octa_deterministic()) nb = 1;
         tot += nb < 1 ? 1 : nb;
         b.dwsn[j] = q.dw_sn; b.wsn[j] = q.w_sn; b.u[j] = q.u; b.v[j] = q.v; b.sigma[j] = q.sigma; b.dw[j] = q.dw; b.dot[j] = q.ws;
         b.K[j] = q.K; b.khw[j] = q.dwsn_khw; b.acc[j] = q.accumulate; b.nel[j] = nel;
@@ -452,7 +456,7 @@ extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bia
     }
     const float* badd = out_prezeroed ? bias : nullptr;      // zeroed `out`: the first workgroup of every sample adds the bias itself
     int nblk = (int)(cdiv64(n, 256 * 8) > 64 ? 64 : cdiv64(n, 256 * 8));
-    if (nblk < 1) nblk = 1;
+    if (nblk < 1 || octa_deterministic()) nblk = 1;
     dim3 grid(nblk, B);
     if (dtype == OCTA_F32) fullconv_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, w, out, n, sign, sign_dev, nblk, badd);
     else if (dtype == OCTA_BF16) fullconv_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, w, out, n, sign, sign_dev, nblk, badd);

@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256) void halo8_splitk_fix_kernel(const ConvArgs a,
 
 // How many parts the tiles behind the last full round are split into (1 = no split): halo8's stages are a (slice, tap) pair, a part
 // is a contiguous range of slices and should keep at least two of them (18 stages) to amortise its prologue
-static int halo8_parts(int tiles, int nsl) {
+static int halo8_parts(const ConvArgs& a, int tiles, int nsl) {
     static const bool off = getenv("OCTA_NO_SPLITK") != nullptr;
-    if (off || !g_sk_ws) return 1;
+    if (off || !a.sk_ws) return 1;
     const int ncu = octa_num_cus();
     const int tail = tiles % ncu;
     if (tail == 0 || tail > ncu / 2) return 1;
@@ -417,7 +417,7 @@ static int halo8_parts(int tiles, int nsl) {
     if (parts > 8) parts = 8;
     if (parts > nsl / 2) parts = nsl / 2;
     if (parts < 2) return 1;
-    if ((int64_t)tail * parts * 256 * 128 * 4 > g_sk_ws_bytes) return 1;
+    if ((int64_t)tail * parts * 256 * 128 * 4 > a.sk_cap) return 1;
     return parts;
 }
 
@@ -436,10 +436,10 @@ static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
     dim3 grid(a.B * tiles_y * tiles_x, cdiv(a.Ng, 128), groups);
     ConvArgs b = a;
     const int tiles = grid.x * grid.y * groups;
-    const int parts = (groups == 1 || a.NgSt == a.Ng) ? halo8_parts(tiles, a.Cg / 64) : 1;
+    const int parts = (groups == 1 || a.NgSt == a.Ng) ? halo8_parts(a, tiles, a.Cg / 64) : 1;
     const int ntail = tiles % octa_num_cus();
     if (parts > 1) {
-        b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
+        b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
         grid = dim3(b.sk_full + ntail * parts, 1, 1);
     }
     if (a.mode == 0) conv_halo8_kernel<T, 0><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y);

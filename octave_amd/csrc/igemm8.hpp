@@ -394,15 +394,11 @@ __global__ __launch_bounds__(256) void igemm8_splitk_fix_kernel(const ConvArgs a
     }
 }
 
-// the caller-owned fp32 scratch of the tail split (octa_conv_splitk_workspace); NULL = never split
-static float* g_sk_ws = nullptr;
-static int64_t g_sk_ws_bytes = 0;
-
 // How many parts the tiles behind the last full round of 256 are split into (1 = no split), for a grid of `tiles` tiles whose K
 // range has `nsl` 64-channel slices of `ntaps` stages each.
-static int splitk_parts(int tiles, int nsl, int ntaps, int64_t tile_floats) {
+static int splitk_parts(const ConvArgs& a, int tiles, int nsl, int ntaps, int64_t tile_floats) {
     static const bool off = getenv("OCTA_NO_SPLITK") != nullptr;
-    if (off || !g_sk_ws) return 1;
+    if (off || !a.sk_ws) return 1;
     static const int maxtail = getenv("OCTA_SK_MAXTAIL") ? atoi(getenv("OCTA_SK_MAXTAIL")) : 128;
     static const int minst = getenv("OCTA_SK_MINSTAGES") ? atoi(getenv("OCTA_SK_MINSTAGES")) : 12;
     const int ncu = octa_num_cus();                        // one workgroup per CU: a round is ncu tiles (256 on MI355X)
@@ -413,7 +409,7 @@ static int splitk_parts(int tiles, int nsl, int ntaps, int64_t tile_floats) {
     if (parts > nsl) parts = nsl;
     while (parts > 1 && (nsl / parts) * ntaps < minst) --parts;    // at least a dozen stages per part: prologue + ring fill are ~4
     if (parts < 2) return 1;
-    if ((int64_t)tail * parts * tile_floats * 4 > g_sk_ws_bytes) return 1;
+    if ((int64_t)tail * parts * tile_floats * 4 > a.sk_cap) return 1;
     return parts;
 }
 
@@ -436,10 +432,10 @@ static bool launch_igemm8(const ConvArgs& a, int groups, int variant, hipStream_
         ConvArgs b = a;
         const int tiles = grid.x * grid.y * groups;
         // (grouped layers: NgSt == Ng, i.e. no pad channels to zero-fill between the groups)
-        const int parts = (!a.upshuffle && !a.stats && (groups == 1 || a.NgSt == a.Ng)) ? splitk_parts(tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
+        const int parts = (!a.upshuffle && !a.stats && (groups == 1 || a.NgSt == a.Ng)) ? splitk_parts(a, tiles, a.Cg / 64, a.KH * a.KW, (int64_t)BM * BN) : 1;
         const int ntail = tiles % octa_num_cus();             // tiles behind the last full round
         if (parts > 1) {
-            b.sk_ws = g_sk_ws; b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
+            b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
             grid = dim3(b.sk_full + ntail * parts, 1, 1);
         }
         if (variant == 0) {

@@ -54,6 +54,7 @@ extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, i
     const int RY = 256 / TX;
     int rpb = cdiv(HW, 64);
     if (rpb < RY * 8) rpb = RY * 8;
+    if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
     const size_t sh = (size_t)256 * epc * sizeof(float);
     if (dtype == OCTA_F32) splat_gap_kernel<float><<<grid, 256, sh, st>>>((const float*)x, gap, HW, C, TX, rpb);
@@ -219,6 +220,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
         const int RY = 256 / TX;
         int rpb = cdiv(HW, 64);
         if (rpb < RY * 8) rpb = RY * 8;
+        if (octa_deterministic()) rpb = HW;
         dim3 grid(gx, cdiv(HW, rpb), B);
         const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
         if (dtype == OCTA_F32) splat_bwd_reduce_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, (const float*)out, dlogits, HW, C, TX, rpb, relu);
@@ -650,6 +652,7 @@ extern "C" int octa_splat_bn_gap(const void* x, const float* mean, const float* 
     const int RY = 256 / TX;
     int rpb = cdiv(HW, 64);
     if (rpb < RY * 8) rpb = RY * 8;
+    if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
     const size_t sh = (size_t)256 * epc * sizeof(float);
     if (dtype == OCTA_F32) splat_gap_bn_kernel<float><<<grid, 256, sh, st>>>((const float*)x, bn, gap, HW, C, TX, rpb);
@@ -683,6 +686,7 @@ extern "C" int octa_splat_bn_bwd_logits(const void* dout, const void* x, const f
     const int RY = 256 / TX;
     int rpb = cdiv(HW, 64);
     if (rpb < RY * 8) rpb = RY * 8;
+    if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
     const size_t sh = (size_t)256 * epc * 2 * sizeof(float);
     if (dtype == OCTA_F32) splat_bwd_reduce_bn_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, HW, C, TX, rpb, relu);
@@ -707,6 +711,7 @@ extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const 
     const int RY = 256 / TX;
     int rpb = cdiv(HW, 64);
     if (rpb < RY * 8) rpb = RY * 8;
+    if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
     const size_t sh = (size_t)256 * epc * 5 * sizeof(float);
     if (dtype == OCTA_F32) splat_bwd_reduce_bn2_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, aux, HW, C, TX, rpb, relu);
@@ -1016,6 +1021,7 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
         int js = Ig / 32;                 // >= 32 rows of W1 per block
         if (js < 1) js = 1;
         if (js > 8) js = 8;
+        if (octa_deterministic()) js = 1;      // one workgroup per 64 channels of dgap: one add per address
         const int nC = cdiv(C, 64) * js;
         if (B <= 16) splat_mlp_bwdCD_kernel<16><<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
         else splat_mlp_bwdCD_kernel<32><<<nC + inter, 256, 0, st>>>(dh1_ws, w1, gap, dgap, dw1, B, C, inter, groups, cdiv(C, 64), js);
@@ -1097,7 +1103,7 @@ template <typename T, int K, int CPL>
 __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ y,
                                                       const T* __restrict__ dmasked, const float* __restrict__ dy, T* __restrict__ dx,
                                                       float* __restrict__ dw, float* __restrict__ dbias, int64_t npix, int HW, int C, int LPP,
-                                                      int mode, float* __restrict__ part /* [gridDim.x][K*C + K] or null */) {
+                                                      int mode, float* __restrict__ part /* [gridDim.x][K*C + K] or null */, int det) {
     constexpr int EPC = DT<T>::EPC;
     extern __shared__ float sm[];   // ws[K][C] then dwred[K][C + 1]
     float* ws = sm;
@@ -1203,6 +1209,31 @@ __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, c
         }
     }
     // block reduction of the weight gradient through LDS atomics, then one global atomic per element
+    if (det) {
+        // deterministic mode: the 256 / LPP pixel slots (and the four waves' bias sums) add in slot order
+        for (int slot = 0; slot < ppb; ++slot) {
+            if ((int)threadIdx.x / LPP == slot) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int ch = lp + j * LPP;
+                    if (ch < cpr)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) dwred[k * C + ch * EPC + e] += dwa[k][j][e];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float s = wave_sum(dba[k]);
+            for (int wv = 0; wv < 4; ++wv) {
+                if ((int)threadIdx.x == wv * 64) dwred[K * C + k] += s;
+                __syncthreads();
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         const int ch = lp + j * LPP;
@@ -1216,6 +1247,7 @@ __global__ __launch_bounds__(256) void aag_bwd_kernel(const T* __restrict__ x, c
     for (int k = 0; k < K; ++k) {
         const float s = wave_sum(dba[k]);
         if ((threadIdx.x & 63) == 0) atomicAdd(&dwred[K * C + k], s);
+    }
     }
     __syncthreads();
     if (part) {
@@ -1288,9 +1320,10 @@ static int aag_bwd_launch(const void* x, const float* w, const float* y, const v
     int cpl;
     const int lpp = aag_lpp(C / DT<T>::EPC, cpl);
     const int ppb = 256 / lpp;
-    const int64_t nb = aag_bwd_blocks(npix, ppb);
+    const int det = octa_deterministic() ? 1 : 0;
+    const int64_t nb = (det && !part) ? 1 : aag_bwd_blocks(npix, ppb);      // (deterministic without the partials workspace: one workgroup)
     const size_t sh = (size_t)(2 * K * C + K) * sizeof(float);
-#define AAG_B(CPLV) aag_bwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, y, (const T*)dmasked, dy, (T*)dx, dw, dbias, npix, HW, C, lpp, mode, part)
+#define AAG_B(CPLV) aag_bwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, y, (const T*)dmasked, dy, (T*)dx, dw, dbias, npix, HW, C, lpp, mode, part, det)
     if (cpl <= 1) AAG_B(1); else if (cpl <= 2) AAG_B(2); else if (cpl <= 4) AAG_B(4);
     else OCTA_FAIL(OCTA_ERR_UNSUPPORTED, "octa_aag_bwd: C=%d too large", C);
 #undef AAG_B

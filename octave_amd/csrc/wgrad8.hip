@@ -662,7 +662,7 @@ static void wg_take_fold(WgProb& p, hipStream_t st) {
     // these kernels add into DIFFERENT tiles' addresses at the full atomic rate, and the slices cost a write and a read more.
     // octa_tuning_set(4, 1) / OCTA_WGRAD8_FOLD=1 turns it on (tests, A/B runs).
     static const bool env_on = getenv("OCTA_WGRAD8_FOLD") != nullptr && atoi(getenv("OCTA_WGRAD8_FOLD")) != 0;
-    if (!(env_on || g_wg8_fold) || p.splitM < 2) return;
+    if (!(env_on || g_wg8_fold || octa_deterministic()) || p.splitM < 2) return;
     const int64_t strides[4] = {p.s_o, p.s_i, p.s_h, p.s_w};
     int64_t slice = 0;
     float* ws = octa_wgrad_fold_reserve(st, p.dw, p.dbias, strides, p.groups * p.Ng, p.Kpad, p.Cg, p.CgReal, p.KW, p.splitM, &slice);
@@ -705,7 +705,7 @@ static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
         static const int minsteps = getenv("OCTA_WG8_MINSTEPS") ? atoi(getenv("OCTA_WG8_MINSTEPS")) : 4;
         auto blocks_at = [&](int64_t s) { int64_t b = 0; for (size_t i = i0; i < i1; ++i) b += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups * ((plans[i].steps + s - 1) / s); return b; };
         int64_t S = maxsteps, best = -1;
-        for (int64_t s = maxsteps; s >= minsteps; s = (s > 64 ? s - s / 32 : s - 1)) {
+        for (int64_t s = maxsteps; s >= minsteps && !octa_deterministic(); s = (s > 64 ? s - s / 32 : s - 1)) {      // (deterministic mode: no M-split, one workgroup per output tile)
             const int64_t rounds = (blocks_at(s) + 255) / 256;
             const int64_t cost = rounds * (s + E);
             if (best < 0 || cost < best) { best = cost; S = s; }
@@ -759,7 +759,7 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
         static const int minsteps = getenv("OCTA_WG9_MINSTEPS") ? atoi(getenv("OCTA_WG9_MINSTEPS")) : 24;
         auto blocks_at = [&](int64_t s) { int64_t b = 0; for (size_t i = i0; i < i1; ++i) b += (int64_t)plans[i].p.tilesN * plans[i].p.tilesK * plans[i].p.groups * ((plans[i].steps + s - 1) / s); return b; };
         int64_t S = maxsteps, best = -1;
-        for (int64_t s = maxsteps; s >= minsteps; s = (s > 64 ? s - s / 32 : s - 1)) {
+        for (int64_t s = maxsteps; s >= minsteps && !octa_deterministic(); s = (s > 64 ? s - s / 32 : s - 1)) {      // (deterministic mode: no M-split)
             const int64_t rounds = (blocks_at(s) + 255) / 256;
             const int64_t cost = rounds * (s + E);
             if (best < 0 || cost < best) { best = cost; S = s; }
@@ -806,7 +806,9 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
 }
 
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
+void octa_set_deterministic(int on);   // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 5) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 5 = deterministic mode (0 / 1)"); octa_set_deterministic(value); return OCTA_OK; }
     if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
     if (key == 4) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 4 = partial tiles + fold for the batched weight-gradient kernels (0 / 1)"); g_wg8_fold = value; return OCTA_OK; }
     if (key == 3) { OCTA_REQUIRE(value >= 8 && value <= 4096, "octa_tuning_set: key 3 = minimum Cout / groups of the batched weight-gradient kernels"); g_wg8_min_ng = value; return OCTA_OK; }
@@ -830,18 +832,19 @@ extern "C" size_t octa_wgrad_job_class(const octa_wgrad_job* job) {
     return 1 + wg8_variant(*job);
 }
 
-extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, octa_stream_t stream) {
+extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, float* ws, int64_t ws_bytes, octa_stream_t stream) {
     OCTA_REQUIRE(jobs != nullptr && n >= 0, "octa_conv2d_wgrad_batch: bad arguments");
+    OCTA_REQUIRE(ws_bytes >= 0 && (ws || ws_bytes == 0) && ((uintptr_t)ws & 15) == 0, "octa_conv2d_wgrad_batch: ws must be a 16-byte aligned buffer of ws_bytes, or NULL / 0");
     static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
     hipStream_t st = (hipStream_t)stream;
     std::vector<WgPlan> plans[2][3];   // [f16][variant]
     // the per-layer jobs of the batch share one fold session: their partial tiles are summed by ONE fold launch (conv.hip)
     struct FoldSession {
         bool mine;
-        explicit FoldSession(hipStream_t s) : mine(octa_wgrad_fold_begin(s)) {}
+        FoldSession(hipStream_t s, float* w, int64_t nfl) : mine(octa_wgrad_fold_begin(s, w, nfl)) {}
         ~FoldSession() { if (mine) octa_wgrad_fold_end(); }
         int close() { const bool m = mine; mine = false; return m ? octa_wgrad_fold_end() : OCTA_OK; }
-    } fold(st);
+    } fold(st, ws_bytes > 0 ? ws : nullptr, ws_bytes / 4);
     for (int i = 0; i < n; ++i) {
         const octa_wgrad_job& j = jobs[i];
         if (off || !wg8_eligible(j)) {

@@ -188,48 +188,49 @@ def _zeroed_f32(shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device), 0
 
 
-# ----------------------------------------------------------------------------- tail split-K scratch of the 8-wave conv kernel
+# ----------------------------------------------------------------------------- per-call scratch of the conv engine
+# The library keeps no device pointer between calls (include/octa_hip.h: octa_conv_desc.ws, octa_conv2d_wgrad_batch's ws): the scratch
+# of the 8-wave kernels' tail split and of the weight gradients' partial-tile fold travels with every call.  WHICH buffer a call gets is
+# host-side context: a training step enters its phase's buffers here (the discriminator's step, replayed on a second stream, has a
+# fold scratch of its own and no tail-split scratch), side branches launch without a tail-split scratch.
 _SPLITK_WS = None
-
-
 _WGRAD_FOLD_WS = None
 
 
 def set_wgrad_fold_workspace(ws: Optional[Tensor]):
-    """Register (None: withdraw) the fp32 scratch of octa_wgrad_fold_workspace: the single-problem weight-gradient kernels then
-    store private partial tiles and one fold launch per batch adds them to the gradient -- no float atomics, deterministic.
-    Read when a weight gradient is launched; phases that run concurrently on two streams register different buffers."""
+    """fp32 scratch handed to every weight-gradient call from now on (None: none): the single-problem kernels then store private
+    partial tiles and one fold launch per batch adds them to the gradient -- no float atomics, deterministic.  Phases that run
+    concurrently on two streams enter different buffers."""
     global _WGRAD_FOLD_WS
-    if ws is None:
-        if _WGRAD_FOLD_WS is not None:
-            lib().octa_wgrad_fold_workspace(None, 0)
-        _WGRAD_FOLD_WS = None
-        return
-    if ws.dtype != torch.float32 or not ws.is_contiguous():
-        raise OctaError("set_wgrad_fold_workspace: contiguous fp32 tensor")
-    lib().octa_wgrad_fold_workspace(_p(ws), ws.numel() * 4)
+    if ws is not None and (ws.dtype != torch.float32 or not ws.is_cuda or not ws.is_contiguous() or ws.data_ptr() % 16):
+        raise OctaError("set_wgrad_fold_workspace: contiguous, 16-byte aligned fp32 device tensor")
     _WGRAD_FOLD_WS = ws
 
 
 def set_splitk_workspace(ws: Optional[Tensor]):
-    """Register (None: withdraw) the fp32 scratch octa_conv_splitk_workspace describes.  Read when a conv is launched: a training
-    step registers it around the segmentor's launches and withdraws it around launches issued for another stream."""
+    """fp32 scratch handed to every forward / data-gradient conv call from now on (None: none) for the 8-wave kernels' tail split."""
     global _SPLITK_WS
-    if ws is None:
-        lib().octa_conv_splitk_workspace(None, 0)
-    else:
-        if ws.dtype != torch.float32 or not ws.is_cuda or not ws.is_contiguous():
-            raise OctaError("split-K workspace: contiguous fp32 device tensor")
-        lib().octa_conv_splitk_workspace(_p(ws), ws.numel() * 4)
+    if ws is not None and (ws.dtype != torch.float32 or not ws.is_cuda or not ws.is_contiguous() or ws.data_ptr() % 16):
+        raise OctaError("split-K workspace: contiguous, 16-byte aligned fp32 device tensor")
     _SPLITK_WS = ws
+
+
+def _fold_ws_args():
+    w = _WGRAD_FOLD_WS
+    return (None, 0) if w is None else (w.data_ptr(), w.numel() * 4)
+
+
+def set_deterministic(on: bool):
+    """octa_tuning_set(5, .): every cross-workgroup sum of the library in a fixed order (parity tests; slower)."""
+    lib().octa_tuning_set(5, 1 if on else 0)
 
 
 # ----------------------------------------------------------------------------- side branches (second stream)
 # A block's shortcut branch (avg-pool -> 1x1 -> BatchNorm of a strided bottleneck; the 1x1 of a decoder block) does not depend on the
 # main branch until the final add.  Issued on a second stream between a fork and a join, it runs BESIDE the main branch: eagerly as a
 # second HIP queue, inside a captured step as a parallel branch of the hipGraph.  autograd replays the stream of every node's forward in
-# its backward and inserts the cross-stream waits itself; what it cannot see is handled here: the tail-split scratch of the conv kernels
-# is process-wide (side-branch launches never split), and a gradient parked in a GradHolder travels by event.
+# its backward and inserts the cross-stream waits itself; what it cannot see is handled here: side-branch launches get no tail-split
+# scratch (the main branch's launches are using it), and a gradient parked in a GradHolder travels by event.
 _SIDE_BRANCH = os.environ.get("OCTA_SIDE_BRANCH", "1") != "0"
 _SIDE_STREAMS = {}
 _IN_SIDE = False
@@ -249,16 +250,13 @@ class no_splitk:
         _NO_SPLIT -= 1
 
 
-def _launch_unsplit(fn):
-    """Run the conv launch `fn` with the tail-split scratch withdrawn when a side branch asked for it."""
-    if _NO_SPLIT and _SPLITK_WS is not None:
-        lib().octa_conv_splitk_workspace(None, 0)
-        try:
-            fn()
-        finally:
-            lib().octa_conv_splitk_workspace(_p(_SPLITK_WS), _SPLITK_WS.numel() * 4)
+def _set_conv_ws(d):
+    """The tail-split scratch of this fwd / dgrad call: the phase's buffer, or none inside a side branch."""
+    w = None if _NO_SPLIT else _SPLITK_WS
+    if w is None:
+        d.ws, d.ws_bytes = None, 0
     else:
-        fn()
+        d.ws, d.ws_bytes = w.data_ptr(), w.numel() * 4
 
 
 class SideBranch:
@@ -551,15 +549,17 @@ def _choose_algo(kind: str, d, launch) -> int:
         return a
     if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
-    cg = d.cin_g_pad if kind == "fwd" else d.cout_g_pad
+    cg = d.cin_g_pad if kind in ("fwd", "fwd_stats") else d.cout_g_pad
     cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
-    if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind == "fwd" or d.stride == 1):
+    if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind in ("fwd", "fwd_stats") or d.stride == 1):
         cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
-    if kind != "dgrad_add" and cg in (32, 64) and d.groups in (1, 2, 4, 8) and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
+    if kind == "fwd_stats":
+        pass                        # (the resident-weight, pointwise-GEMM and 2-D patch kernels cannot take the statistics along)
+    elif kind != "dgrad_add" and cg in (32, 64) and d.groups in (1, 2, 4, 8) and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
-    if cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
+    if kind != "fwd_stats" and cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
         cands += [9, 10, 11]        # persistent pointwise GEMM (pwgemm.hpp): 256x128, 128x256, 128x128 tiles, cross-tile pipelined
-    if kind != "dgrad_add" and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
+    if kind not in ("dgrad_add", "fwd_stats") and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
         cands += [12]               # 8-wave 3x3 kernel, 2-D pixel patch per tile (halo8.hpp)
     best, best_t = 1, None
     if len(cands) > 1:
@@ -593,26 +593,35 @@ class ConvStats:
 def _launch_fwd(d, x, wp, bias, y, stats: Optional["ConvStats"] = None):
     L, st = lib(), _st()
     px, pw, pb, py = _p(x), _p(wp), _p(bias), _p(y)
-    d.algo = _choose_algo("fwd", d, lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
+    _set_conv_ws(d)                 # (before the tuner: its timing launches are this call's launches)
     if stats is not None:
+        # the statistics-fusing launch is its own shape class: only kernels that can fuse are candidates, and they are timed as such
         flag = ctypes.c_int(0)
-        L.octa_conv2d_fwd_stats(ctypes.byref(d), px, pw, pb, py, _p(stats.sums), _p(stats.shift), stats.replicas, ctypes.byref(flag), st)
+
+        def launch_stats():
+            L.octa_conv2d_fwd_stats(ctypes.byref(d), px, pw, pb, py, _p(stats.sums), _p(stats.shift), stats.replicas, ctypes.byref(flag), st)
+        d.algo = _choose_algo("fwd_stats", d, launch_stats)
+        if _AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            stats.sums.zero_()      # (the tuner's launches added into the accumulators)
+        launch_stats()
         stats.fused = bool(flag.value)
         return
-    _launch_unsplit(lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
+    d.algo = _choose_algo("fwd", d, lambda: L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st))
+    L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
 
 
 def _launch_dgrad(d, dy, wt, dx, addend=None):
     L, st = lib(), _st()
     pdy, pw, pdx = _p(dy), _p(wt), _p(dx)
+    _set_conv_ws(d)
     if addend is not None:
         # dx = conv^T(dy) + addend in the kernel's epilogue (the generic / LDS-DMA kernels; tuned as its own shape class)
         pa, lda = _p(addend), nhwc_ld(addend)
         d.algo = _choose_algo("dgrad_add", d, lambda: L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st))
-        _launch_unsplit(lambda: L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st))
+        L.octa_conv2d_dgrad_add(ctypes.byref(d), pdy, pw, pa, lda, pdx, st)
         return
     d.algo = _choose_algo("dgrad", d, lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
-    _launch_unsplit(lambda: L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st))
+    L.octa_conv2d_dgrad(ctypes.byref(d), pdy, pw, pdx, st)
 
 
 def _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, ldx, ldy, dtype, act=ACT_NONE, upshuffle=0) -> ConvDesc:
@@ -798,13 +807,14 @@ def flush_wgrads(min_jobs: int = 1) -> int:
             # (recording tools want one entry per layer; otherwise the single-problem jobs travel as one batch too, so that their
             # partial tiles are folded by ONE launch: octa_wgrad_fold_workspace)
             for j, keep in jobs:
+                j.d.ws, j.d.ws_bytes = _fold_ws_args()
                 L.octa_conv2d_wgrad(ctypes.byref(j.d), j.x, j.dy, j.dw, j.dw_strides, j.dbias, st)
                 _record("wgrad", j.d, (j.x, j.dy, keep[2], keep[3]), keep)
             continue
         arr = (WgradJob * len(jobs))()
         for i, (j, keep) in enumerate(jobs):
             ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(j), ctypes.sizeof(WgradJob))
-        L.octa_conv2d_wgrad_batch(arr, len(jobs), st)
+        L.octa_conv2d_wgrad_batch(arr, len(jobs), *_fold_ws_args(), st)
         if _RECORD is not None:
             _RECORD.append(("wgrad_batch", arr, len(jobs), [k for _, k in jobs]))
     n = len(q)
@@ -877,12 +887,15 @@ def raw_conv_wgrad(x: Tensor, dy: Tensor, w: Tensor, stride: int, pad: int, grou
     for a, sv in enumerate(dw.stride()):
         j.dw_strides[a] = sv
     keep = (x, dy, tuple(dw.shape), tuple(dw.stride()), dw, dbias)
-    if defer and _WGRAD_Q is not None:
+    if defer and _WGRAD_Q is not None and not _IN_SIDE:
+        # (a side branch's x / dy live in the side stream's allocator pool: their weight gradient is launched there and then, not
+        # parked for a flush on the main stream)
         _WGRAD_Q.append((j, keep))
         return dw
     L = lib()
     # (a non-deferrable job that is wide enough for the 8-wave kernel could go there as a batch of one: measured 0.07 ms per
     # step for the four 15-channel discriminator convs, at the price of six 30 us launches in that kernel's statistics - not taken)
+    d.ws, d.ws_bytes = _fold_ws_args()
     L.octa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _strides4(dw), _p(dbias), _st())
     _record("wgrad", d, (_p(x), _p(dy), tuple(dw.shape), tuple(dw.stride())), (x, dy))
     return dw

@@ -422,10 +422,10 @@ class TrainStep:
         self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
         self._disc_stream = None
-        # 64 MB of fp32 scratch for the 8-wave conv kernel's tail split (octa_conv_splitk_workspace): the 25 x 25 / 50 x 50 decoder
+        # 64 MB of fp32 scratch for the 8-wave conv kernel's tail split (octa_conv_desc.ws): the 25 x 25 / 50 x 50 decoder
         # layers launch 316 / 626 tiles on 256 CUs
         self._sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=next(net.parameters()).device) if os.environ.get("OCTA_SPLITK", "1") != "0" else None
-        # scratch of the partial-store weight gradients (octa_wgrad_fold_workspace): one per phase, because the discriminator's step
+        # scratch of the partial-store weight gradients (octa_conv2d_wgrad_batch's ws): one per phase, because the discriminator's step
         # replays on a second stream beside the segmentor's backward pass.  The largest batch of single-problem jobs (the four halo-kernel layers of decoder_0 / decoder_1: 38 MB each) needs ~170 MB.  (The batched 8-wave kernels can use it too, octa_tuning_set(4, 1)
         # with OCTA_WGRAD_FOLD_MB=1024: measured +0.1 ms per step, their atomics are not contended; off.)
         fold_on = os.environ.get("OCTA_WGRAD_FOLD", "1") != "0"
@@ -517,9 +517,9 @@ class TrainStep:
             self._started.append(i)
 
     def _phase_segmentor(self, x, ys, out, disc, hooks=False, between=None):
-        # the tail-split scratch and the zero slab are process-wide and read by every conv at launch time: registered for THIS
-        # phase only (withdrawn in the finally below), so that a conv launched on another stream between steps -- a validation
-        # forward, a second TrainStep -- never shares the partial-tile workspace
+        # the phase's scratch buffers are host-side context (functional._SPLITK_WS / _WGRAD_FOLD_WS) that every conv CALL of the phase
+        # carries in its own arguments (octa_conv_desc.ws; the library keeps no pointer): entered for THIS phase only, so that a conv
+        # launched between steps -- a validation forward, a second TrainStep -- never shares the partial-tile workspace
         F_.set_splitk_workspace(self._sk_ws)
         F_.set_wgrad_fold_workspace(self._fold_ws)
         try:
@@ -532,41 +532,44 @@ class TrainStep:
         self.seg_arena.zero_grad()
         F_.ZERO_SLAB.begin(x.device)          # one clear for every small fp32 accumulator of the step
         self._started = []
+        hooked = frozen = False
+        # ONE try / finally around everything behind begin(): whatever raises (the forward, a loss, the discriminator call, backward),
+        # the slab is ended, the discriminator's parameters get their requires_grad back and the mark hooks are cleared -- the next
+        # step or a validation forward never meets a half-open slab or a frozen discriminator
         try:
             att, agg, _ = self.seg(x)
-        except BaseException:
-            F_.ZERO_SLAB.end()
-            raise
-        l = F_.wpce_dice(agg, ys, from_logits=True)
-        loss = l[0] + l[1] if self.use_dice else l[0]
-        out["wpce"], out["dice"] = l[0].detach(), l[1].detach()
-        if self.adversarial:
-            p = F_.class_softmax(agg)
-            kl = F_.interlayer_kl([p, *att], [1] * len(att))[0]
-            # the generator pass only needs dL/d(att) through D: D's own weight gradients of this pass are discarded
-            # (zeroed before D's step, here and in the reference), so they are not computed at all
-            for q in self.disc_arena.params:
-                q.requires_grad_(False)
-            # (this is also what makes the concurrent discriminator graph safe: with requires_grad off nothing in the segmentor's
-            # backward pass writes the discriminator's gradient arena, which that graph zeroes and fills on its own stream)
-            g_adv = F_.lsgan_generator(disc(att))
-            assert not any(q.requires_grad for q in self.disc_arena.params)
-            loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
-            out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
-        att_out = [a.detach() for a in att]
-        if between is not None:
-            between(att_out)                  # capture(): the forward graph ends here (the discriminator's step only needs att_out)
-        if callable(hooks):
-            F_.add_mark_hook(hooks, getattr(hooks, "tags", None) or self._tag_to_bucket.keys())     # capture(): cuts the graph at the bucket-completing marks
-        elif hooks:
-            F_.add_mark_hook(self._on_mark, self._tag_to_bucket.keys())
-        try:
+            l = F_.wpce_dice(agg, ys, from_logits=True)
+            loss = l[0] + l[1] if self.use_dice else l[0]
+            out["wpce"], out["dice"] = l[0].detach(), l[1].detach()
+            if self.adversarial:
+                p = F_.class_softmax(agg)
+                kl = F_.interlayer_kl([p, *att], [1] * len(att))[0]
+                # the generator pass only needs dL/d(att) through D: D's own weight gradients of this pass are discarded
+                # (zeroed before D's step, here and in the reference), so they are not computed at all
+                frozen = True
+                for q in self.disc_arena.params:
+                    q.requires_grad_(False)
+                # (this is also what makes the concurrent discriminator graph safe: with requires_grad off nothing in the segmentor's
+                # backward pass writes the discriminator's gradient arena, which that graph zeroes and fills on its own stream)
+                g_adv = F_.lsgan_generator(disc(att))
+                assert not any(q.requires_grad for q in self.disc_arena.params)
+                loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
+                out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
+            att_out = [a.detach() for a in att]
+            if between is not None:
+                between(att_out)                  # capture(): the forward graph ends here (the discriminator's step only needs att_out)
+            if hooks:
+                hooked = True
+                if callable(hooks):
+                    F_.add_mark_hook(hooks, getattr(hooks, "tags", None) or self._tag_to_bucket.keys())     # capture(): cuts the graph at the bucket-completing marks
+                else:
+                    F_.add_mark_hook(self._on_mark, self._tag_to_bucket.keys())
             self._scaled(loss).backward()
             F_.flush_wgrads()
         finally:
-            if hooks:
+            if hooked:
                 F_.clear_mark_hooks()
-            if self.adversarial:
+            if frozen:
                 for q in self.disc_arena.params:
                     q.requires_grad_(True)
             F_.ZERO_SLAB.end()

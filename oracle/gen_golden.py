@@ -360,6 +360,8 @@ def gen_trainstep():
         for k, pr in net.segmentor.named_parameters():
             if pr.grad is not None:
                 d[f"seg_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+                if k in grads:
+                    d[f"seg_grad{tag}/{k}"] = _np(pr.grad.contiguous().flatten()[::grad_stride(pr.numel())])
         net.zero_grad()
         l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
         l_d.backward()
@@ -488,7 +490,21 @@ def gen_unet304():
 
 
 
-def _adversarial_step_fixture(B, H, d, noise_seed=2024, logits=False):
+# Full gradients stored by the conditioned 400 x 400 fixture: sixteen tensors spread over all ten gradient buckets of the train step
+# (octave_amd/train.py SEG_GRAD_ORDER), every kernel family of the weight gradients among them (stem 3 -> 32, grouped split-attention
+# convs, the big decoder 3x3s, the up-shuffle, the attention micro-net, BatchNorm affine, the 1x1 gates / head).  Tensors beyond
+# 40 000 elements are stored as flat[::stride] of the OIHW-logical order.
+GRAD_TENSORS_400C = (
+    "fc.weight", "decoder_0.conv.0.weight", "decoder_0.conv.3.conv.weight", "upsampling_0.up.weight", "decoder_1.conv.3.conv.weight",
+    "aag_2.conv1.weight", "decoder_2.conv.3.fc1.weight", "decoder_2.conv.0.weight", "decoder_3.conv.3.bn0.weight", "decoder_4.conv.0.weight",
+    "encoder_4.2.conv3.weight", "encoder_3.0.conv2.fc1.weight", "encoder_2.0.conv1.weight", "encoder_1.0.conv2.conv.weight",
+    "encoder_0_1_2.0.3.weight", "encoder_0_1_2.0.0.weight")
+
+
+from oracle.gen_golden_meta import grad_stride  # noqa: E402
+
+
+def _adversarial_step_fixture(B, H, d, noise_seed=2024, logits=False, scale=None, grads=(), logits_sub=1):
     """One full adversarial step on the reference modules at (B, H): the four loss parts, both losses and every
     gradient norm, in fp32 and (same modules, .double()) in float64.  logits=True also stores the segmentor's logits (the
     float64 twin rounded to float32: 2e-6 absolute, three orders below the reference's own fp32-vs-fp64 band)."""
@@ -507,14 +523,14 @@ def _adversarial_step_fixture(B, H, d, noise_seed=2024, logits=False):
         d[f"uniform{c}"] = _np(torch.FloatTensor(1).uniform_(0, 1))
     for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
         net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False)
-        fill_state_dict(net.state_dict())
+        fill_state_dict(net.state_dict(), scale=scale)
         net = net.to(dt).train()
         xx, yy = x.to(dt), ys.to(dt)
         real_pyr = [real[:, :, ::2 ** i, ::2 ** i].contiguous().to(dt) for i in range(5)]
         torch.manual_seed(noise_seed)
         att, agg, _ = net.segmentor(xx)
         if logits:
-            d["agg" + ("_f64_as_f32" if tag else "")] = _np(agg).astype(np.float32)
+            d["agg" + ("_f64_as_f32" if tag else "")] = _np(agg[:, :, ::logits_sub, ::logits_sub]).astype(np.float32)
         p = F.softmax(agg, dim=1)
         parts = [net.supervised_loss(p, yy), DiceLoss()(p, yy), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
         l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
@@ -525,6 +541,8 @@ def _adversarial_step_fixture(B, H, d, noise_seed=2024, logits=False):
         for k, pr in net.segmentor.named_parameters():
             if pr.grad is not None:
                 d[f"seg_gradnorm{tag}/{k}"] = _np(pr.grad.double().norm())
+                if k in grads:
+                    d[f"seg_grad{tag}/{k}"] = _np(pr.grad.contiguous().flatten()[::grad_stride(pr.numel())])
         net.zero_grad()
         l_d = net.discriminatorial_loss(net.discriminator(real_pyr), net.discriminator([a.detach() for a in att]))
         l_d.backward()
@@ -540,6 +558,18 @@ def gen_trainstep400():
     d = {}
     _adversarial_step_fixture(2, 400, d, logits=True)
     _save("trainstep_400.npz", d)
+
+
+def gen_trainstep400c():
+    """The WELL-CONDITIONED twin of trainstep_400: B = 4 (every split-attention bn1 normalises over four samples instead of two,
+    extra/resnest.py:120-121) and the discriminator's full-extent head scaled by COND_SCALE so that the LS-GAN generator term is O(1)
+    (g_adv ~ 1 instead of 180 of a loss of ~20; discriminator/blocks.py:68-72).  Everything else as trainstep_400; the logits are
+    stored on every second row / column, and sixteen FULL gradients (GRAD_TENSORS_400C) beside every gradient norm."""
+    from oracle.fill import COND_SCALE
+    d = {}
+    _adversarial_step_fixture(4, 400, d, logits=True, scale=COND_SCALE, grads=GRAD_TENSORS_400C, logits_sub=2)
+    d["cond_scale_head"] = np.array([COND_SCALE["discriminator.out.0.weight"]])
+    _save("trainstep_400c.npz", d)
 
 
 def gen_round4():
@@ -633,7 +663,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     torch.manual_seed(0)
     which = sys.argv[1:] or ["blocks", "losses", "disc", "unet", "trainstep", "extras", "unet304", "trainstep304", "round3",
-                             "trainstep400", "round4"]
+                             "trainstep400", "round4", "trainstep400c"]
     if "blocks" in which:
         gen_blocks()
     if "losses" in which:
@@ -654,5 +684,7 @@ if __name__ == "__main__":
         gen_round3()
     if "trainstep400" in which:
         gen_trainstep400()
+    if "trainstep400c" in which:
+        gen_trainstep400c()
     if "round4" in which:
         gen_round4()

@@ -97,15 +97,33 @@ def test_group_merge_factor_host_logic():
     assert F_._densify(4, 64, 128, 3, 3, 2, 1, 200, 200, bf) == 0
 
 
-def test_wgrad_fold_workspace_argument_checks(L):
-    """octa_wgrad_fold_workspace: NULL / 0 withdraws, a misaligned or negative-size buffer is refused (no launch involved)."""
-    from octave_amd._lib import OctaError
-    L.octa_wgrad_fold_workspace(None, 0)                     # (the binding raises on a non-zero status)
+def test_scratch_argument_checks(L):
+    """The per-call scratch (octa_conv_desc.ws, octa_conv2d_wgrad_batch's ws): a misaligned or negative-size buffer is refused before any
+    launch; NULL / 0 = none.  (No registration entry points exist any more: the library keeps no device pointer between calls.)"""
+    from octave_amd._lib import OctaError, WgradJob
+    assert not hasattr(L._dll, "octa_conv_splitk_workspace") and not hasattr(L._dll, "octa_wgrad_fold_workspace")
+    jobs = (WgradJob * 1)()
+    L.octa_conv2d_wgrad_batch(jobs, 0, None, 0, None)         # empty batch, no scratch: nothing launched
     with pytest.raises(OctaError, match="aligned"):
-        L.octa_wgrad_fold_workspace(ctypes.c_void_p(8), 1 << 20)
+        L.octa_conv2d_wgrad_batch(jobs, 0, ctypes.c_void_p(8), 1 << 20, None)
     with pytest.raises(OctaError, match="aligned|NULL"):
-        L.octa_wgrad_fold_workspace(None, 1 << 20)
-    L.octa_wgrad_fold_workspace(None, 0)
+        L.octa_conv2d_wgrad_batch(jobs, 0, None, 1 << 20, None)
+
+
+def test_no_static_device_pointer_in_csrc():
+    """SURVEY 8(b) Ownership: the library never retains a device pointer past return.  Static check: no file-scope pointer variable in
+    csrc/ (thread-local call-scoped session state and host-side strings excepted)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octave_amd", "csrc")
+    bad = []
+    for fn in sorted(os.listdir(root)):
+        if not fn.endswith((".hip", ".hpp", ".cpp")):
+            continue
+        for i, line in enumerate(open(os.path.join(root, fn)), 1):
+            if re.match(r"^static\s+(?!thread_local)(?!const\s+char)(?!inline)(?!bool\b)(?!int\b)[\w:<> ]*\*\s*g_\w+", line):
+                bad.append(f"{fn}:{i}: {line.strip()}")
+    assert not bad, "file-scope device pointer(s): " + "; ".join(bad)
 
 
 def test_bench_rank0_block_issues_no_training_step():

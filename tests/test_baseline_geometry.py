@@ -112,7 +112,7 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
     seen = set()
     sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
     for algo in (0, 2, 3, 8, 1, 102, 103, 12, 112, 9, 10, 7):      # 12 / 112: the 2-D patch kernel (halo8.hpp) without / with the scratch; 9 / 10: pwgemm.hpp (1x1 layers); 7: resident weights
-        # 102 / 103: the 8-wave kernel with the tail-split scratch registered (octa_conv_splitk_workspace): the 316-tile (25 x 25)
+        # 102 / 103: the 8-wave kernel with the tail-split scratch registered (octa_conv_desc.ws): the 316-tile (25 x 25)
         # and 626-tile (50 x 50) launches then run their last 60 / 114 tiles as 4 / 2 workgroups each + the fix-up launch
         split = algo >= 100
         F_._ALGO_OVERRIDE = algo % 100

@@ -651,7 +651,7 @@ def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 256, 20, 20, 136, 1), (1, 512, 25, 25, 256, 2), (3, 384, 9, 30, 128, 1)])
 def test_halo8_tail_split_vs_torch(dev, case, dtype):
-    """halo8 with the tail-split scratch registered (octa_conv_splitk_workspace): a handful of tiles on 256 CUs, so every tile is
+    """halo8 with the tail-split scratch registered (octa_conv_desc.ws): a handful of tiles on 256 CUs, so every tile is
     split over the 64-channel slices into 2-3 parts of raw fp32 partial tiles that halo8_splitk_fix_kernel sums, biases, activates
     and stores at the patch's pixels; forward and data gradient against torch's CPU conv."""
     from octave_amd import functional as F_
@@ -682,6 +682,48 @@ def test_halo8_tail_split_vs_torch(dev, case, dtype):
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
     check(f"halo8 split dgrad {case} [{dname}]", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
+def test_two_streams_split_convs_with_their_own_scratch(dev):
+    """SURVEY 8(b) "re-entrant across streams": the tail-split scratch travels in the call (octa_conv_desc.ws), so two streams run
+    split convs CONCURRENTLY, each with a buffer of its own, with no registration dance: 20 alternating launches per stream of two
+    different layers, every result equal to the same layer run alone (bit for bit: the split is deterministic)."""
+    import ctypes
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    L = lib()
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(31)
+    layers = []
+    for (B, Cin, H, W, Cout) in [(2, 256, 20, 20, 136), (1, 512, 25, 25, 256)]:
+        x = F_.to_nhwc((torch.randn(B, Cin, H, W, generator=gen)).to(dev), dtype=dtype)
+        w = torch.nn.Parameter((torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05).to(dev).contiguous(memory_format=torch.channels_last))
+        wp = F_._packed(w, "fwd", dtype, 1, F_.round8(Cin))
+        y = F_.nhwc_empty(B, Cout, H, W, dtype, dev)
+        d = F_._desc(B, H, W, H, W, Cin, Cout, 3, 3, 1, 1, 1, F_.nhwc_ld(x), F_.nhwc_ld(y), dtype)
+        d.algo = 12
+        ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        layers.append((d, x, wp, y, ws, w))
+    torch.cuda.synchronize()
+    alone = []
+    for d, x, wp, y, ws, _ in layers:
+        L.octa_conv2d_fwd(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert "+tail" in L.octa_last_conv_kernel().decode(), L.octa_last_conv_kernel().decode()
+        torch.cuda.synchronize()
+        alone.append(y.clone())
+        y.zero_()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [[], []]
+    for it in range(20):
+        for si, (d, x, wp, y, ws, _) in enumerate(layers):
+            with torch.cuda.stream(streams[si]):
+                L.octa_conv2d_fwd(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), streams[si].cuda_stream)
+                outs[si].append(y.clone())
+    torch.cuda.synchronize()
+    for si in range(2):
+        for it, o in enumerate(outs[si]):
+            assert torch.equal(o, alone[si]), f"stream {si} launch {it}: differs from the layer run alone"
 
 
 ADD_CASES = [
@@ -833,7 +875,7 @@ def test_resident_weight_conv_vs_torch(dev, case, grid, dtype, monkeypatch):
 
 
 FOLD_CASES = [
-    # Cin, Cout, k, s, p, g, B, H, W, bias : the few-channel weight gradients (partial tiles + fold, octa_wgrad_fold_workspace)
+    # Cin, Cout, k, s, p, g, B, H, W, bias : the few-channel weight gradients (partial tiles + fold, the fold scratch)
     (2, 64, 4, 2, 1, 1, 2, 96, 96, True),       # discriminator stack_0
     (3, 32, 3, 2, 1, 1, 2, 80, 72, False),      # stem
     (64, 13, 1, 1, 0, 1, 2, 50, 44, True),      # squeeze conv (13 output channels)
@@ -981,7 +1023,7 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
 def test_wgrad_batch_vs_torch(dev, dtype, fold):
     """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations of wgrad8, the 256 x 256 tiles of wgrad9, grouped convs,
     strided ones, a small-N job that falls through to the single-problem kernel, fused bias gradients) in ONE call against
-    torch's CPU gradients.  fold: with octa_wgrad_fold_workspace registered the M-split jobs of every kernel family store
+    torch's CPU gradients.  fold: with the fold scratch registered the M-split jobs of every kernel family store
     partial tiles and the batch ends in fold launches (two of them: more than 16 jobs would need a third); the gradients must
     also be bit-identical between two runs."""
     import ctypes
@@ -1024,14 +1066,14 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold):
     if fold:
         L.octa_tuning_set(4, 1)       # the batched kernels too (off by default: no gain in situ)
     try:
-        L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+        L.octa_conv2d_wgrad_batch(jobs, len(cases), *F_._fold_ws_args(), torch.cuda.current_stream().cuda_stream)
         first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in keep]
         if fold:
             for _, _, dw, db in keep:
                 dw.zero_()
                 if db is not None:
                     db.zero_()
-            L.octa_conv2d_wgrad_batch(jobs, len(cases), torch.cuda.current_stream().cuda_stream)
+            L.octa_conv2d_wgrad_batch(jobs, len(cases), *F_._fold_ws_args(), torch.cuda.current_stream().cuda_stream)
     finally:
         F_.set_wgrad_fold_workspace(None)
         L.octa_tuning_set(4, 0)

@@ -195,6 +195,144 @@ def test_hip_adversarial_step_400_vs_reference(dev, golden):
     _norm_band("trainstep 400 disc", gnd, G, "disc_gradnorm/", "disc_gradnorm_f64/", floor=2e-3)
 
 
+def test_oracle_trainstep_400c_conditioned(golden):
+    """The oracle's step on the CONDITIONED 400 x 400 fixture (B = 4, discriminator head scaled by COND_SCALE): logits, losses, gradient
+    norms and the sixteen full gradients against the reference's."""
+    from oracle.fill import COND_SCALE
+    from oracle.shapes import octa_state_shapes
+    from test_oracle import make_state
+    G = golden("trainstep_400c.npz")
+    Bn, H = 4, 400
+    assert float(G["cond_scale_head"][0]) == COND_SCALE["discriminator.out.0.weight"]
+    P = make_state(octa_state_shapes(H, with_disc=True))
+    with torch.no_grad():
+        P["discriminator.out.0.weight"].mul_(COND_SCALE["discriminator.out.0.weight"])
+    x, ys, real = _step_inputs(Bn, H)
+    noise = [torch.from_numpy(G[f"noise{c}"]) for c in range(3)]
+    flip = [bool(G[f"uniform{c}"][0] < 0.1) for c in range(3)]
+    l_seg, att, agg = R.segmentor_loss(P, x, ys, noise=noise[0], flip=flip[0])
+    ref32, ref64 = G["agg"], G["agg_f64_as_f32"].astype(np.float64)
+    band = float(np.abs(ref32 - ref64).max())
+    assert float(np.abs(agg.detach()[:, :, ::2, ::2].numpy() - ref32).max()) <= 0.05 * band + 1e-4 * float(np.abs(ref32).max())
+    l_seg.backward()
+    assert abs(l_seg.item() - float(G["l_seg"])) <= 1e-5 * abs(float(G["l_seg"]))
+    dev_ = [abs(P["segmentor." + k[13:]].grad.double().norm().item() - float(g)) / float(g) for k, g in G.items()
+            if k.startswith("seg_gradnorm/") and float(g) > 1e-9]
+    assert np.median(dev_) <= 2e-3 and np.max(dev_) <= 5e-2, (np.median(dev_), np.max(dev_))
+    from oracle.gen_golden_meta import grad_stride
+    for k, g in G.items():
+        if k.startswith("seg_grad/"):
+            q = P["segmentor." + k[9:]].grad
+            got = q.contiguous().flatten()[::grad_stride(q.numel())].numpy()
+            g64 = G["seg_grad_f64/" + k[9:]]
+            e_ref = np.linalg.norm(g - g64) / np.linalg.norm(g64)
+            assert np.linalg.norm(got - g) / np.linalg.norm(g64) <= 0.25 * e_ref + 1e-5, (k, e_ref)
+
+
+@pytest.fixture
+def deterministic():
+    """Deterministic mode of the library for one test (octa_tuning_set(5, .): every cross-workgroup sum in a fixed order)."""
+    from octave_amd import functional as F_
+    F_.set_deterministic(True)
+    try:
+        yield
+    finally:
+        F_.set_deterministic(False)
+
+
+@pytest.mark.gpu
+def test_hip_adversarial_step_400c_conditioned_vs_reference(dev, golden, deterministic):
+    """The headline resolution on a WELL-CONDITIONED fixture (B = 4: every split-attention bn1 normalises over four samples; the
+    discriminator's head scaled so that g_adv ~ 1 instead of 180): the reference's own fp32 gradient norms sit a median of 0.12 % / p95
+    0.9 % from its float64 twin here (1.3 % / 5.5 % in trainstep_400), so the bounds can be the ones the review asked for.  The library
+    runs in DETERMINISTIC mode: the step is evaluated twice and must be bit-identical (logits, every gradient), and
+      * logits: max |hip - ref64| <= BAND x max |ref32 - ref64| (no factor 2), RMS likewise;
+      * gradient norms: median <= BAND_GRAD x reference + 2 %, p95 <= BAND_GRAD x reference + 10 %, no tensor beyond 75 %;
+      * sixteen FULL gradients spread over the ten buckets: relative L2 distance to float64 <= BAND_GRAD x the reference's own + 2 %."""
+    from architectures.models.octa import OctaScribbleNet
+    from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
+    from octave_amd.synth import COND_SCALE
+    from octave_amd.train import mask_pyramid
+    from oracle.gen_golden_meta import grad_stride
+    G = golden("trainstep_400c.npz")
+    Bn, H = 4, 400
+    x, ys, real = (t.to(dev) for t in _step_inputs(Bn, H))
+    runs = []
+    for rep in range(2):
+        net = OctaScribbleNet(torch.Size((Bn, 3, H, H)), torch.Size((Bn, 2, H, H)), True, False)
+        fill_state_dict(net.state_dict(), scale=COND_SCALE)
+        net = net.to(dev).train()
+        torch.manual_seed(2024)
+        att, agg, x4 = net.segmentor(x)
+        p = torch.softmax(agg, dim=1)
+        parts = [net.supervised_loss(p, ys), DiceLoss()(p, ys), InterlayerDivergence()([p, *att]), net.generator_loss(net.discriminator(att))]
+        l_seg = parts[0] + parts[1] + 0.1 * parts[2] + 0.1 * parts[3]
+        net.zero_grad()
+        l_seg.backward()
+        grads = {k: q.grad.detach().clone() for k, q in net.segmentor.named_parameters() if q.grad is not None}
+        net.zero_grad()
+        l_d = net.discriminatorial_loss(net.discriminator(mask_pyramid(real)), net.discriminator([a.detach() for a in att]))
+        l_d.backward()
+        dgrads = {k: q.grad.detach().clone() for k, q in net.discriminator.named_parameters()}
+        runs.append((agg.detach().clone(), [v.item() for v in parts], l_seg.item(), grads, l_d.item(), dgrads))
+    # ---- run-to-run: bit-identical in deterministic mode
+    a, b = runs
+    assert torch.equal(a[0], b[0]), "logits differ between two deterministic runs"
+    assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4], (a[1], b[1])
+    nd = [k for k in a[3] if not torch.equal(a[3][k], b[3][k])] + [k for k in a[5] if not torch.equal(a[5][k], b[5][k])]
+    assert not nd, f"{len(nd)} gradient tensors differ between two deterministic runs: {nd[:8]}"
+    agg, parts, l_seg, grads, l_d, dgrads = a
+    # ---- logits
+    ref32, ref64 = G["agg"], G["agg_f64_as_f32"].astype(np.float64)
+    noise, scale = float(np.abs(ref32 - ref64).max()), float(np.abs(ref32).max())
+    got = agg[:, :, ::2, ::2].cpu().numpy()
+    rms = lambda v: float(np.sqrt((v.astype(np.float64) ** 2).mean()))      # noqa: E731
+    e64, e_rms, n_rms = float(np.abs(got.astype(np.float64) - ref64).max()), rms(got - ref64), rms(ref32 - ref64)
+    print(f"[trainstep 400c] logits |hip-ref64| max {e64:.3e} rms {e_rms:.3e}; |ref32-ref64| max {noise:.3e} rms {n_rms:.3e}; ratios {e64 / noise:.2f} / {e_rms / n_rms:.2f}; scale {scale:.1f}")
+    assert e64 <= BAND * noise + 1e-4 * scale, (e64, noise)
+    assert e_rms <= BAND * n_rms + 1e-5 * scale, (e_rms, n_rms)
+    margin = np.abs(ref64[:, 0] - ref64[:, 1])
+    safe = margin > 10 * noise
+    assert safe.mean() > 0.5 and np.array_equal(np.argmax(got, 1)[safe], np.argmax(ref32, 1)[safe])
+    # ---- losses
+    p32, p64 = G["parts"], G["parts_f64"]
+    for i, name in enumerate(("wpce", "dice", "kl", "g_adv")):
+        print(f"[trainstep 400c] {name}: hip {parts[i]:.6f} ref32 {p32[i]:.6f} ref64 {p64[i]:.6f}")
+        assert abs(parts[i] - p64[i]) <= BAND * abs(p32[i] - p64[i]) + 1e-4 * abs(p64[i]) + 1e-6, (name, parts[i], p32[i], p64[i])
+    assert 0.5 <= p64[3] <= 2.0                      # the conditioned LS-GAN term is O(1)
+    l32, l64 = float(G["l_seg"]), float(G["l_seg_f64"])
+    assert abs(l_seg - l64) <= BAND * abs(l32 - l64) + 1e-4 * abs(l64), (l_seg, l32, l64)
+    # ---- gradient norms
+    gn = {k: v.double().norm().item() for k, v in grads.items()}
+    for k in ("fc.weight", "fc.bias"):
+        g32, g64 = float(G[f"seg_gradnorm/{k}"]), float(G[f"seg_gradnorm_f64/{k}"])
+        assert abs(gn[k] - g64) <= BAND * abs(g32 - g64) + 1e-3 * g64, (k, gn[k], g32, g64)
+    _norm_band("trainstep 400c seg", gn, G, "seg_gradnorm/", "seg_gradnorm_f64/", floor=0.02, tail_floor=0.10)
+    top = max(float(g) for k, g in G.items() if k.startswith("seg_gradnorm_f64/"))
+    devs = {k: abs(v - float(G[f"seg_gradnorm_f64/{k}"])) / float(G[f"seg_gradnorm_f64/{k}"]) for k, v in gn.items()
+            if float(G[f"seg_gradnorm_f64/{k}"]) > 1e-6 * top}
+    worst = max(devs.items(), key=lambda kv: kv[1])
+    print(f"[trainstep 400c] largest gradient-norm deviation {worst[1]:.3f} ({worst[0]})")
+    assert worst[1] <= 0.75, worst
+    # ---- full gradients
+    for k, g32 in G.items():
+        if not k.startswith("seg_grad/"):
+            continue
+        name = k[len("seg_grad/"):]
+        g64 = G["seg_grad_f64/" + name]
+        q = grads[name]
+        got = q.cpu().contiguous().flatten()[::grad_stride(q.numel())].double().numpy()
+        assert got.shape == g64.shape, (name, got.shape, g64.shape)
+        e_h, e_r = np.linalg.norm(got - g64) / np.linalg.norm(g64), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
+        print(f"[trainstep 400c] grad {name:34s} rel L2 to ref64: hip {e_h:.3e} ref32 {e_r:.3e}")
+        assert e_h <= BAND_GRAD * e_r + 0.02, (name, e_h, e_r)
+    # ---- the discriminator's own step
+    d32, d64 = float(G["l_d"]), float(G["l_d_f64"])
+    assert abs(l_d - d64) <= BAND * abs(d32 - d64) + 2e-4 * abs(d64), (l_d, d32, d64)
+    gnd = {k: v.double().norm().item() for k, v in dgrads.items()}
+    _norm_band("trainstep 400c disc", gnd, G, "disc_gradnorm/", "disc_gradnorm_f64/", floor=2e-3)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("H", [304, 400])
 def test_hip_eval_onehot_at_baseline_resolutions(dev, golden, H):

@@ -161,6 +161,46 @@ def test_train_step_object_fp32_matches_manual_adam():
     assert agree > 0.99, agree
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deterministic_mode_train_steps_are_bit_identical(dtype):
+    """octa_tuning_set(5, 1) ("deterministic variant required for parity tests"): two TrainSteps from the same state, two
+    full adversarial steps each (noise and label flips included: same CPU seed) -- every parameter, BatchNorm / spectral buffer and
+    loss of the two runs is BIT-identical, in fp32 and in bf16 (the batched 8-wave weight gradients run unsplit, the few-channel ones
+    through the ordered fold, the split-attention / gate / column sums with one workgroup per output address).  Without the mode the
+    same comparison differs (float atomics), which is also checked so that the test cannot pass vacuously."""
+    from octave_amd.train import TrainStep, mask_pyramid
+    from octave_amd import functional as F_
+    from octave_amd.layers import defer_bn_counters
+    dev = torch.device("cuda:0")
+    Bn, H = 4, 64
+    x, ys, real = _inputs(Bn, H, dev)
+
+    def run():
+        net = _net(Bn, H, dev)
+        torch.manual_seed(7)
+        try:
+            step = TrainStep(net, lr=1e-3, compute_dtype=dtype)
+            outs = [step(x, ys, mask_pyramid(real)) for _ in range(2)]
+            step.close()
+        finally:
+            F_.set_grad_sink(False)
+            defer_bn_counters(False)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.state_dict().items()}, [{k: v.item() for k, v in o.items()} for o in outs]
+
+    F_.set_deterministic(True)
+    try:
+        (sa, la), (sb, lb) = run(), run()
+    finally:
+        F_.set_deterministic(False)
+    assert la == lb, (la, lb)
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not bad, f"{len(bad)} state entries differ between two deterministic runs: {bad[:8]}"
+    (sc, _), (sd, _) = run(), run()
+    differ = sum(0 if torch.equal(sc[k], sd[k]) else 1 for k in sc)
+    print(f"[deterministic {dtype}] default mode: {differ} of {len(sc)} state entries differ between two runs (float atomics)")
+
+
 def test_train_step_bf16_runs_and_learns():
     from architectures.models.octa import OctaScribbleNet
     from octave_amd.train import TrainStep, mask_pyramid

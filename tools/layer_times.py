@@ -28,7 +28,7 @@ for kind, d, ptrs, keep in rec:
     if kind == "wgrad_batch":
         arr, n = d, ptrs
         def launchb():
-            L.octa_conv2d_wgrad_batch(arr, n, st)
+            L.octa_conv2d_wgrad_batch(arr, n, *F_._fold_ws_args(), st)
         launchb()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); launchb(); launchb(); launchb(); e1.record(); e1.synchronize()

@@ -94,7 +94,7 @@ def check(it):
     db_o = torch.zeros(Cout, device=dev) if it["bias"] else None
     db_n = torch.zeros(Cout, device=dev) if it["bias"] else None
     run_old(it, dw_o, db_o)
-    L.octa_conv2d_wgrad_batch(job_array([it], [dw_n], [db_n]), 1, st())
+    L.octa_conv2d_wgrad_batch(job_array([it], [dw_n], [db_n]), 1, None, 0, st())
     torch.cuda.synchronize()
     scale = dw_o.abs().max().item()
     err = (dw_o - dw_n).abs().max().item()
@@ -123,7 +123,7 @@ def check_small():
         B, Cin, H, W, Cout, k, s, p, g, bias = cfg
         dw = torch.zeros_like(it["w"])
         db = torch.zeros(Cout, device=dev) if bias else None
-        L.octa_conv2d_wgrad_batch(job_array([it], [dw], [db]), 1, st())
+        L.octa_conv2d_wgrad_batch(job_array([it], [dw], [db]), 1, None, 0, st())
         xr = it["x"].float().cpu().contiguous(); dyr = it["dy"].float().cpu().contiguous()
         wr = torch.zeros(Cout, Cin // g, k, k, requires_grad=True)
         y = torch.nn.functional.conv2d(xr, wr, None, s, p, 1, g)
@@ -156,7 +156,7 @@ def main():
             db = torch.zeros(it["cfg"][4], device=dev) if it["bias"] else None
             arr = job_array([it], [dw], [db])
             t_old = timeit(lambda: run_old(it, dw, db))
-            t_new = timeit(lambda: L.octa_conv2d_wgrad_batch(arr, 1, st()))
+            t_new = timeit(lambda: L.octa_conv2d_wgrad_batch(arr, 1, None, 0, st()))
             print(f"{n:12s} old {t_old:8.1f} us {it['flops'] / t_old / 1e6:7.1f} TF/s | new {t_new:8.1f} us {it['flops'] / t_new / 1e6:7.1f} TF/s", flush=True)
     if "batch" in args:
         stages = {
@@ -177,7 +177,7 @@ def main():
                 for it, dw, db in zip(items, dws, dbs):
                     run_old(it, dw, db)
             t_old = timeit(old)
-            t_new = timeit(lambda: L.octa_conv2d_wgrad_batch(arr, len(items), st()))
+            t_new = timeit(lambda: L.octa_conv2d_wgrad_batch(arr, len(items), None, 0, st()))
             print(f"stage {sname:10s} {len(items):2d} jobs: old {t_old:8.1f} us {fl / t_old / 1e6:7.1f} TF/s | batched {t_new:8.1f} us {fl / t_new / 1e6:7.1f} TF/s", flush=True)
     if "ab" in args:
         evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
@@ -201,7 +201,7 @@ def main():
                         evict.zero_()
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        L.octa_conv2d_wgrad_batch(arr, len(items), st())
+                        L.octa_conv2d_wgrad_batch(arr, len(items), None, 0, st())
                         e1.record(); e1.synchronize()
                         res[mask].append(e0.elapsed_time(e1) * 1e3)
                         names_k[mask] = L.octa_last_conv_kernel().decode()
@@ -227,13 +227,13 @@ def main():
                     evict.zero_()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    L.octa_conv2d_wgrad_batch(arr, 1, st())
+                    L.octa_conv2d_wgrad_batch(arr, 1, None, 0, st())
                     e1.record(); e1.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3)
                 dw.zero_()
                 if db is not None:
                     db.zero_()
-                L.octa_conv2d_wgrad_batch(arr, 1, st())
+                L.octa_conv2d_wgrad_batch(arr, 1, None, 0, st())
                 torch.cuda.synchronize()
                 res[mode] = (sorted(ts)[2], dw.clone(), L.octa_last_conv_kernel().decode())
             L.octa_tuning_set(3, 128)
@@ -259,7 +259,7 @@ def main():
                             evict.zero_()
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        L.octa_conv2d_wgrad_batch(arr, 1, st())
+                        L.octa_conv2d_wgrad_batch(arr, 1, None, 0, st())
                         e1.record(); e1.synchronize()
                         ts.append(e0.elapsed_time(e1) * 1e3)
                 print(f"ablate {n} {what:40s} cold {sorted(ts[:4])[1]:8.1f} us  warm {sorted(ts[4:])[1]:8.1f} us", flush=True)

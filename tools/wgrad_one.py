@@ -10,5 +10,5 @@ it = make(name)
 dw = torch.zeros_like(it["w"])
 arr = job_array([it], [dw], [None])
 for _ in range(reps):
-    L.octa_conv2d_wgrad_batch(arr, 1, st())
+    L.octa_conv2d_wgrad_batch(arr, 1, None, 0, st())
 torch.cuda.synchronize()
