@@ -530,7 +530,8 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * (fp32 jobs too) or unsplit when no scratch was passed, the split-attention GAP / logit-gradient / dgap sums, the attention gate's
  * dw, column sums, the spectral-norm power iteration and dot product and the full-extent conv as ONE workgroup per output address,
  * no BatchNorm statistics in conv epilogues -- so two runs on the same inputs are bit-identical.  Slower (parity tests; never the
- * benchmark). */
+ * benchmark).  key 6: LDS image of the 2-D patch kernel's input patch (algo 12): 1 (default) = lines placed so that fragment reads
+ * are bank-conflict-free, 0 = the linear image of round 4 (A/B runs). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -1,10 +1,20 @@
 #!/bin/bash
 # Build libocta_hip.so for gfx950 (MI355X) in-tree.  Usage: build.sh [outdir]
+#        build.sh diag   -> libocta_hip_diag.so: the same library with in-kernel clock stamps in the three MFMA-bound kernels
+#                           (common.hpp OCTA_STAMP_*; tools/clock_stamps.py loads it through OCTA_HIP_LIB); never the shipped library
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -mcode-object-version=5"
+if [ "${1:-}" = "diag" ]; then
+  mkdir -p "$HERE/obj/diag"
+  for f in conv wgrad8; do $HIPCC $FLAGS -DOCTA_DIAG_STAMPS -c "$HERE/$f.hip" -o "$HERE/obj/diag/$f.o" & done
+  wait
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libocta_hip_diag.so" "$HERE"/obj/diag/{conv,wgrad8}.o "$HERE"/obj/{norm,pool_misc,splat_aag,loss,disc,extras,api}.o
+  echo "built $HERE/../libocta_hip_diag.so"
+  exit 0
+fi
+OUT="${1:-$HERE/..}"
 mkdir -p "$HERE/obj"
 pids=()
 for f in conv wgrad8 norm pool_misc splat_aag loss disc extras; do

@@ -22,6 +22,29 @@ float* octa_wgrad_fold_reserve(hipStream_t st, float* dw, float* dbias, const in
                                int split, int64_t* slice_out);
 void octa_note_conv_kernel(const char* name);   // conv.hip: name reported by octa_last_conv_kernel()
 
+// ---------------------------------------------------------------- in-kernel clock stamps (DIAGNOSTIC build only)
+// build.sh diag compiles the library once more with -DOCTA_DIAG_STAMPS into libocta_hip_diag.so: the three MFMA-bound kernels then
+// stamp s_memtime (shader cycles) and s_memrealtime (100 MHz) around their main loop into a __device__ array of the code object that
+// nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6: in-kernel clock = d memtime / d memrealtime x 100 MHz).  The
+// shipped library contains no stamp: the macros expand to nothing.
+#ifdef OCTA_DIAG_STAMPS
+#define OCTA_STAMP_DECL unsigned long long stamp_t0 = 0, stamp_r0 = 0
+#define OCTA_STAMP_BEGIN asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0), "=s"(stamp_r0) :: "memory")
+#define OCTA_STAMP_END(ARR)                                                                                                   \
+    {                                                                                                                         \
+        unsigned long long t1_, r1_;                                                                                          \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_), "=s"(r1_) :: "memory");          \
+        if (threadIdx.x == 0) {                                                                                               \
+            unsigned long long* d_ = ARR[blockIdx.x & 4095];                                                                  \
+            d_[0] = stamp_t0; d_[1] = stamp_r0; d_[2] = t1_; d_[3] = r1_;                                                     \
+        }                                                                                                                     \
+    }
+#else
+#define OCTA_STAMP_DECL
+#define OCTA_STAMP_BEGIN
+#define OCTA_STAMP_END(ARR)
+#endif
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

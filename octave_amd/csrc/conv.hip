@@ -809,6 +809,7 @@ static int octa_num_cus() {
 #include "igemm8.hpp"
 #include "pwgemm.hpp"
 #include "halo8.hpp"
+#include "halo16.hpp"
 #include "convres.hpp"
 
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
@@ -850,6 +851,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         if (want >= 9 && want <= 11 && launch_pwgemm<T>(a, groups, want - 9, st)) { OCTA_CHECK_LAUNCH("pwgemm"); return OCTA_OK; }
         // 8-wave 3x3 kernel with a 2-D pixel patch per tile (halo8.hpp)
         if (want == 12 && launch_halo8<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_halo8"); return OCTA_OK; }
+        if (want == 13 && launch_halo8<T>(a, groups, st, true)) { OCTA_CHECK_LAUNCH("conv_halo16"); return OCTA_OK; }      // the same with v_mfma_f32_16x16x32 (halo16.hpp)
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
         if (!a.addend && (want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }
@@ -913,6 +915,19 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
     if (fused) *fused = (sizeof(T) == 2 && !dma) ? 1 : 0;
     return OCTA_OK;
 }
+
+void octa_set_halo8_packed(int on) { g_h8_packed = on ? 1 : 0; }
+#ifdef OCTA_DIAG_STAMPS
+extern "C" int octa_diag_stamps_read_conv(int which, void* host, int clear) {      // which 0: halo8, 1: igemm8 (8-wave)
+    static unsigned long long z[4096][4];
+    if (which == 0) {
+        if (clear) return hipMemcpyToSymbol(HIP_SYMBOL(octa_diag_stamps_halo8), z, sizeof(z)) == hipSuccess ? 0 : -3;
+        return hipMemcpyFromSymbol(host, HIP_SYMBOL(octa_diag_stamps_halo8), sizeof(z)) == hipSuccess ? 0 : -3;
+    }
+    if (clear) return hipMemcpyToSymbol(HIP_SYMBOL(octa_diag_stamps_igemm8), z, sizeof(z)) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(octa_diag_stamps_igemm8), sizeof(z)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 static int check_desc(const octa_conv_desc* d, const char* who) {
     OCTA_REQUIRE(d != nullptr, "%s: null descriptor", who);

@@ -17,6 +17,7 @@
 #pragma once
 
 typedef __attribute__((ext_vector_type(16))) float h8_f32x16_t;
+
 template <typename T> struct Mma32;
 template <> struct Mma32<bf16_t> {
     __device__ static __forceinline__ void run(const ig8_u32x4_t& a, const ig8_u32x4_t& b, h8_f32x16_t& c) {
@@ -54,6 +55,15 @@ template <int CNT, int N> __device__ __forceinline__ void h8_waitc(ig8_u32x4_t (
 __device__ __forceinline__ unsigned h8_rowbase(int R) { return (unsigned)(((R >> 4) << 11) + ((R & 7) << 8) + (((R >> 3) & 1) << 7)); }
 
 constexpr int H8_AROWS = 352;                          // patch rows an A buffer holds: (PH + 2) (PW + 2) <= 352
+// Where the patch's lines live in an A buffer (round 5).  Row (ry, rx) of the (PH + 2) x (PW + 2) patch sits at image row
+// base[ry] + rx.  A linear image (base[ry] = ry (PW + 2)) makes every fragment read of 32 consecutive tile pixels cross a patch line,
+// whose +2 row jump puts two of a ds_read_b128 lane group's 16 rows on the same (row mod 16) bank quad: 4 extra cycles on every
+// 4-cycle pixel read, 40 % of the kernel's LDS cycles (profiles/r04_halo8_pmc.txt).  The host therefore places line ry at a row
+// = PW ry (mod 16): then image row = tile pixel index + a per-tap constant (mod 16) whatever lines the 32 pixels span, and the
+// reads are conflict-free.  The lines are packed greedily in residue order (10 x 25: 333 rows instead of 324); the DMA roles and
+// fragment addresses are per-lane precomputed values anyway, so the placement costs nothing per stage.
+constexpr int H8_MAXLINES = 68;
+struct H8Lines { int n, rows; unsigned base[H8_MAXLINES]; };
 constexpr int H8_A_BYTES = H8_AROWS * 128;             // 45056 = 44 DMA instructions of 1 KiB
 constexpr int H8_A_IPW = 6;                            // patch DMA instructions per wave and slice (44 / 8, rounded up)
 
@@ -72,11 +82,14 @@ constexpr int H8_A_IPW = 6;                            // patch DMA instructions
 //     vector bookkeeping is ~40 instructions (the first version spent 160 around its 16 MFMAs and was issue-bound:
 //     SQ_ACTIVE_INST_ANY 38 % of the wave cycles against 12 % of MFMA issue, profiles/r04_halo8_pmc.txt).
 template <typename T, int MODE>
-__global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int PH, int PW, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int PH, int PW, int tiles_x, int tiles_y, const H8Lines lines) {
     constexpr int WNW = 2, MI = 2, NJ = 2, BN = 128, BST = 3;
     constexpr int B_BYTES = BN * 128, B_IPW = BN / 64;
     constexpr int A_OFF = BST * B_BYTES, SCRATCH = A_OFF + 2 * H8_A_BYTES;       // weight ring first: its slot offsets fit ds_read's 16-bit offset field
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SCRATCH + 1024];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SCRATCH + 1024 + H8_MAXLINES * 4];
+    unsigned* const ltab = (unsigned*)(smem + SCRATCH + 1024);                    // line table: image row of patch line ry
+    for (int i = 0; i < lines.n; ++i) if (threadIdx.x == 0) ltab[i] = lines.base[i];      // (uniform index: scalar loads of the kernel argument)
+    __syncthreads();
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
     const int ty = (mt / tiles_x) % tiles_y;
     const int b = mt / (tiles_x * tiles_y);
     const int y0 = ty * PH, x0 = tx * PW, n0 = nt * BN;
-    const int PW2 = PW + 2, PR = (PH + 2) * PW2, NI = 2 * ((PR + 15) >> 4), NPIX = PH * PW;
+    const int PW2 = PW + 2, NI = 2 * ((lines.rows + 15) >> 4), NPIX = PH * PW, NLINES = lines.n;
     const int Cg = a.Cg;
     int s0 = 0, s1 = Cg >> 6;                              // this workgroup's 64-channel slices
     if (part >= 0) { const int nsl = s1; s0 = part * nsl / a.sk_parts; s1 = (part + 1) * nsl / a.sk_parts; }
@@ -120,9 +133,10 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
         const int I = wave + 8 * j;
         const int L = 4 * I + Lq;
         const int R = (L & 7) + 8 * hq + 16 * (L >> 3);
-        const int ry = R / PW2, rx = R - ry * PW2;
+        int ry = -1, rx = 0;                               // the patch line that owns image row R (none: a hole of the packing)
+        for (int q = 0; q < NLINES; ++q) { const unsigned d = (unsigned)R - ltab[q]; if (d < (unsigned)PW2) { ry = q; rx = (int)d; } }
         const int iy = y0 - 1 + ry, ix = x0 - 1 + rx;
-        const bool ok = (I < NI) && (R < PR) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
+        const bool ok = (I < NI) && (ry >= 0) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
         aoff[j] = ok ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.ldx + chunk * 8) * 2u : 0u;
         amask |= (ok ? 1u : 0u) << j;
     }
@@ -167,11 +181,13 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
         int p = wm * (32 * MI) + 32 * i + r5;
         p = p < NPIX ? p : NPIX - 1;                       // padding rows of the tile: any valid row, never stored
         const int py = p / PW, px = p - py * PW;
-        const int Rc = (py + 1) * PW2 + px + 1;
+        unsigned lb[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) lb[dy] = ltab[py + dy];         // image rows of patch lines py .. py + 2
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int kh = tp / 3, kw = tp - kh * 3;
-            const int R = Rc + (MODE == 0 ? (kh - 1) : (1 - kh)) * PW2 + (MODE == 0 ? (kw - 1) : (1 - kw));
+            const int R = (int)lb[MODE == 0 ? kh : 2 - kh] + px + 1 + (MODE == 0 ? (kw - 1) : (1 - kw));
             ta[tp][i] = sbase + (unsigned)A_OFF + h8_rowbase(R) + (unsigned)((kq ^ (R & 7)) << 4);
         }
     }
@@ -185,6 +201,8 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
 #define H8_SB __builtin_amdgcn_sched_barrier(0)
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
     // prologue: patch 0, B(0), B(1), B(2); then wait for the patch and B(0), fetch the fragments of (0, step 0) and (0, step 1)
 #pragma unroll
     for (int j = 0; j < H8_A_IPW; ++j) dmaA(j, s0);
@@ -276,6 +294,7 @@ __global__ __launch_bounds__(512) void conv_halo8_kernel(const ConvArgs a, int P
 #undef H8_STAGE
 #undef H8_MM
 #undef H8_SB
+    OCTA_STAMP_END(octa_diag_stamps_halo8)
 
     // ---- epilogue.  D[n][m]: lane l holds pixel m = l & 31 of block i and, for v = 0 .. 15, channel 8 (v >> 2) + 4 (l >> 5) + (v & 3)
     // of block jn: four groups of 4 consecutive channels (8-byte stores).
@@ -364,6 +383,35 @@ static void halo8_patch(int H, int W, int& PH, int& PW) {
     }
 }
 
+// Line placement of the patch image (see H8Lines): packed = line ry at a row = PW ry (mod 16), lines laid out greedily in the order
+// that wastes the fewest rows; falls back to the linear image when the packing does not fit an A buffer (patch widths that are
+// multiples of 16 need a pitch of PW + 16) or when octa_tuning_set(6, 0) asks for the old image (A/B runs).
+static int g_h8_packed = 1;
+static void halo8_lines(int PH, int PW, H8Lines& t) {
+    const int nl = PH + 2, PW2 = PW + 2;
+    t.n = nl;
+    static const bool env_lin = getenv("OCTA_H8_LINEAR") != nullptr;
+    if (g_h8_packed && !env_lin && nl <= H8_MAXLINES) {
+        bool used[H8_MAXLINES] = {};
+        int pos = 0;
+        for (int k = 0; k < nl; ++k) {
+            int best = -1, bgap = 16;
+            for (int ry = 0; ry < nl; ++ry) {
+                if (used[ry]) continue;
+                const int gap = ((PW * ry - pos) % 16 + 16) % 16;
+                if (gap < bgap) { bgap = gap; best = ry; }
+            }
+            used[best] = true;
+            t.base[best] = (unsigned)(pos + bgap);
+            pos += bgap + PW2;
+        }
+        t.rows = pos;
+        if (pos <= H8_AROWS) return;
+    }
+    for (int ry = 0; ry < nl; ++ry) t.base[ry] = (unsigned)(ry * PW2);
+    t.rows = nl * PW2;
+}
+
 // Finishes the split tiles: y = act(sum of the parts + bias), stored at the patch's pixels.  One thread per (tile pixel row, 4 channels);
 // blockIdx.x = tail tile, blockIdx.y = strip of 32 pixel rows.
 template <typename T>
@@ -422,8 +470,10 @@ static int halo8_parts(const ConvArgs& a, int tiles, int nsl) {
 }
 
 // eligibility + launch.  Returns false when another kernel must run.
+template <typename T, int MODE> __global__ void conv_halo16_kernel(const ConvArgs a, int PH, int PW, int tiles_x, int tiles_y, const H8Lines lines);   // halo16.hpp
+// shape16: the v_mfma_f32_16x16x32 form of the kernel (halo16.hpp, algo 13) instead of 32x32x16 (algo 12)
 template <typename T>
-static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
+static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st, bool shape16 = false) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.upshuffle || a.addend || a.stats) return false;
     if (a.H != a.OH || a.W != a.OW || a.Cg % 64 != 0) return false;
     if ((int64_t)a.B * a.H * a.W * (int64_t)a.ldx >= (1ll << 30)) return false;      // 32-bit byte offsets of the patch rows
@@ -432,6 +482,9 @@ static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
     halo8_patch(a.H, a.W, PH, PW);
     static const int env_pw = getenv("OCTA_H8_PW") ? atoi(getenv("OCTA_H8_PW")) : 0, env_ph = getenv("OCTA_H8_PH") ? atoi(getenv("OCTA_H8_PH")) : 0;
     if (env_pw > 0 && env_ph > 0 && env_pw * env_ph <= 256 && (env_pw + 2) * (env_ph + 2) <= H8_AROWS) { PW = env_pw; PH = env_ph; }     // (experiments)
+    if (PH + 2 > H8_MAXLINES) return false;
+    H8Lines lines;
+    halo8_lines(PH, PW, lines);
     const int tiles_y = cdiv(a.H, PH), tiles_x = cdiv(a.W, PW);
     dim3 grid(a.B * tiles_y * tiles_x, cdiv(a.Ng, 128), groups);
     ConvArgs b = a;
@@ -442,10 +495,13 @@ static bool launch_halo8(const ConvArgs& a, int groups, hipStream_t st) {
         b.sk_parts = parts; b.sk_full = tiles - ntail; b.sk_gy = grid.y; b.sk_tpg = grid.x * grid.y;
         grid = dim3(b.sk_full + ntail * parts, 1, 1);
     }
-    if (a.mode == 0) conv_halo8_kernel<T, 0><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
-    else conv_halo8_kernel<T, 1><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
+    if (shape16) {
+        if (a.mode == 0) conv_halo16_kernel<T, 0><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y, lines);
+        else conv_halo16_kernel<T, 1><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y, lines);
+    } else if (a.mode == 0) conv_halo8_kernel<T, 0><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y, lines);
+    else conv_halo8_kernel<T, 1><<<grid, 512, 0, st>>>(b, PH, PW, tiles_x, tiles_y, lines);
     if (parts > 1) halo8_splitk_fix_kernel<T><<<dim3(ntail, 8), 256, 0, st>>>(b, PH, PW, tiles_x, tiles_y);
-    note_kernel<T>("conv_halo8_kernel", 256, 128);
+    note_kernel<T>(shape16 ? "conv_halo16_kernel" : "conv_halo8_kernel", 256, 128);
     if (parts > 1) { const size_t l = strlen(g_last_kernel); snprintf(g_last_kernel + l, sizeof(g_last_kernel) - l, "+tail%dx%d", ntail, parts); }
     return true;
 }

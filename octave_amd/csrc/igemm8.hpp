@@ -14,6 +14,10 @@
 #pragma once
 
 typedef __attribute__((ext_vector_type(4))) unsigned ig8_u32x4_t;
+#ifdef OCTA_DIAG_STAMPS
+__device__ unsigned long long octa_diag_stamps_halo8[4096][4];
+__device__ unsigned long long octa_diag_stamps_igemm8[4096][4];
+#endif
 template <int OFF> __device__ __forceinline__ ig8_u32x4_t ig8_rd(unsigned addr) {
     ig8_u32x4_t v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
@@ -241,6 +245,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     if (nk > 1) issue(1);
     if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
     ig8_u32x4_t xfX[4], wfX[4], xfY[4], wfY[4];
     ig8_load_sub(afrag0, bfrag0, xfX, wfX);
     ig8_wait8(xfX, wfX);
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm8_kernel(const ConvArg
     }
 #undef IG8_SB
 #undef IG8_MMA
+    OCTA_STAMP_END(octa_diag_stamps_igemm8)
     }
 
     if (NW == 8 && part >= 0) {

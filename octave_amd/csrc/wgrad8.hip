@@ -295,9 +295,18 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgBatch batch) {
 
     float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
     if (do_bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
+        // the row groups' column sums meet through the (now idle) stage ring and are added in row-group order: no LDS float
+        // atomics, so the bias gradient does not depend on the order in which the waves arrive (deterministic mode relies on it)
         __syncthreads();
+        float* const bred = (float*)smem;                  // [B_RG][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[brow * BN + bchunk * 8 + e] = bsum[e];
+        __syncthreads();
+        if (t < BN) {
+            float v = 0.f;
+            for (int rg = 0; rg < B_RG; ++rg) v += bred[rg * BN + t];
+            sBias[t] = v;
+        }
         if (t < BN && n0 + t < Ng) {
             if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
             else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
@@ -342,6 +351,13 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(const WgBatch batch) {
 }
 
 // ------------------------------------------------------------------------------------------
+#ifdef OCTA_DIAG_STAMPS
+__device__ unsigned long long octa_diag_stamps_wgrad9[4096][4];
+extern "C" int octa_diag_stamps_read_wgrad9(void* host, int clear) {
+    if (clear) { static unsigned long long z[4096][4]; return hipMemcpyToSymbol(HIP_SYMBOL(octa_diag_stamps_wgrad9), z, sizeof(z)) == hipSuccess ? 0 : -3; }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(octa_diag_stamps_wgrad9), sizeof(octa_diag_stamps_wgrad9)) == hipSuccess ? 0 : -3;
+}
+#endif
 // wgrad9: 256(N) x 256(K) output tile per workgroup (round 3).  Same batch interface, DMA roles, zero page and epilogue as
 // wgrad8; what changed, and why:
 //   * the tile is twice as big and a stage is 32 pixel rows (4 ring slots of 32 KB): per FLOP a wave issues 25 % fewer
@@ -550,6 +566,8 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 #define WG9_TR(F, i, HS, ad)                                                                                                               \
     if (!(ABL & 8)) { F[i][0] = wg_tr<HS * 8192>(ad); F[i][1] = wg_tr<HS * 8192 + 2048>(ad); }
 #define WG9_SB __builtin_amdgcn_sched_barrier(0)
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
     for (int it = 0; it < nsteps; ++it) {
         const int rem = nsteps - 1 - it;                            // stages after this one
         const bool more = !(ABL & 2) && rem >= 3;                   // stage it + 3 goes into the slot of stage it - 1 (its reads ended before the last barrier)
@@ -599,12 +617,22 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 #undef WG9_MMA
 #undef WG9_TR
 #undef WG9_SB
+    OCTA_STAMP_END(octa_diag_stamps_wgrad9)
 
     float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
     if (do_bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&sBias[bchunk * 8 + e], bsum[e]);
+        // the row groups' column sums meet through the (now idle) stage ring and are added in row-group order: no LDS float
+        // atomics, so the bias gradient does not depend on the order in which the waves arrive (deterministic mode relies on it)
         __syncthreads();
+        float* const bred = (float*)smem;                  // [512 / LPR][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[brow * BN + bchunk * 8 + e] = bsum[e];
+        __syncthreads();
+        if (t < BN) {
+            float v = 0.f;
+            for (int rg = 0; rg < 512 / LPR; ++rg) v += bred[rg * BN + t];
+            sBias[t] = v;
+        }
         if (t < BN && n0 + t < Ng) {
             if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
             else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
@@ -807,7 +835,9 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
 
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
 void octa_set_deterministic(int on);   // api.cpp
+void octa_set_halo8_packed(int on);    // conv.hip
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 6) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 6 = halo8 patch image: 1 packed (bank-conflict-free), 0 linear"); octa_set_halo8_packed(value); return OCTA_OK; }
     if (key == 5) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 5 = deterministic mode (0 / 1)"); octa_set_deterministic(value); return OCTA_OK; }
     if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
     if (key == 4) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 4 = partial tiles + fold for the batched weight-gradient kernels (0 / 1)"); g_wg8_fold = value; return OCTA_OK; }

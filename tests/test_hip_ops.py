@@ -616,11 +616,13 @@ HALO8_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("algo", [12])
+@pytest.mark.parametrize("algo", [12, 13, 112])
 @pytest.mark.parametrize("case", HALO8_CASES)
 def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     """halo8.hpp (octa_conv_desc.algo 12): the 8-wave 3x3 kernel with a 2-D pixel patch per tile, forward (+ bias, ReLU) and
-    data gradient (flipped taps) against torch's CPU conv on the same rounded operands."""
+    data gradient (flipped taps) against torch's CPU conv on the same rounded operands.  13 = its v_mfma_f32_16x16x32 form
+    (halo16.hpp); 112 = algo 12 with the linear patch image of round 4 (octa_tuning_set(6, 0)) instead of the packed,
+    bank-conflict-free one."""
     from octave_amd import functional as F_
     from octave_amd._lib import lib
     B, Cin, H, W, Cout, g = case
@@ -632,25 +634,29 @@ def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
     want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, 1, 1, g))
     t = TOL[dtype]
-    F_._ALGO_OVERRIDE = algo
+    kname = "conv_halo16_kernel" if algo == 13 else "conv_halo8_kernel"
+    lib().octa_tuning_set(6, 0 if algo == 112 else 1)
+    F_._ALGO_OVERRIDE = 12 if algo == 112 else algo
     try:
         y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
         name = lib().octa_last_conv_kernel().decode()
-        assert "conv_halo8_kernel" in name, name
+        assert kname in name, name
         check(f"halo8 fwd {case} algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
         dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
         dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)
-        assert ("conv_halo8_kernel" in lib().octa_last_conv_kernel().decode()) == ((Cout // g) % 64 == 0)
+        assert (kname in lib().octa_last_conv_kernel().decode()) == ((Cout // g) % 64 == 0)
     finally:
         F_._ALGO_OVERRIDE = 0
+        lib().octa_tuning_set(6, 1)
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
     check(f"halo8 dgrad {case} algo {algo}", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("algo", [12, 13])
 @pytest.mark.parametrize("case", [(2, 256, 20, 20, 136, 1), (1, 512, 25, 25, 256, 2), (3, 384, 9, 30, 128, 1)])
-def test_halo8_tail_split_vs_torch(dev, case, dtype):
+def test_halo8_tail_split_vs_torch(dev, case, dtype, algo):
     """halo8 with the tail-split scratch registered (octa_conv_desc.ws): a handful of tiles on 256 CUs, so every tile is
     split over the 64-channel slices into 2-3 parts of raw fp32 partial tiles that halo8_splitk_fix_kernel sums, biases, activates
     and stores at the patch's pixels; forward and data gradient against torch's CPU conv."""
@@ -667,11 +673,11 @@ def test_halo8_tail_split_vs_torch(dev, case, dtype):
     t = TOL[dtype]
     ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
     F_.set_splitk_workspace(ws)
-    F_._ALGO_OVERRIDE = 12
+    F_._ALGO_OVERRIDE = algo
     try:
         y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
         name = lib().octa_last_conv_kernel().decode()
-        assert "conv_halo8_kernel" in name and "+tail" in name, name
+        assert ("conv_halo16_kernel" if algo == 13 else "conv_halo8_kernel") in name and "+tail" in name, name
         check(f"halo8 split fwd {case}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
         dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
         dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)

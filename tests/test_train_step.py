@@ -68,21 +68,21 @@ def test_adversarial_step_losses_and_grads_vs_reference(golden):
             sr.append((float(G["seg_gradnorm/" + name]) - float(g)) / float(g))
     sh, sr = np.array(sh), np.array(sr)
     # The deviations are COMMON-MODE: in the reference's own fp32 run every parameter upstream of the attention maps sits
-    # -0.67 % +- 0.05 % from its float64 norm (fc.*, which is not upstream of them, 0.00 %): the gradient of the KL term is
-    # ~ P / Q at the pixels where an attention probability Q is tiny, a handful of such pixels carries the norm, and their 1 / Q
-    # amplifies the logit noise into ONE shared factor per evaluation.  One heavy-tailed draw per implementation cannot be held
-    # to a ratio (round 4 measured +2.4 % for the HIP path against the reference's -0.67 %: profiles/r04_band_ratios.txt), so the
-    # shared factor gets an absolute bound of 5 % and what is left after removing it -- the per-parameter scatter -- BAND_GRAD
-    # (p95 with 1 % of absolute slack: six runs on one box gave 1.9e-2 .. 2.6e-2 against 4 x 6.6e-3, same file).
+    # -0.63 % +- 0.05 % from its float64 norm (fc.*, which is not upstream of them, 0.00 %).  Round 5 measured what that factor is
+    # (tests/diag/grad_bias_probe.py -> profiles/r05_grad_bias_probe.txt): a property of the INPUT POINT, not of an implementation --
+    # on this input the oracle's fp32 run gives -1.8 % and the HIP path -1.4 %, on three other inputs both give -0.3 %, +1e-5 and
+    # +-2e-4; the loss kernels behind the attention maps (KL, LS-GAN, discriminator) reproduce the float64 gradients to 1e-7 on
+    # identical inputs, tiny-Q pixels included.  So the common factor is held to BAND_GRAD x the reference's own plus a small floor,
+    # and the per-parameter scatter around it to ratio bounds (median / p95: BAND_GRAD, maximum: 2 x BAND_GRAD, each with a floor).
     c_h, c_r = float(np.median(sh)), float(np.median(sr))
     res_h, res_r = np.abs(sh - c_h), np.abs(sr - c_r)
     print(f"[trainstep] l_seg {l_seg.item():.6f} (ref32 {l32:.6f}, ref64 {l64:.6f}); grad norms vs ref64: common factor HIP {c_h:+.2e} ref32 {c_r:+.2e}; "
           f"scatter around it HIP median {np.median(res_h):.2e} p95 {np.percentile(res_h, 95):.2e} max {res_h.max():.2e}; "
           f"ref32 median {np.median(res_r):.2e} p95 {np.percentile(res_r, 95):.2e} max {res_r.max():.2e}")
-    assert abs(c_h) <= max(BAND_GRAD * abs(c_r), 5e-2), (c_h, c_r)
-    assert np.median(res_h) <= BAND_GRAD * np.median(res_r) + 1e-3 and np.percentile(res_h, 95) <= BAND_GRAD * np.percentile(res_r, 95) + 1e-2, \
+    assert abs(c_h) <= BAND_GRAD * abs(c_r) + 2e-3, (c_h, c_r)
+    assert np.median(res_h) <= BAND_GRAD * np.median(res_r) + 1e-3 and np.percentile(res_h, 95) <= BAND_GRAD * np.percentile(res_r, 95) + 5e-3, \
         (np.median(res_h), np.median(res_r), np.percentile(res_h, 95), np.percentile(res_r, 95))
-    assert res_h.max() <= 0.25, res_h.max()          # structure: no parameter off by tens of per cent
+    assert res_h.max() <= 2 * BAND_GRAD * res_r.max() + 1e-2, (res_h.max(), res_r.max())
     net.zero_grad()
     real_pyr = mask_pyramid(real)
     P2 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}     # u/v advanced by the generator step

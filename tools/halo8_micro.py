@@ -27,6 +27,9 @@ def run(name):
     for kind in ("fwd", "dgrad"):
         line += f" | {kind}:"
         for algo in ALGOS:
+            # 12 = halo8 with the packed (bank-conflict-free) patch image, 112 = the same kernel with the linear image of round 4
+            lib().octa_tuning_set(6, 0 if algo == 112 else 1)
+            algo = 12 if algo == 112 else algo
             F_._ALGO_OVERRIDE = algo
             fn = (lambda: F_.raw_conv_fwd(x, w, bias, s, p, g, 1)) if kind == "fwd" else (lambda: F_.raw_conv_dgrad(dy, w, tuple(x.shape), s, p, g))
             out = fn()
@@ -38,6 +41,7 @@ def run(name):
             t = timeit(fn)
             line += f" a{algo}[{kn.split('<')[0].replace('conv_', '').replace('_kernel', '')}{kn[kn.find(','):-1] if ',' in kn else ''}] {t:6.1f}us {flops / t / 1e6:6.1f}TF{bad}"
     F_._ALGO_OVERRIDE = 0
+    lib().octa_tuning_set(6, 1)
     F_.set_splitk_workspace(None)
     print(line, flush=True)
 
