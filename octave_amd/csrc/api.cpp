@@ -25,3 +25,12 @@ bool octa_deterministic() {
     return g_det == 1;
 }
 void octa_set_deterministic(int on) { g_det = on ? 1 : 0; }
+
+// First-pass reductions (BatchNorm statistics / backward sums, split-attention backward sums) walk their tensor END FIRST: see
+// bn_reduce_kernel.  octa_tuning_set(7, 0 / 1), default 1; OCTA_REV_WALK=0 in the environment turns it off (A/B runs).
+static int g_rev = -1;
+int octa_rev_walk() {
+    if (g_rev < 0) { const char* e = getenv("OCTA_REV_WALK"); g_rev = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_rev;
+}
+void octa_set_rev_walk(int on) { g_rev = on ? 1 : 0; }

@@ -16,6 +16,7 @@ void octa_set_error(const char* fmt, ...);
     octa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return OCTA_ERR_LAUNCH; } } while (0)
 
 bool octa_wgrad_fold_begin(hipStream_t st, float* ws, int64_t ws_floats);      // conv.hip: fold session of the partial-store weight gradients over the CALLER's scratch (true: this call opened it)
+int octa_rev_walk();                             // api.cpp: first-pass reductions walk their tensor end first (octa_tuning_set(7, .))
 bool octa_deterministic();                        // api.cpp: octa_tuning_set(5, 1) / OCTA_DETERMINISTIC=1: every cross-workgroup sum in a fixed order
 int octa_wgrad_fold_end();
 float* octa_wgrad_fold_reserve(hipStream_t st, float* dw, float* dbias, const int64_t* strides, int Ntot, int Kpad, int Cg, int CgReal, int KW,

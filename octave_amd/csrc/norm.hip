@@ -33,14 +33,19 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                                                         int dyoff, const T* __restrict__ y, int ldy, int yoff,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                         const uint8_t* __restrict__ rmask, int64_t rows, int C, int TX, int rpb,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, int rev) {
     constexpr int EPC = DT<T>::EPC;
     extern __shared__ float red[];   // [RY][TX*EPC][2 or 3]
     const int RY = 256 / TX;
     const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
     const int col = blockIdx.x * TX + cx;
     const int cpr = C / EPC;
-    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    // row slab of this workgroup.  REVERSED (octa_tuning_set(7, .), default on): the workgroups are dispatched in blockIdx order, so
+    // slab gridDim.y - 1 runs first and the pass walks the tensor END FIRST -- the end is what its producer (a conv's epilogue, the
+    // upstream gradient kernel) wrote last and what the 256 MB memory-side cache still holds when the tensor is larger than it; the
+    // apply pass that follows walks forward again and starts on the lines this pass read last
+    const int slab = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int64_t r0 = (int64_t)slab * rpb, r1 = min(rows, r0 + rpb);
     float sa[EPC], sb[EPC], mu[EPC], is[EPC];
     int cnt = 0;
 #pragma unroll
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                     n = tot;
                 }
             }
-            partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)mean_b;
-            partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)m2;
+            partial[((size_t)slab * 2 + 0) * C + c] = (float)mean_b;
+            partial[((size_t)slab * 2 + 1) * C + c] = (float)m2;
         }
         return;
     }
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
         if (c >= C) continue;
         float a = 0.f, b = 0.f;
         for (int yy = 0; yy < RY; ++yy) { a += red[((size_t)yy * TX * EPC + ch) * 2]; b += red[((size_t)yy * TX * EPC + ch) * 2 + 1]; }
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
+        partial[((size_t)slab * 2 + 0) * C + c] = a;
+        partial[((size_t)slab * 2 + 1) * C + c] = b;
     }
 }
 
@@ -602,11 +607,11 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
     dim3 grid(cm.gridx, nby);
     const size_t sh = (size_t)256 * epc * 3 * sizeof(float);
     if (dtype == OCTA_F32)
-        bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<float, 0><<<grid, 256, sh, st>>>((const float*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     else if (dtype == OCTA_BF16)
-        bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<bf16_t, 0><<<grid, 256, sh, st>>>((const bf16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     else
-        bn_reduce_kernel<f16_t, 0><<<grid, 256, sh, st>>>((const f16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<f16_t, 0><<<grid, 256, sh, st>>>((const f16_t*)x, ld, off, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     OCTA_CHECK_LAUNCH("bn_reduce(stats)");
     bn_stats_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, rpb, C, rows, eps, momentum, mean, invstd, running_mean, running_var);
     OCTA_CHECK_LAUNCH("bn_stats_finalize");
@@ -868,11 +873,11 @@ extern "C" int octa_bn_bwd(const void* dy, int lddy, int dyoff, const void* x, i
     }
     {
     if (dtype == OCTA_F32)
-        bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<float, 1><<<grid, 256, sh, st>>>((const float*)x, ldx, xoff, (const float*)dy, lddy, dyoff, (const float*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     else if (dtype == OCTA_BF16)
-        bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<bf16_t, 1><<<grid, 256, sh, st>>>((const bf16_t*)x, ldx, xoff, (const bf16_t*)dy, lddy, dyoff, (const bf16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     else
-        bn_reduce_kernel<f16_t, 1><<<grid, 256, sh, st>>>((const f16_t*)x, ldx, xoff, (const f16_t*)dy, lddy, dyoff, (const f16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws);
+        bn_reduce_kernel<f16_t, 1><<<grid, 256, sh, st>>>((const f16_t*)x, ldx, xoff, (const f16_t*)dy, lddy, dyoff, (const f16_t*)y, ldy, yoff, mean, invstd, relu, relu_mask, rows, C, cm.TX, rpb, ws, octa_rev_walk());
     OCTA_CHECK_LAUNCH("bn_reduce(bwd)");
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(ws, nby, C, rows, fin, dgamma, dbeta);
     OCTA_CHECK_LAUNCH("bn_bwd_finalize");

@@ -533,14 +533,15 @@ __global__ __launch_bounds__(256) void splat_bn_bwd_kernel(const T* __restrict__
 // (tools/bn_ledger.py: 8.2 GB -> 5.9 GB per step at B = 16, 400 x 400).
 template <typename T>
 __global__ __launch_bounds__(256) void splat_bwd_reduce_bn2_kernel(const T* __restrict__ dout, const T* __restrict__ x, SplatBn bn, const T* __restrict__ outp,
-                                                                   float* __restrict__ da, float* __restrict__ aux, int HW, int C, int TX, int rpb, int relu) {
+                                                                   float* __restrict__ da, float* __restrict__ aux, int HW, int C, int TX, int rpb, int relu, int rev) {
     constexpr int EPC = DT<T>::EPC;
     extern __shared__ float red[];   // [RY][TX*EPC][5], used twice
     const int RY = 256 / TX;
     const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
     const int col = blockIdx.x * TX + cx, cpr = C / EPC;
-    const int b = blockIdx.z;
-    const int r0 = blockIdx.y * rpb, r1 = min(HW, r0 + rpb);
+    // (rev: end first -- the last samples / rows are what the upstream gradient kernel wrote last, see bn_reduce_kernel)
+    const int b = rev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int r0 = (rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * rpb, r1 = min(HW, r0 + rpb);
     float s[10][EPC];                // 0: da_u, 1..4: P Px M Mx (u); 5: da_v, 6..9: P Px M Mx (v)
 #pragma unroll
     for (int k = 0; k < 10; ++k)
@@ -714,9 +715,9 @@ extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const 
     if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
     const size_t sh = (size_t)256 * epc * 5 * sizeof(float);
-    if (dtype == OCTA_F32) splat_bwd_reduce_bn2_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, aux, HW, C, TX, rpb, relu);
-    else if (dtype == OCTA_BF16) splat_bwd_reduce_bn2_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, bn, (const bf16_t*)out, dlogits, aux, HW, C, TX, rpb, relu);
-    else splat_bwd_reduce_bn2_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, bn, (const f16_t*)out, dlogits, aux, HW, C, TX, rpb, relu);
+    if (dtype == OCTA_F32) splat_bwd_reduce_bn2_kernel<float><<<grid, 256, sh, st>>>((const float*)dout, (const float*)x, bn, (const float*)out, dlogits, aux, HW, C, TX, rpb, relu, octa_rev_walk());
+    else if (dtype == OCTA_BF16) splat_bwd_reduce_bn2_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, bn, (const bf16_t*)out, dlogits, aux, HW, C, TX, rpb, relu, octa_rev_walk());
+    else splat_bwd_reduce_bn2_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, bn, (const f16_t*)out, dlogits, aux, HW, C, TX, rpb, relu, octa_rev_walk());
     OCTA_CHECK_LAUNCH("splat_bwd_reduce_bn2");
     splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
     OCTA_CHECK_LAUNCH("splat_softmax_bwd");

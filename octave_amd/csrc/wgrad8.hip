@@ -836,7 +836,9 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
 void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
+void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }
     if (key == 6) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 6 = halo8 patch image: 1 packed (bank-conflict-free), 0 linear"); octa_set_halo8_packed(value); return OCTA_OK; }
     if (key == 5) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 5 = deterministic mode (0 / 1)"); octa_set_deterministic(value); return OCTA_OK; }
     if (key == 2) { g_wg9_ablate = value; return OCTA_OK; }
