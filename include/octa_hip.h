@@ -531,9 +531,9 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * dw, column sums, the spectral-norm power iteration and dot product and the full-extent conv as ONE workgroup per output address,
  * no BatchNorm statistics in conv epilogues -- so two runs on the same inputs are bit-identical.  Slower (parity tests; never the
  * benchmark).  key 6: LDS image of the 2-D patch kernel's input patch (algo 12): 1 (default) = lines placed so that fragment reads
- * are bank-conflict-free, 0 = the linear image of round 4 (A/B runs).  key 7: 1 (default) = the first-pass reductions (BatchNorm
+ * are bank-conflict-free, 0 = the linear image of round 4 (A/B runs).  key 7: 1 = the first-pass reductions (BatchNorm
  * statistics / backward sums, split-attention backward sums) walk their tensor END FIRST, i.e. start on what the producing kernel wrote
- * last and the 256 MB memory-side cache still holds; 0 = forward (A/B runs).  Results are identical (same partial slots). */
+ * last and the 256 MB memory-side cache still holds; 0 (default: no gain measured) = forward.  Results are identical (same partial slots). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -27,10 +27,11 @@ bool octa_deterministic() {
 void octa_set_deterministic(int on) { g_det = on ? 1 : 0; }
 
 // First-pass reductions (BatchNorm statistics / backward sums, split-attention backward sums) walk their tensor END FIRST: see
-// bn_reduce_kernel.  octa_tuning_set(7, 0 / 1), default 1; OCTA_REV_WALK=0 in the environment turns it off (A/B runs).
+// bn_reduce_kernel.  octa_tuning_set(7, 0 / 1) or OCTA_REV_WALK=1.  Default OFF: measured in situ (tools/ab_tuning.py "7=0" "7=1",
+// profiles/r05_ab_rev_walk.txt) 25.62 ms per step without against 25.63 - 26.45 with -- no gain, kept as a documented experiment.
 static int g_rev = -1;
 int octa_rev_walk() {
-    if (g_rev < 0) { const char* e = getenv("OCTA_REV_WALK"); g_rev = (e && atoi(e) == 0) ? 0 : 1; }
+    if (g_rev < 0) { const char* e = getenv("OCTA_REV_WALK"); g_rev = (e && atoi(e) != 0) ? 1 : 0; }
     return g_rev;
 }
 void octa_set_rev_walk(int on) { g_rev = on ? 1 : 0; }

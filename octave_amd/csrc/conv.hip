@@ -810,6 +810,7 @@ static int octa_num_cus() {
 #include "pwgemm.hpp"
 #include "halo8.hpp"
 #include "halo16.hpp"
+#include "halo16p.hpp"
 #include "convres.hpp"
 
 static int g_conv_variant = -1;   // 0: register-staged double buffer, 1: LDS-DMA ring (default)
@@ -852,6 +853,7 @@ static int launch_igemm(const ConvArgs& a, int groups, hipStream_t st, int algo 
         // 8-wave 3x3 kernel with a 2-D pixel patch per tile (halo8.hpp)
         if (want == 12 && launch_halo8<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_halo8"); return OCTA_OK; }
         if (want == 13 && launch_halo8<T>(a, groups, st, true)) { OCTA_CHECK_LAUNCH("conv_halo16"); return OCTA_OK; }      // the same with v_mfma_f32_16x16x32 (halo16.hpp)
+        if (want == 14 && launch_halo16p<T>(a, groups, st)) { OCTA_CHECK_LAUNCH("conv_halo16p"); return OCTA_OK; }          // ... with a persistent tile loop (halo16p.hpp)
         // resident-weight persistent kernel (convres.hpp): wide shallow layers, >= 2 tiles per CU
         static const bool no_res = getenv("OCTA_NO_CONVRES") != nullptr;
         if (!a.addend && (want == 7 || (want == 0 && !no_res && a.M >= 512 * 256)) && launch_res<T>(a, groups, st, want == 7)) { OCTA_CHECK_LAUNCH("conv_res"); return OCTA_OK; }

@@ -562,7 +562,7 @@ def _choose_algo(kind: str, d, launch) -> int:
     if kind not in ("dgrad_add", "fwd_stats") and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
         cands += [12]               # 8-wave 3x3 kernel, 2-D pixel patch per tile (halo8.hpp)
         if os.environ.get("OCTA_NO_HALO16") != "1":
-            cands += [13]           # ... on v_mfma_f32_16x16x32 (halo16.hpp)
+            cands += [13, 14]       # ... on v_mfma_f32_16x16x32 (halo16.hpp) / with a persistent tile loop (halo16p.hpp)
     best, best_t = 1, None
     if len(cands) > 1:
         for c in cands:

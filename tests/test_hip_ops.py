@@ -616,13 +616,14 @@ HALO8_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("algo", [12, 13, 112])
+@pytest.mark.parametrize("algo", [12, 13, 14, 112])
 @pytest.mark.parametrize("case", HALO8_CASES)
 def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     """halo8.hpp (octa_conv_desc.algo 12): the 8-wave 3x3 kernel with a 2-D pixel patch per tile, forward (+ bias, ReLU) and
     data gradient (flipped taps) against torch's CPU conv on the same rounded operands.  13 = its v_mfma_f32_16x16x32 form
     (halo16.hpp); 112 = algo 12 with the linear patch image of round 4 (octa_tuning_set(6, 0)) instead of the packed,
-    bank-conflict-free one."""
+    bank-conflict-free one; 14 = halo16 with the persistent tile loop (halo16p.hpp: several tiles per workgroup on the small cases'
+    grids only when the tile count exceeds the CU count -- test_halo16p_many_tiles_per_workgroup covers that)."""
     from octave_amd import functional as F_
     from octave_amd._lib import lib
     B, Cin, H, W, Cout, g = case
@@ -634,7 +635,7 @@ def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
     wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
     want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, 1, 1, g))
     t = TOL[dtype]
-    kname = "conv_halo16_kernel" if algo == 13 else "conv_halo8_kernel"
+    kname = {13: "conv_halo16_kernel", 14: "conv_halo16p_kernel"}.get(algo, "conv_halo8_kernel")
     lib().octa_tuning_set(6, 0 if algo == 112 else 1)
     F_._ALGO_OVERRIDE = 12 if algo == 112 else algo
     try:
@@ -654,7 +655,7 @@ def test_halo8_forward_and_dgrad_vs_torch(dev, case, algo, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("algo", [12, 13])
+@pytest.mark.parametrize("algo", [12, 13, 14])
 @pytest.mark.parametrize("case", [(2, 256, 20, 20, 136, 1), (1, 512, 25, 25, 256, 2), (3, 384, 9, 30, 128, 1)])
 def test_halo8_tail_split_vs_torch(dev, case, dtype, algo):
     """halo8 with the tail-split scratch registered (octa_conv_desc.ws): a handful of tiles on 256 CUs, so every tile is
@@ -677,7 +678,7 @@ def test_halo8_tail_split_vs_torch(dev, case, dtype, algo):
     try:
         y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
         name = lib().octa_last_conv_kernel().decode()
-        assert ("conv_halo16_kernel" if algo == 13 else "conv_halo8_kernel") in name and "+tail" in name, name
+        assert {13: "conv_halo16_kernel", 14: "conv_halo16p_kernel"}.get(algo, "conv_halo8_kernel") in name and "+tail" in name, name
         check(f"halo8 split fwd {case}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
         dy = torch.randn(tuple(want.shape), generator=gen).to(dtype).float()
         dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)
@@ -688,6 +689,46 @@ def test_halo8_tail_split_vs_torch(dev, case, dtype, algo):
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
     check(f"halo8 split dgrad {case} [{dname}]", dx, xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(16, 128, 50, 50, 256, 1, False), (9, 256, 50, 50, 384, 1, True), (8, 256, 60, 44, 512, 4, False)])
+def test_halo16p_many_tiles_per_workgroup(dev, case):
+    """halo16p.hpp (algo 14): grids of several hundred tiles, so every workgroup walks 2-4 work items back to back (whole tiles, then
+    with the scratch the parts of the tail-split tiles; grouped layer included): the item hand-over -- next item's patch / weight prefetch
+    during the last slice, fragment reads across the item change, epilogue between two items -- against torch's CPU conv, forward and
+    data gradient, and bit-identical to the one-tile-per-workgroup kernel (algo 13: same MFMA order per tile)."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import lib
+    B, Cin, H, W, Cout, g, split = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cout, Cin // g, 3, 3, generator=gen) * 0.05).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    wd = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    want = torch.relu(torch.nn.functional.conv2d(x, w, bias, 1, 1, 1, g))
+    t = TOL[dtype]
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=dev) if split else None
+    F_.set_splitk_workspace(ws)
+    outs = {}
+    try:
+        for algo in (14, 13):
+            F_._ALGO_OVERRIDE = algo
+            y = F_.raw_conv_fwd(xd, wd, bias.to(dev), 1, 1, g, 1)
+            name = lib().octa_last_conv_kernel().decode()
+            assert ("conv_halo16p_kernel" if algo == 14 else "conv_halo16_kernel") in name and (("+tail" in name) == split), name
+            dy = torch.randn(tuple(want.shape), generator=torch.Generator().manual_seed(43)).to(dtype).float()
+            dx = F_.raw_conv_dgrad(F_.to_nhwc(dy.to(dev), dtype=dtype), wd, (B, Cin, H, W), 1, 1, g)
+            outs[algo] = (y, dx)
+    finally:
+        F_._ALGO_OVERRIDE = 0
+        F_.set_splitk_workspace(None)
+    check(f"halo16p fwd {case}", outs[14][0], want, t["rtol"], t["atol"] * float(want.abs().max()))
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w, None, 1, 1, 1, g).backward(dy)
+    check(f"halo16p dgrad {case}", outs[14][1], xr.grad, t["rtol"], t["atol"] * float(xr.grad.abs().max()))
+    assert torch.equal(outs[14][0], outs[13][0]) and torch.equal(outs[14][1], outs[13][1]), "persistent and one-tile-per-workgroup kernels differ"
 
 
 def test_two_streams_split_convs_with_their_own_scratch(dev):

@@ -11,7 +11,7 @@ from octave_amd import functional as F_
 from octave_amd._lib import lib
 from octave_amd.train import TrainStep, mask_pyramid
 
-DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 1}
+DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 0}
 cfgs = [sys.argv[1], sys.argv[2]]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda", 0)

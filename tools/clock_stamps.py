@@ -92,7 +92,7 @@ def wgrad_case(layer):
 if __name__ == "__main__":
     print("in-kernel clock stamps (diagnostic build; random bf16 operands; every kernel behind ~2 s of back-to-back launches of itself)")
     for layer in ("dec2_3x3", "dec3_3x3"):
-        for algo, which, tag in ((12, "halo", "halo8 32x32x16"), (13, "halo", "halo16 16x16x32"), (3, "igemm8", "igemm8 128x256 16x16x32")):
+        for algo, which, tag in ((12, "halo", "halo8 32x32x16"), (13, "halo", "halo16 16x16x32"), (14, "halo", "halo16p persistent"), (3, "igemm8", "igemm8 128x256 16x16x32")):
             for kind in ("fwd", "dgrad"):
                 fn, keep = conv_case(layer, algo, kind)
                 run(f"{layer} {kind} {tag}", which, fn)

@@ -21,6 +21,10 @@ torch.cuda.synchronize()
 F_.set_splitk_workspace(step._sk_ws if os.environ.get("LAYER_TIMES_SPLITK", "1") != "0" else None)     # as during the segmentor phase of a step
 F_.set_wgrad_fold_workspace(getattr(step, "_fold_ws", None) if os.environ.get("LAYER_TIMES_FOLD", "1") != "0" else None)   # as during a step's backward pass
 L = lib(); st = torch.cuda.current_stream().cuda_stream
+# Yardstick = the hardware peaks of MI355X_MICROARCH.md (dense bf16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s), as the bench's roofline uses.
+# (Rounds 2-4 graded against 650 TFLOP/s / 5 TB/s -- "what the best kernels here reach" -- which made the conv engine look finished;
+# LAYER_TIMES_SOFT=1 prints that figure instead.)
+PEAK_FLOPS, PEAK_BYTES = (650e12, 5.0e12) if os.environ.get("LAYER_TIMES_SOFT") == "1" else (2500e12, 8.0e12)
 rows = []
 excess = []
 scratch = {}
@@ -37,7 +41,7 @@ for kind, d, ptrs, keep in rec:
         dd = arr[0].d
         desc = f"batch of {n}: first B{dd.B} {dd.H}x{dd.W} {dd.Cin}->{dd.Cout} k{dd.KH} g{dd.groups}"
         rows.append((us, "wgradB", desc, fl))
-        excess.append((us - fl / 650e12 * 1e6, us, fl / 650e12 * 1e6, "wgradB", desc))
+        excess.append((us - fl / PEAK_FLOPS * 1e6, us, fl / PEAK_FLOPS * 1e6, "wgradB", desc))
         print(f"  wgrad batch {n:2d} jobs {us:8.1f} us {fl / us / 1e6:7.1f} TF/s  " + ", ".join(f"{arr[i].d.H}x{arr[i].d.W}:{arr[i].d.Cin}->{arr[i].d.Cout}k{arr[i].d.KH}g{arr[i].d.groups}" for i in range(n)))
         continue
     def launch():
@@ -56,7 +60,7 @@ for kind, d, ptrs, keep in rec:
     esz = 2 if d.dtype else 4
     up = 4 if d.upshuffle else 1
     byt = esz * d.B * (d.H * d.W * d.Cin + d.OH * d.OW * up * (d.Cout // up if d.upshuffle else d.Cout)) + esz * d.Cout * (d.Cin // d.groups) * d.KH * d.KW
-    ideal = max(fl / 650e12, byt / 5.0e12) * 1e6
+    ideal = max(fl / PEAK_FLOPS, byt / PEAK_BYTES) * 1e6
     excess.append((us - ideal, us, ideal, kind, f"B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''}"))
     kn = L.octa_last_conv_kernel().decode().replace("conv_", "").replace("_kernel", "")
     rows.append((us, kind, f"{'bf16' if d.dtype else 'f32'} B{d.B} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} g{d.groups}{' up' if d.upshuffle else ''} [{kn}]", fl))
@@ -68,7 +72,7 @@ for us, kind, desc, fl in rows:
 for (kind, desc), (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:90]:
     print(f"{us:9.1f} us {n:3d}x  {kind:6s} {desc:44s} {fl / us / 1e6:7.1f} TF/s")
 
-print("\n== excess over max(flops/650T, bytes/5TB/s), aggregated per (kind, layer) ==")
+print(f"\n== excess over max(flops / {PEAK_FLOPS / 1e12:.0f} TFLOP/s, bytes / {PEAK_BYTES / 1e12:.1f} TB/s), aggregated per (kind, layer) ==")
 ex = {}
 for e, us, ideal, kind, desc in excess:
     a = ex.setdefault((kind, desc), [0.0, 0.0, 0.0, 0]); a[0] += e; a[1] += us; a[2] += ideal; a[3] += 1
