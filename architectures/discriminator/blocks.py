@@ -173,7 +173,7 @@ class DiscriminatorBlock(nn.Module):
             s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype))
         # the spectral-norm convs' power iterations (independent of each other and of the activations): one batched call
         sn = [self.spectral_dict[f'spectral_{i}'][0] for i in range(self.depth)]
-        wn = F_.spectral_norm_batch([(m.weight_orig, m.weight_u, m.weight_v) for m in sn], sn[0].training, sn[0].sn_eps) \
+        wn = F_.spectral_norm_batch([(m.weight_orig, m.weight_u, m.weight_v) for m in sn], sn[0].training, sn[0].sn_eps, dtype) \
             if (_SN_BATCH and 1 <= self.depth <= 8 and all(m.training == sn[0].training and m.sn_eps == sn[0].sn_eps for m in sn)) else [None] * self.depth
         for i in range(self.depth):
             try:

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 310
+#define OCTA_HIP_ABI_VERSION 311
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -478,6 +478,11 @@ int octa_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u
 typedef struct octa_sn_job {
     const float* w; float* u; float* v; float* sigma; float* w_sn; float* ws /* K + Cout floats */; float* uv_saved /* optional */;
     int32_t Cout, K;
+    /* optional (round 5): the conv operands of w_sn in `pack_dtype`, written by the same launch that writes w_sn -- the forward operand
+     * [Cout][KH][KW][round8(Cin)] (octa_pack_weight_fwd's layout, groups 1) and / or the tap-major data-gradient operand
+     * [KH*KW][round8(Cin)][round8(Cout)] (octa_pack_weight_dgrad_taps's); needs K == Cin*KH*KW.  NULL: not written. */
+    void* packed_fwd; void* packed_dgrad_taps;
+    int32_t KH, KW, Cin, pack_dtype;
 } octa_sn_job;
 typedef struct octa_sn_bwd_job {
     const float* dw_sn; const float* w_sn; const float* u; const float* v; const float* sigma; float* dw; float* ws /* 1 float */;
@@ -538,6 +543,10 @@ int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */
 int octa_probe_mfma(int which, const void* a, const void* b, float* d, octa_stream_t stream);
+/* Measurement aid (tools/comm_pressure.py): `nblocks` 256-thread workgroups stream over buf[0, bytes) (read, add 0, write back: the
+ * contents are unchanged) `reps` times -- a stand-in for the CU footprint and HBM traffic of a collective's kernels on a communication
+ * stream when only one GPU is available. */
+int octa_probe_stream_load(float* buf, int64_t bytes, int nblocks, int reps, octa_stream_t stream);
 
 /* dst <- slot (*dev_counter % slots) of a ring of `slots` x slot_bytes in pinned, device-addressable HOST memory, copied
  * by a kernel (no hipMemcpy).  dev_counter is the step counter octa_host_tick advances. */

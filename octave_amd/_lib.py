@@ -37,7 +37,8 @@ class PackDesc(ctypes.Structure):
 
 class SnJob(ctypes.Structure):
     """octa_sn_job: one layer of a batched spectral normalisation (octa_spectral_norm_fwd_batch)."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("w", "u", "v", "sigma", "w_sn", "ws", "uv_saved")] + [("Cout", ctypes.c_int32), ("K", ctypes.c_int32)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w", "u", "v", "sigma", "w_sn", "ws", "uv_saved")] + [("Cout", ctypes.c_int32), ("K", ctypes.c_int32)] + \
+               [("packed_fwd", ctypes.c_void_p), ("packed_dgrad_taps", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in ("KH", "KW", "Cin", "pack_dtype")]
 
 
 class SnBwdJob(ctypes.Structure):

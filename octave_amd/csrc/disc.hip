@@ -243,7 +243,34 @@ struct SnBatch {
     const float* w[SN_MAXJOBS]; float* u[SN_MAXJOBS]; float* v[SN_MAXJOBS]; float* sigma[SN_MAXJOBS]; float* wsn[SN_MAXJOBS];
     float* ws[SN_MAXJOBS]; float* uvs[SN_MAXJOBS];
     int Cout[SN_MAXJOBS], K[SN_MAXJOBS];
+    // optional packed conv operands of w_sn, written by the C kernel beside w_sn (saves the per-call pack launches of a normalised weight):
+    void* pk_fwd[SN_MAXJOBS]; void* pk_dgt[SN_MAXJOBS];
+    int pk_khw[SN_MAXJOBS], pk_kw[SN_MAXJOBS], pk_cin[SN_MAXJOBS], pk_cinp[SN_MAXJOBS], pk_coutp[SN_MAXJOBS], pk_dtype[SN_MAXJOBS];
 };
+template <typename T> __device__ __forceinline__ void sn_pack(const SnBatch& b, int j, const float* __restrict__ w, float inv, int lb, int nblk) {
+    const int Cout = b.Cout[j], K = b.K[j], khw = b.pk_khw[j], KW = b.pk_kw[j], Cin = b.pk_cin[j], cinp = b.pk_cinp[j], coutp = b.pk_coutp[j];
+    if (b.pk_fwd[j]) {            // forward operand [Cout][KH][KW][cin_pad]
+        T* __restrict__ out = (T*)b.pk_fwd[j];
+        const int64_t tot = (int64_t)Cout * khw * cinp;
+        for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += (int64_t)nblk * 256) {
+            const int ci = (int)(i % cinp);
+            const int64_t t = i / cinp;
+            const int tap = (int)(t % khw), co = (int)(t / khw);
+            DT<T>::st(out + i, ci < Cin ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f);
+        }
+    }
+    if (b.pk_dgt[j]) {            // tap-major data-gradient operand [KH*KW][cin_pad][cout_pad]
+        T* __restrict__ out = (T*)b.pk_dgt[j];
+        const int64_t tot = (int64_t)khw * cinp * coutp;
+        for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += (int64_t)nblk * 256) {
+            const int co = (int)(i % coutp);
+            const int64_t t = i / coutp;
+            const int ci = (int)(t % cinp), tap = (int)(t / cinp);
+            DT<T>::st(out + i, (ci < Cin && co < Cout) ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f);
+        }
+    }
+    (void)KW;
+}
 __device__ __forceinline__ int sn_job_of(const SnBatch& b, int blk, int& local) {
     int j = 0;
 #pragma unroll
@@ -331,6 +358,11 @@ __global__ __launch_bounds__(256) void spectral_C_batch_kernel(const SnBatch b, 
     const float inv = 1.f / sg;
     const int64_t n = (int64_t)Cout * K;
     for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) wsn[i] = w[i] * inv;
+    if (b.pk_fwd[j] || b.pk_dgt[j]) {
+        if (b.pk_dtype[j] == OCTA_F32) sn_pack<float>(b, j, w, inv, lb, nblk);
+        else if (b.pk_dtype[j] == OCTA_BF16) sn_pack<bf16_t>(b, j, w, inv, lb, nblk);
+        else sn_pack<f16_t>(b, j, w, inv, lb, nblk);
+    }
 }
 extern "C" int octa_spectral_norm_fwd_batch(const octa_sn_job* jobs, int n, int do_power_iter, float eps, int ws_prezeroed, octa_stream_t stream) {
     OCTA_REQUIRE(jobs && n >= 1 && n <= SN_MAXJOBS, "octa_spectral_norm_fwd_batch: 1..%d jobs", SN_MAXJOBS);
@@ -348,6 +380,12 @@ extern "C" int octa_spectral_norm_fwd_batch(const octa_sn_job* jobs, int n, int 
         rb.w[j] = cb.w[j] = q.w; rb.u[j] = cb.u[j] = q.u; rb.v[j] = cb.v[j] = q.v; rb.sigma[j] = cb.sigma[j] = q.sigma;
         rb.wsn[j] = cb.wsn[j] = q.w_sn; rb.ws[j] = cb.ws[j] = q.ws; rb.uvs[j] = cb.uvs[j] = q.uv_saved;
         rb.Cout[j] = cb.Cout[j] = q.Cout; rb.K[j] = cb.K[j] = q.K;
+        cb.pk_fwd[j] = q.packed_fwd; cb.pk_dgt[j] = q.packed_dgrad_taps;
+        cb.pk_khw[j] = q.KH * q.KW; cb.pk_kw[j] = q.KW; cb.pk_cin[j] = q.Cin; cb.pk_cinp[j] = (q.Cin + 7) / 8 * 8; cb.pk_coutp[j] = (q.Cout + 7) / 8 * 8;
+        cb.pk_dtype[j] = q.pack_dtype;
+        if (q.packed_fwd || q.packed_dgrad_taps)
+            OCTA_REQUIRE(q.KH > 0 && q.KW > 0 && q.Cin > 0 && q.Cin * q.KH * q.KW == q.K && OCTA_DTYPE_OK(q.pack_dtype),
+                         "octa_spectral_norm_fwd_batch: job %d: packed operands need KH, KW, Cin with Cin*KH*KW == K and a dtype", j);
         if (q.K > kmax) kmax = q.K;
         if (do_power_iter && !ws_prezeroed && octa_zero_async(q.ws, (size_t)q.K * sizeof(float), st) != hipSuccess)
             OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_spectral_norm_fwd_batch: memset failed");

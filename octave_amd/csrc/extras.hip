@@ -457,3 +457,20 @@ extern "C" int octa_ring_fetch(const void* ring_host, int64_t slot_bytes, int sl
     return OCTA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ comm-stream stand-in (tools/comm_pressure.py)
+__global__ __launch_bounds__(256) void probe_stream_load_kernel(float4* __restrict__ buf, int64_t n4, int reps) {
+    for (int rp = 0; rp < reps; ++rp)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            float4 v = buf[i];
+            v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // (keeps the round trip from being optimised away)
+            buf[i] = v;
+        }
+}
+extern "C" int octa_probe_stream_load(float* buf, int64_t bytes, int nblocks, int reps, octa_stream_t stream) {
+    OCTA_REQUIRE(buf && bytes >= 16 && ((uintptr_t)buf & 15) == 0 && nblocks >= 1 && nblocks <= 4096 && reps >= 1, "octa_probe_stream_load: bad arguments");
+    probe_stream_load_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>((float4*)buf, bytes / 16, reps);
+    OCTA_CHECK_LAUNCH("probe_stream_load");
+    return OCTA_OK;
+}

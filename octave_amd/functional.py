@@ -375,6 +375,11 @@ def _pack_desc_fill(d, kind: str, w: Tensor, out: Tensor, dtype, groups: int, pa
 def _packed(w: Tensor, kind: str, dtype, groups: int, pad_to: int) -> Tensor:
     # only nn.Parameters are cached (they persist); identity is checked through a weak reference
     # because both id() and data_ptr() are recycled once a tensor dies
+    pre = getattr(w, "_octa_packed", None)       # operands that came with the tensor (a spectral-normalised weight: SpectralNormBatchFn)
+    if pre is not None:
+        t = pre.get((kind, dtype, groups, pad_to))
+        if t is not None:
+            return t
     cacheable = isinstance(w, torch.nn.Parameter)
     key = (id(w), kind, dtype, groups, pad_to)
     tag = _pack_tag(w)
@@ -1083,6 +1088,7 @@ class Conv2dFn(Function):
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
+        ctx.w_pre = getattr(w, "_octa_packed", None)       # operands that came with the weight (saved tensors come back as new objects)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -1090,6 +1096,8 @@ class Conv2dFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
+        if ctx.w_pre is not None:
+            w._octa_packed = ctx.w_pre
         stride, pad, groups, act, xshape = ctx.cfg
         if act != ACT_NONE:
             dy = raw_act_bwd(y, dy, act)
@@ -1818,7 +1826,7 @@ class SpectralNormBatchFn(Function):
     v1, ...) -> (w0 / sigma0, w1 / sigma1, ...)."""
 
     @staticmethod
-    def forward(ctx, training, eps, *wuv):
+    def forward(ctx, training, eps, pack_dtype, *wuv):
         from ._lib import SnJob
         n = len(wuv) // 3
         if n < 1 or n > 8 or len(wuv) != 3 * n:
@@ -1848,6 +1856,19 @@ class SpectralNormBatchFn(Function):
             off += K + Cout
             j = jobs[i]
             j.w, j.u, j.v, j.sigma, j.w_sn, j.ws, j.uv_saved, j.Cout, j.K = _p(wd), _p(u), _p(v), _p(sigma), _p(wsn), _p(ws), _p(uv), Cout, K
+            if pack_dtype is not None and wd.dim() == 4 and _SN_PACK:
+                # the conv that consumes w_sn wants its packed operands (forward; tap-major data gradient for the few-channel strided
+                # layers): written by the launch that writes w_sn instead of two pack launches per layer and call
+                _, Cin, KH, KW = wd.shape
+                cp, op = round8(Cin), round8(Cout)
+                pf = torch.empty((Cout * KH * KW * cp,), dtype=pack_dtype, device=dev)
+                j.packed_fwd, j.KH, j.KW, j.Cin, j.pack_dtype = _p(pf), KH, KW, Cin, _dt(pack_dtype)
+                pre = {("fwd", pack_dtype, 1, cp): pf}
+                if Cin <= 16 and _COL2IM_TAPS and training:
+                    pd = torch.empty((KH * KW * cp * op,), dtype=pack_dtype, device=dev)
+                    j.packed_dgrad_taps = _p(pd)
+                    pre[("dgrad_taps", pack_dtype, 1, op)] = pd
+                wsn._octa_packed = pre
             keep.append((wd, sigma, uv))
             outs.append(wsn)
         if not pz:
@@ -1894,16 +1915,21 @@ class SpectralNormBatchFn(Function):
                 j.Cout, j.K, j.accumulate, j.dwsn_khw = Cout, K, acc, khw
                 keep.append((dwsn, dw))
             lib().octa_spectral_norm_bwd_batch(jobs, len(live), 1, _st())
-        out = [None, None]
+        out = [None, None, None]
         for i in range(n):
             out += [grads[i], None, None]
         return tuple(out)
 
 
-def spectral_norm_batch(triples, training: bool, eps: float):
-    """[(weight_orig, u, v), ...] -> [weight / sigma, ...] with one power iteration each in training (blocks.py:105-108)."""
+_SN_PACK = os.environ.get("OCTA_SN_PACK", "1") != "0"
+
+
+def spectral_norm_batch(triples, training: bool, eps: float, pack_dtype=None):
+    """[(weight_orig, u, v), ...] -> [weight / sigma, ...] with one power iteration each in training (blocks.py:105-108).
+    pack_dtype: the compute dtype of the convs that will consume the weights -- their packed operands are then produced by the same
+    launch (they travel on the returned tensors as `_octa_packed`, which functional._packed honours)."""
     flat = [t for tr in triples for t in tr]
-    return list(SpectralNormBatchFn.apply(training, eps, *flat))
+    return list(SpectralNormBatchFn.apply(training, eps, pack_dtype, *flat))
 
 
 class FullConvFn(Function):

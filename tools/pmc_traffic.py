@@ -25,9 +25,9 @@ def short(name):
     if mr:      # <T, TAPS, NCH, TN, MODE> -> the name launch_res() reports (256 pixels x TN*16 channels)
         fam = "conv_res3x3_kernel" if int(mr.group(2)) == 9 else "conv_res1x1_kernel"
         return f"{fam}<{'bf16' if mr.group(1) == 'unsigned short' else 'f16'},256x{int(mr.group(4)) * 16}>"
-    mh = re.match(r"void conv_halo8_kernel<(unsigned short|f16_t), (\d+)>", name)
+    mh = re.match(r"void (conv_halo8_kernel|conv_halo16_kernel|conv_halo16p_kernel)<(unsigned short|f16_t), (\d+)>", name)
     if mh:
-        return f"conv_halo8_kernel<{'bf16' if mh.group(1) == 'unsigned short' else 'f16'},256x128>"
+        return f"{mh.group(1)}<{'bf16' if mh.group(2) == 'unsigned short' else 'f16'},256x128>"
     mp = re.match(r"void pwgemm_kernel<(unsigned short|f16_t), (\d+), (\d+)>", name)
     if mp:
         return f"pwgemm_kernel<{'bf16' if mp.group(1) == 'unsigned short' else 'f16'},{int(mp.group(2)) * 64}x{int(mp.group(3)) * 64}>"
