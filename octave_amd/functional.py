@@ -573,12 +573,15 @@ def _choose_algo(kind: str, d, launch) -> int:
         for c in cands:
             d.algo = c
             launch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch(); launch(); launch()
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
+            t = None
+            for _ in range(2):                             # the better of two timings of three launches (one noisy sample used to decide ~1 pick in 20)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch(); launch(); launch()
+                e1.record()
+                e1.synchronize()
+                tt = e0.elapsed_time(e1)
+                t = tt if t is None else min(t, tt)
             if best_t is None or t < best_t * 0.97:        # a challenger must win by 3 %
                 best, best_t = c, t
     _ALGO_CACHE[key] = best

@@ -3,7 +3,7 @@ import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 fam = collections.OrderedDict([
-    ("conv fwd/dgrad", r"conv_igemm|conv3x3_halo_kernel|conv_halo8|halo8_splitk|igemm8_splitk|pwgemm|conv_res_kernel|col2im"), ("conv wgrad", r"wgrad"), ("split-attention (+ its bn0 on the fly)", r"splat"), ("batchnorm", r"bn_"),
+    ("conv fwd/dgrad", r"conv_igemm|conv3x3_halo_kernel|conv_halo8|conv_halo16|halo8_splitk|igemm8_splitk|pwgemm|conv_res_kernel|col2im"), ("conv wgrad", r"wgrad"), ("split-attention (+ its bn0 on the fly)", r"splat"), ("batchnorm", r"bn_"),
     ("attention gate", r"aag"), ("loss", r"wpce|kl_|softmax|lsgan"), ("pack/adam", r"pack|adam"), ("disc misc", r"noise|spectral|fullconv"),
     ("layout/pool/copy (octa)", r"nchw|nhwc|copy_channels|pool|act_bwd|colsum|zero_words"), ("ATen / runtime", r"at::|rocclr|Cijk|elementwise|vectorized"),
 ])
