@@ -309,7 +309,7 @@ def main():
                     help="after capture: replay the hipGraphs, launch the same static step from Python, or time both and pick (default)")
     ap.add_argument("--algo-cache", default=None, help="JSON file with measured per-shape conv kernel choices: loaded if present, written after warm-up")
     ap.add_argument("--grad-comm", default="auto", choices=["auto", "f32", "bf16"],
-                    help="dtype of the gradient all-reduce: auto = bf16 when --gpus > 1 (143 MB instead of 286 MB per step over xGMI), f32 otherwise")
+                    help="dtype of the gradient all-reduce: auto = f32 (what DistributedDataParallel on the reference exchanges; 286 MB per step); bf16 halves the bytes over xGMI at two extra roundings per gradient")
     ap.add_argument("--sustained", type=int, default=500, help="replayed steps of the sustained-rate leg after the timed region (0: skip)")
     ap.add_argument("--no-dice", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -360,7 +360,10 @@ def main():
     net_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if (rank == 0 and not args.no_cpu_baseline and world == 1) else None
     cdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     ls = (1024.0 if args.dtype == "f16" else 1.0) if args.loss_scale is None else ("dynamic" if args.loss_scale == "dynamic" else float(args.loss_scale))
-    comm_dt = torch.bfloat16 if (args.grad_comm == "bf16" or (args.grad_comm == "auto" and world > 1)) else None
+    # the reference's DistributedDataParallel exchanges fp32 gradients: the headline does too ("auto" = f32 since round 5; 286 MB per
+    # step, ~1.4 ms of ring time at 200 GB/s, overlapped with ~15 ms of backward).  --grad-comm bf16 halves the bytes at two extra
+    # roundings per gradient and is reported as what it is in config.grad_comm_dtype
+    comm_dt = torch.bfloat16 if args.grad_comm == "bf16" else None
     step = TrainStep(net, lr=1e-4, compute_dtype=cdt, adversarial=not args.seg_only, loss_scale=ls, grad_comm_dtype=comm_dt)
     x, ys, real = synth_batch(B, H, rank, dev)
     batch = (x, ys, mask_pyramid(real))
@@ -407,7 +410,16 @@ def main():
     loss = float(out["loss_seg"].item())
     if not all(math.isfinite(float(v.item())) for v in out.values()):
         sys.exit(f"bench.py: non-finite losses after the timed steps ({ {k: float(v.item()) for k, v in out.items()} }): the measurement is void")
-    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host enqueue {t_enq / args.steps * 1e3:.1f} ms/step)")
+    # the host's own cost of a step: two steps enqueued into an EMPTY queue (nothing to wait for).  t_enq above is not that number: once
+    # the runtime's queue is full the host blocks inside the launch, so over 20-40 steps it approaches the device time (5 ms per step
+    # over 20 steps, 20 over 40).  All ranks run it (a step exchanges gradients).
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    for _ in range(2):
+        step(*batch)
+    host_ms = (time.perf_counter() - th) / 2 * 1e3
+    torch.cuda.synchronize()
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host: {host_ms:.2f} ms per step into an empty queue; {t_enq / args.steps * 1e3:.1f} ms per step incl. blocking on the full queue)")
     # sustained rate: >= 500 back-to-back steps on the launch path chosen above, nothing on the host inside the loop but the
     # step call itself (no health checks, no .item()); same barriers and max over ranks as the headline
     sustained = None
@@ -447,6 +459,7 @@ def main():
                        "launch": "eager" if args.no_graph else ("hipGraph replay (forward | backward pieces | discriminator step on a second stream | Adam, around the 2 gradient all-reduces)" if step.launch == "graph"
                                                                else "eager launches of the captured static step (auto-tuned: faster than graph replay on this host)")},
             "final_loss_seg": round(loss, 5),
+            "host_ms_per_step": round(host_ms, 3),      # host time to enqueue one step into an empty queue (the replay is device-bound while this < ms_per_step)
         }
         res["config"]["grad_comm_dtype"] = "bf16" if comm_dt is not None else "fp32"
         if sustained is not None:
