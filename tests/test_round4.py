@@ -247,8 +247,8 @@ def test_hip_adversarial_step_400c_conditioned_vs_reference(dev, golden, determi
     0.9 % from its float64 twin here (1.3 % / 5.5 % in trainstep_400), so the bounds can be the ones the review asked for.  The library
     runs in DETERMINISTIC mode: the step is evaluated twice and must be bit-identical (logits, every gradient), and
       * logits: max |hip - ref64| <= BAND x max |ref32 - ref64| (no factor 2), RMS likewise;
-      * gradient norms: median <= BAND_GRAD x reference + 2 %, p95 <= BAND_GRAD x reference + 10 %, no tensor beyond 75 %;
-      * sixteen FULL gradients spread over the ten buckets: relative L2 distance to float64 <= BAND_GRAD x the reference's own + 2 %."""
+      * gradient norms: median <= BAND_GRAD x reference + 0.2 %, p95 <= BAND_GRAD x reference + 1 %, no tensor beyond 25 %;
+      * sixteen FULL gradients spread over the ten buckets: relative L2 distance to float64 <= BAND x the reference's own + 0.5 %."""
     from architectures.models.octa import OctaScribbleNet
     from architectures.segmentor.losses import DiceLoss, InterlayerDivergence
     from octave_amd.synth import COND_SCALE
@@ -307,13 +307,15 @@ def test_hip_adversarial_step_400c_conditioned_vs_reference(dev, golden, determi
     for k in ("fc.weight", "fc.bias"):
         g32, g64 = float(G[f"seg_gradnorm/{k}"]), float(G[f"seg_gradnorm_f64/{k}"])
         assert abs(gn[k] - g64) <= BAND * abs(g32 - g64) + 1e-3 * g64, (k, gn[k], g32, g64)
-    _norm_band("trainstep 400c seg", gn, G, "seg_gradnorm/", "seg_gradnorm_f64/", floor=0.02, tail_floor=0.10)
+    # (measured, deterministic: median 2.4e-3 / p95 8.6e-3 / max 2.7e-2 against the reference's own 1.2e-3 / 9.0e-3 / 5.2e-2:
+    # profiles/r05_band_ratios.txt; the review allowed floors of 2 % / 10 %, the measurement supports 0.2 % / 1 %)
+    _norm_band("trainstep 400c seg", gn, G, "seg_gradnorm/", "seg_gradnorm_f64/", floor=2e-3, tail_floor=1e-2)
     top = max(float(g) for k, g in G.items() if k.startswith("seg_gradnorm_f64/"))
     devs = {k: abs(v - float(G[f"seg_gradnorm_f64/{k}"])) / float(G[f"seg_gradnorm_f64/{k}"]) for k, v in gn.items()
             if float(G[f"seg_gradnorm_f64/{k}"]) > 1e-6 * top}
     worst = max(devs.items(), key=lambda kv: kv[1])
     print(f"[trainstep 400c] largest gradient-norm deviation {worst[1]:.3f} ({worst[0]})")
-    assert worst[1] <= 0.75, worst
+    assert worst[1] <= 0.25, worst
     # ---- full gradients
     for k, g32 in G.items():
         if not k.startswith("seg_grad/"):
@@ -325,7 +327,7 @@ def test_hip_adversarial_step_400c_conditioned_vs_reference(dev, golden, determi
         assert got.shape == g64.shape, (name, got.shape, g64.shape)
         e_h, e_r = np.linalg.norm(got - g64) / np.linalg.norm(g64), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
         print(f"[trainstep 400c] grad {name:34s} rel L2 to ref64: hip {e_h:.3e} ref32 {e_r:.3e}")
-        assert e_h <= BAND_GRAD * e_r + 0.02, (name, e_h, e_r)
+        assert e_h <= BAND * e_r + 5e-3, (name, e_h, e_r)
     # ---- the discriminator's own step
     d32, d64 = float(G["l_d"]), float(G["l_d_f64"])
     assert abs(l_d - d64) <= BAND * abs(d32 - d64) + 2e-4 * abs(d64), (l_d, d32, d64)
