@@ -731,6 +731,43 @@ def test_halo16p_many_tiles_per_workgroup(dev, case):
     assert torch.equal(outs[14][0], outs[13][0]) and torch.equal(outs[14][1], outs[13][1]), "persistent and one-tile-per-workgroup kernels differ"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_spectral_norm_batch_writes_the_packed_conv_operands(dev, dtype):
+    """octa_sn_job.packed_fwd / packed_dgrad_taps (round 5): the launch that writes w / sigma also writes the conv's packed operands.
+    They must equal, bit for bit, what the stand-alone pack kernels make of the returned normalised weight, and a conv through
+    functional.conv2d must pick them up (no pack launch: the weight is a plain tensor, so nothing else would cache it)."""
+    from octave_amd import functional as F_
+    gen = torch.Generator().manual_seed(5)
+    triples = []
+    for (Cout, Cin) in [(128, 15), (256, 15)]:
+        w = torch.nn.Parameter((torch.randn(Cout, Cin, 4, 4, generator=gen) * 0.1).to(dev))
+        u = torch.nn.functional.normalize(torch.randn(Cout, generator=gen), dim=0).to(dev)
+        v = torch.nn.functional.normalize(torch.randn(Cin * 16, generator=gen), dim=0).to(dev)
+        triples.append((w, u, v))
+    wn = F_.spectral_norm_batch(triples, True, 1e-12, dtype)
+    for (w, u, v), wsn in zip(triples, wn):
+        Cout, Cin = w.shape[:2]
+        pre = getattr(wsn, "_octa_packed", None)
+        assert pre is not None and ("fwd", dtype, 1, 16) in pre and ("dgrad_taps", dtype, 1, F_.round8(Cout)) in pre
+        plain = wsn.detach().clone()                         # same values, no operands attached
+        for kind, pad in (("fwd", 16), ("dgrad_taps", F_.round8(Cout))):
+            want = F_._packed(plain, kind, dtype, 1, pad)
+            assert torch.equal(pre[(kind, dtype, 1, pad)].view(torch.uint8), want.view(torch.uint8)), (kind, Cout)
+        assert F_._packed(wsn, "fwd", dtype, 1, 16) is pre[("fwd", dtype, 1, 16)]
+
+
+def test_probe_stream_load_leaves_the_buffer_unchanged(dev):
+    """octa_probe_stream_load (tools/comm_pressure.py's stand-in for a collective's kernels): any footprint / repetition count, the
+    buffer's contents are what they were."""
+    from octave_amd._lib import lib
+    x = torch.randn(1 << 20, device=dev)
+    want = x.clone()
+    for nb, reps in ((1, 1), (32, 3), (256, 2)):
+        lib().octa_probe_stream_load(x.data_ptr(), x.numel() * 4, nb, reps, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+
+
 def test_two_streams_split_convs_with_their_own_scratch(dev):
     """SURVEY 8(b) "re-entrant across streams": the tail-split scratch travels in the call (octa_conv_desc.ws), so two streams run
     split convs CONCURRENTLY, each with a buffer of its own, with no registration dance: 20 alternating launches per stream of two
