@@ -256,7 +256,9 @@ template <typename T> __device__ __forceinline__ void sn_pack(const SnBatch& b, 
             const int ci = (int)(i % cinp);
             const int64_t t = i / cinp;
             const int tap = (int)(t % khw), co = (int)(t / khw);
-            DT<T>::st(out + i, ci < Cin ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f);
+            float v = ci < Cin ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f;
+            asm volatile("" : "+v"(v));     // the fp32 product, rounded as w_sn stores it, THEN converted (no fused mul + f16 convert)
+            DT<T>::st(out + i, v);
         }
     }
     if (b.pk_dgt[j]) {            // tap-major data-gradient operand [KH*KW][cin_pad][cout_pad]
@@ -266,7 +268,9 @@ template <typename T> __device__ __forceinline__ void sn_pack(const SnBatch& b, 
             const int co = (int)(i % coutp);
             const int64_t t = i / coutp;
             const int ci = (int)(t % cinp), tap = (int)(t / cinp);
-            DT<T>::st(out + i, (ci < Cin && co < Cout) ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f);
+            float v = (ci < Cin && co < Cout) ? w[(int64_t)co * K + ci * khw + tap] * inv : 0.f;
+            asm volatile("" : "+v"(v));
+            DT<T>::st(out + i, v);
         }
     }
     (void)KW;

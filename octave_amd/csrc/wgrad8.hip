@@ -808,6 +808,15 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
             batch.p[i - i0] = p;
         }
         if (nblk <= 0 || nblk >= (1ll << 30)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_conv2d_wgrad_batch: bad grid %lld", (long long)nblk);
+        static const bool logit = getenv("OCTA_WG_LOG") != nullptr;      // tools/wgrad_sched_sim.py reads these lines
+        if (logit) {
+            fprintf(stderr, "wg9 launch S %lld nblk %lld :", (long long)S, (long long)nblk);
+            for (int i = 0; i < batch.n; ++i) {
+                const WgProb& p = batch.p[i];
+                fprintf(stderr, " [Ng %d Kpad %d M %d tiles %d steps %d split %d]", p.Ng, p.Kpad, p.M, p.tilesN * p.tilesK * p.groups, (p.M + 31) / 32, p.splitM);
+            }
+            fprintf(stderr, "\n");
+        }
         static const bool stagger = getenv("OCTA_WG8_NOSTAGGER") == nullptr;
         if (g_wg9_ablate && !F16) {
             switch (g_wg9_ablate) {
