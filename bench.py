@@ -419,7 +419,7 @@ def main():
         step(*batch)
     host_ms = (time.perf_counter() - th) / 2 * 1e3
     torch.cuda.synchronize()
-    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step (host: {host_ms:.2f} ms per step into an empty queue; {t_enq / args.steps * 1e3:.1f} ms per step incl. blocking on the full queue)")
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step (host: {host_ms:.2f} ms per step into an empty queue; {t_enq / args.steps * 1e3:.1f} ms per step incl. blocking on the full queue)")
     # sustained rate: >= 500 back-to-back steps on the launch path chosen above, nothing on the host inside the loop but the
     # step call itself (no health checks, no .item()); same barriers and max over ranks as the headline
     sustained = None

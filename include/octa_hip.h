@@ -538,7 +538,11 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * benchmark).  key 6: LDS image of the 2-D patch kernel's input patch (algo 12): 1 (default) = lines placed so that fragment reads
  * are bank-conflict-free, 0 = the linear image of round 4 (A/B runs).  key 7: 1 = the first-pass reductions (BatchNorm
  * statistics / backward sums, split-attention backward sums) walk their tensor END FIRST, i.e. start on what the producing kernel wrote
- * last and the 256 MB memory-side cache still holds; 0 (default: no gain measured) = forward.  Results are identical (same partial slots). */
+ * last and the 256 MB memory-side cache still holds; 0 (default: no gain measured) = forward.  Results are identical (same partial slots).
+ * key 8: schedule of the 256 x 256 weight-gradient kernel: 0 (default) = rounds of workgroups with one split length for the whole
+ * batch (wgrad9); 1 = every class of problems its own split, blocks dealt to the XCDs in eighths, XCDs started at different
+ * positions of their sequences (wgrad9x); 2 = the same with one persistent workgroup per CU.  Same sums, different atomic order;
+ * no gain measured in situ (the launch is power-limited: DESIGN.md 3.12). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -1,6 +1,7 @@
 // Training-mode BatchNorm2d on NHWC activations: statistics, apply (+residual, +ReLU), backward.
 // HBM-bound: every kernel moves 16-byte chunks, consecutive lanes on consecutive chunks.
 #include "common.hpp"
+#include <algorithm>
 #include <stdlib.h>
 
 // thread t of a 256-thread block owns chunk column (blockIdx.x*TX + t%TX) and row lane t/TX
@@ -15,7 +16,10 @@ static ColMap col_map(int cpr) {
     return m;
 }
 static int rows_per_block(int64_t rows, int RY) {
-    int64_t rpb = cdiv64(rows, 1024);
+    // slabs of the reduction passes: 1024 until round 5; 640 measured -0.1 ms per step in situ (tools/ab_envs.sh: fewer, longer workgroups
+    // amortise a workgroup's fixed cost -- coefficient loads, block reduction, partial store); <= 1024: the partial buffer
+    static const int nby_max = getenv("OCTA_BN_NBY") ? std::max(16, std::min(1024, atoi(getenv("OCTA_BN_NBY")))) : 640;
+    int64_t rpb = cdiv64(rows, nby_max);
     if (rpb < (int64_t)RY * 16) rpb = (int64_t)RY * 16;
     return (int)rpb;
 }
@@ -62,6 +66,25 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
             unpack16<T>(*(const uint4*)(x + rbeg * ldx + xoff + col * EPC), mu);
             const T* __restrict__ xp = x + xoff + col * EPC;
             int64_t r = rbeg;
+            // eight row loads in flight per thread first (a slab is only 16-64 row steps long: with four, every step waited for a
+            // full memory latency and the pass read 2 TB/s on the 40 MB layers; round 5, tools/bn_reduce_micro.py)
+            for (; r + 7 * RY < r1; r += 8 * RY) {
+                uint4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = *(const uint4*)(xp + (r + (int64_t)u * RY) * ldx);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    float x0[EPC], x1[EPC];
+                    unpack16<T>(q[u], x0); unpack16<T>(q[u + 1], x1);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float d0 = x0[e] - mu[e], d1 = x1[e] - mu[e];
+                        sa[e] += d0 + d1;
+                        sb[e] += d0 * d0 + d1 * d1;
+                    }
+                }
+                cnt += 8;
+            }
             for (; r + 3 * RY < r1; r += 4 * RY) {
                 const uint4 q0 = *(const uint4*)(xp + r * ldx), q1 = *(const uint4*)(xp + (r + RY) * ldx);
                 const uint4 q2 = *(const uint4*)(xp + (r + 2 * RY) * ldx), q3 = *(const uint4*)(xp + (r + 3 * RY) * ldx);
@@ -87,6 +110,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
         if (MODE == 1) {
             // two rows per iteration, their (up to six) loads issued before any arithmetic
             const bool um = relu && rmask, uy = relu && !rmask;
+            // four rows (8-12 loads) in flight first: same reason as the statistics pass
+            for (; rbeg + 3 * RY < r1; rbeg += 4 * RY) {
+                uint4 xq[4], dq[4], yq[4];
+                unsigned mq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t rr = rbeg + (int64_t)u * RY;
+                    xq[u] = *(const uint4*)(x + rr * ldx + xoff + col * EPC);
+                    dq[u] = *(const uint4*)(dy + rr * lddy + dyoff + col * EPC);
+                    mq[u] = 0xffu; yq[u] = make_uint4(0, 0, 0, 0);
+                    if (um) mq[u] = rmask[rr * cpr + col];
+                    if (uy) yq[u] = *(const uint4*)(y + rr * ldy + yoff + col * EPC);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float xv[EPC], dv[EPC], yv[EPC];
+                    unpack16<T>(xq[u], xv); unpack16<T>(dq[u], dv);
+                    if (uy) unpack16<T>(yq[u], yv);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const bool k = uy ? (yv[e] > 0.f) : ((mq[u] >> e) & 1u) != 0;
+                        const float g = k ? dv[e] : 0.f;
+                        sa[e] += g;
+                        sb[e] += g * (xv[e] - mu[e]) * is[e];
+                    }
+                }
+            }
             for (; rbeg + RY < r1; rbeg += 2 * RY) {
                 const int64_t ra = rbeg, rb2 = rbeg + RY;
                 const uint4 xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC), xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
@@ -151,19 +201,23 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
         for (int ch = threadIdx.x; ch < TX * EPC; ch += 256) {
             const int c = blockIdx.x * TX * EPC + ch;
             if (c >= C) continue;
-            double n = 0.0, mean_b = 0.0, m2 = 0.0;      // Chan et al. pairwise merge
+            // merge of the RY thread partials (n_t, mean_t, M2_t) around a common reference (row group 0's mean, which always has
+            // samples): S1 = sum n_t (mean_t - ref), S2 = sum M2_t + n_t (mean_t - ref)^2; mean = ref + S1 / n, M2 = S2 - S1^2 / n --
+            // plain sums and ONE division (the pairwise Chan merge this replaces divided twice per row group in double precision, a
+            // serial chain of up to 64 x 2 divisions at the end of every workgroup); ref is within a few sigma / sqrt(n_t) of the mean,
+            // so nothing cancels
+            const double ref = (double)red[(size_t)ch * 3];
+            double n = 0.0, s1 = 0.0, s2 = 0.0;
             for (int yy = 0; yy < RY; ++yy) {
                 const float* pr = red + ((size_t)yy * TX * EPC + ch) * 3;
-                const double nb = (double)pr[2];
-                if (nb > 0.0) {
-                    const double delta = (double)pr[0] - mean_b, tot = n + nb;
-                    mean_b += delta * nb / tot;
-                    m2 += (double)pr[1] + delta * delta * n * nb / tot;
-                    n = tot;
-                }
+                const double nb = (double)pr[2], d = (double)pr[0] - ref;
+                n += nb;
+                s1 += nb * d;
+                s2 += (double)pr[1] + nb * d * d;
             }
-            partial[((size_t)slab * 2 + 0) * C + c] = (float)mean_b;
-            partial[((size_t)slab * 2 + 1) * C + c] = (float)m2;
+            const double m1 = n > 0.0 ? s1 / n : 0.0;
+            partial[((size_t)slab * 2 + 0) * C + c] = (float)(ref + m1);
+            partial[((size_t)slab * 2 + 1) * C + c] = (float)(s2 - s1 * m1);
         }
         return;
     }
@@ -623,7 +677,8 @@ extern "C" int octa_bn_stats(const void* x, int64_t rows, int C, int ld, int off
 // per-channel parameters for every 16 bytes of activations: the L1 request rate, not HBM, set its speed.)
 static inline int ew_blocks_aligned(int64_t total, int cpr) {
     int64_t b = cdiv64(total, 256);
-    const int64_t cap = 256 * 10;                       // ~10 resident workgroups per CU
+    static const int per_cu = getenv("OCTA_EW_WG_PER_CU") ? std::max(1, atoi(getenv("OCTA_EW_WG_PER_CU"))) : 10;
+    const int64_t cap = 256 * per_cu;                   // ~10 resident workgroups per CU
     if (b > cap) b = cap;
     int a = cpr, g = 256;                               // unit = cpr / gcd(cpr, 256)
     while (g) { const int t = a % g; a = g; g = t; }

@@ -1,6 +1,14 @@
 // Split-attention glue (radix 2) and the adversarial attention gate / 1x1 head.  HBM-bound streaming
 // kernels: 16-byte chunks, wavefront shuffles for the per-pixel and per-channel sums.
 #include "common.hpp"
+#include <algorithm>
+#include <stdlib.h>
+
+// slab counts of the streaming passes (workgroups per sample along HW): swept in situ (round 5, tools/ab_envs.sh): fewer, longer
+// workgroups amortise a workgroup's fixed cost (coefficient loads, block reduction, partial store)
+static int splat_reduce_slabs() { static const int v = getenv("OCTA_SPLAT_SLABS") ? std::max(1, atoi(getenv("OCTA_SPLAT_SLABS"))) : 24; return v; }
+static int splat_apply_slabs() { static const int v = getenv("OCTA_SPLAT_APPLY_SLABS") ? std::max(1, atoi(getenv("OCTA_SPLAT_APPLY_SLABS"))) : 128; return v; }
+static int splat_dx_slabs(int B) { static const int v = getenv("OCTA_SPLAT_DX_SLABS") ? std::max(1, atoi(getenv("OCTA_SPLAT_DX_SLABS"))) : 64; return std::max(1, std::min(v, 1024 / std::max(1, B))); }
 
 static inline int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b > 131072 ? 131072 : (b < 1 ? 1 : b)); }   // see norm.hip
 
@@ -52,7 +60,7 @@ extern "C" int octa_splat_gap(const void* x, float* gap, int B, int HW, int C, i
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int rpb = cdiv(HW, 64);
+    int rpb = cdiv(HW, splat_reduce_slabs());
     if (rpb < RY * 8) rpb = RY * 8;
     if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256) void splat_apply_kernel(const T* __restrict__ 
 extern "C" int octa_splat_apply(const void* x, const float* logits, void* out, int B, int HW, int C, int dtype, int relu,
                                 octa_stream_t stream) {
     OCTA_REQUIRE(x && logits && out && C % 8 == 0 && C <= 8192, "octa_splat_apply: bad arguments");
-    int rpb = cdiv(HW, 128);
+    int rpb = cdiv(HW, splat_apply_slabs());
     if (rpb < 8) rpb = 8;
     dim3 grid(cdiv(HW, rpb), B);
     const size_t sh = (size_t)C * sizeof(float);
@@ -218,7 +226,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
         int TX, gx;
         splat_map(C / epc, TX, gx);
         const int RY = 256 / TX;
-        int rpb = cdiv(HW, 64);
+        int rpb = cdiv(HW, splat_reduce_slabs());
         if (rpb < RY * 8) rpb = RY * 8;
         if (octa_deterministic()) rpb = HW;
         dim3 grid(gx, cdiv(HW, rpb), B);
@@ -231,7 +239,7 @@ extern "C" int octa_splat_bwd(const void* dout, const void* x, const float* logi
         OCTA_CHECK_LAUNCH("splat_softmax_bwd");
     } else {
         OCTA_REQUIRE(dx, "octa_splat_bwd(phase 1): null pointer");
-        int rpb = cdiv(HW, 128);
+        int rpb = cdiv(HW, splat_apply_slabs());
         if (rpb < 8) rpb = 8;
         dim3 grid(cdiv(HW, rpb), B);
         const size_t sh = (size_t)2 * C * sizeof(float);
@@ -651,7 +659,7 @@ extern "C" int octa_splat_bn_gap(const void* x, const float* mean, const float* 
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int rpb = cdiv(HW, 64);
+    int rpb = cdiv(HW, splat_reduce_slabs());
     if (rpb < RY * 8) rpb = RY * 8;
     if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
@@ -666,7 +674,7 @@ extern "C" int octa_splat_bn_apply(const void* x, const float* mean, const float
                                    void* out, int B, int HW, int C, int dtype, int relu, octa_stream_t stream) {
     OCTA_SPLAT_BN_ARGS;
     OCTA_REQUIRE(logits && out, "octa_splat_bn_apply: null pointer");
-    int rpb = cdiv(HW, 128);
+    int rpb = cdiv(HW, splat_apply_slabs());
     if (rpb < 8) rpb = 8;
     dim3 grid(cdiv(HW, rpb), B);
     const size_t sh = (size_t)5 * C * sizeof(float);
@@ -685,7 +693,7 @@ extern "C" int octa_splat_bn_bwd_logits(const void* dout, const void* x, const f
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int rpb = cdiv(HW, 64);
+    int rpb = cdiv(HW, splat_reduce_slabs());
     if (rpb < RY * 8) rpb = RY * 8;
     if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
@@ -710,7 +718,7 @@ extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const 
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int rpb = cdiv(HW, 64);
+    int rpb = cdiv(HW, splat_reduce_slabs());
     if (rpb < RY * 8) rpb = RY * 8;
     if (octa_deterministic()) rpb = HW;                    // one workgroup per (sample, column block): one add per address, fixed order
     dim3 grid(gx, cdiv(HW, rpb), B);
@@ -732,7 +740,7 @@ extern "C" int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const floa
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int nslab = 1024 / B;
+    int nslab = splat_dx_slabs(B);
     if (nslab < 1) nslab = 1;
     int rpb = cdiv(HW, nslab);
     if (rpb < RY * 8) rpb = RY * 8;
@@ -759,7 +767,7 @@ extern "C" int octa_splat_bn_bwd_dx(const void* dout, const void* x, const float
     int TX, gx;
     splat_map(C / epc, TX, gx);
     const int RY = 256 / TX;
-    int nslab = 1024 / B;                                  // partial rows: B * nslab <= 1024 (octa_bn_workspace_floats)
+    int nslab = splat_dx_slabs(B);                                  // partial rows: B * nslab <= 1024 (octa_bn_workspace_floats)
     if (nslab < 1) nslab = 1;
     int rpb = cdiv(HW, nslab);
     if (rpb < RY * 8) rpb = RY * 8;

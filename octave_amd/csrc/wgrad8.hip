@@ -18,6 +18,9 @@
 #include "common.hpp"
 #include <vector>
 #include <algorithm>
+#include <functional>
+#include <map>
+#include <mutex>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 wg_f16x8_t;
@@ -37,6 +40,7 @@ struct WgProb {
     unsigned magicOW, magicOH;      // floor(2^32 / d) + 1: exact quotient for n * d < 2^32
     int tilesN, tilesK, groups, splitM, mPerSplit;
     int blockStart;
+    int nblocks;                    // tilesN * tilesK * groups * splitM (wgrad9x: the XCD-interleaved schedule)
     // partial-store mode (round 4, conv.hip: wgrad_fold_kernel): part != NULL -> M-split sp stores its raw tile to
     // part[sp * part_slice + (g * Ng + n) * Kpad + k] (bias sums behind the groups * Ng * Kpad block) instead of float atomics into dw
     float* part;
@@ -679,6 +683,325 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
     }
 }
 
+
+// wgrad9x: the wgrad9 tile loop behind an XCD-interleaved, optionally persistent schedule (round 5).
+// What the launch log of a training step showed (OCTA_WG_LOG): a wgrad9 launch is 3-5 lock-step rounds of 256 workgroups, every
+// round ends in one burst of 64 MB of float atomics (~45 us at the chip's 1.3 TB/s, the CUs idle meanwhile), and one split length
+// for all problems of a batch quantises the rounds.  Here
+//   * every problem carries its own split (host: per-class search over a model of this schedule), and its blocks -- pixel range
+//     slowest, tiles fastest, as before -- are dealt to the eight XCDs in eighths, so that every XCD gets the same mix;
+//   * an XCD's sequence is cyclic and XCD x starts at position sched.off[x]: the XCDs are in different problems at any time, their
+//     rounds end at different times and the atomics of one XCD's epilogues drain beside the main loops of the others;
+//   * PERSIST = 1: gridDim.x = 8 * SL resident workgroups; workgroup (xcd, slot) takes the positions slot, slot + SL, ... of its
+//     XCD's sequence (no launch ramp between blocks; the static deal equals the hardware's when a round's blocks are equally long);
+//     PERSIST = 0: one position per workgroup, gridDim.x = 8 * (longest XCD sequence).
+// blockIdx & 7 is used as the XCD label (a performance assumption only: every position is processed exactly once whatever the
+// placement).
+#ifdef OCTA_DIAG_STAMPS
+// timeline of the wgrad9x workgroups (diagnostic build only): [workgroup][0] = items stamped, then per item 4 x s_memrealtime (100 MHz):
+// item begin, main loop begin, main loop end, epilogue drained (the diagnostic build waits for its atomics there), and s_memtime (shader
+// clock) at main loop begin / end
+#define WG9X_MAXIT 12
+__device__ unsigned long long octa_diag_timeline_wg9x[2048][1 + 6 * WG9X_MAXIT];
+extern "C" int octa_diag_timeline_read_wgrad9x(void* host, int clear) {
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(octa_diag_timeline_wg9x)) != hipSuccess) return -3;
+        return hipMemset(p, 0, sizeof(octa_diag_timeline_wg9x)) == hipSuccess ? 0 : -3;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(octa_diag_timeline_wg9x), sizeof(octa_diag_timeline_wg9x)) == hipSuccess ? 0 : -3;
+}
+#define WG9X_STAMP(k)                                                                                                                      \
+    {                                                                                                                                      \
+        unsigned long long r_;                                                                                                             \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory");                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && tl_item < WG9X_MAXIT) octa_diag_timeline_wg9x[blockIdx.x][1 + 6 * tl_item + (k)] = r_;  \
+    }
+#define WG9X_STAMP_CLK(k)                                                                                                                  \
+    {                                                                                                                                      \
+        unsigned long long r_;                                                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory");                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && tl_item < WG9X_MAXIT) octa_diag_timeline_wg9x[blockIdx.x][1 + 6 * tl_item + (k)] = r_;  \
+    }
+#else
+#define WG9X_STAMP(k)
+#define WG9X_STAMP_CLK(k)
+#endif
+struct WgSched { int len[8], off[8]; };   // blocks in XCD x's sequence; the position it starts at (a multiple of the slots per XCD)
+
+template <int F16, int PERSIST>
+__global__ __launch_bounds__(512) void wgrad9x_kernel(const WgBatch batch, const WgSched sched) {
+    constexpr int BN = 256, BK = 256, MT = 32, SLOTS = 4;
+    constexpr int RB = 512, IMG = MT * RB, SBYTES = 2 * IMG;
+    constexpr int LPR = 32, RPI = 2, IPW = 2;
+    constexpr int LPT = 2 * IPW;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SLOTS * SBYTES + BN * 4];
+    float* const sBias = (float*)(smem + SLOTS * SBYTES);
+
+    const int Lb = blockIdx.x, xcd = Lb & 7, SL = (int)(gridDim.x >> 3);
+    const int nprob = batch.n, seqlen = sched.len[xcd], seqoff = sched.off[xcd];
+    int pos = Lb >> 3;
+#ifdef OCTA_DIAG_STAMPS
+    int tl_item = 0;
+#endif
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave >> 2, wk = wave & 3;
+    const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
+    const int drow = wave * RPI + lane / LPR;
+    const int dpos = lane % LPR;
+    const int df_ = (drow & 3) << 1;
+    const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
+    const unsigned sbase = wg_lds_addr(smem);
+    const int r = lane & 15, gq = lane >> 4;
+    const int frow = 8 * (gq >> 1) + (r >> 2);
+    const int fr = ((r >> 2) & 3) << 1;
+    const int cb = (r & 3) * 8;
+    unsigned abase[4], bbase[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = sbase + (unsigned)(frow * RB + ((((wn * 4 + i) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = sbase + (unsigned)(IMG + frow * RB + ((((wk * 2 + j) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+    const int brow = t / LPR, bpos = t % LPR;
+    const int bf_ = (brow & 3) << 1;
+    const int bchunk = (((bpos >> 1) ^ bf_) << 1) | (bpos & 1);
+
+    wg_f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (;;) {
+        // ---- the problem and block of position pos in this XCD's (cyclic) sequence: problem p contributes its x-th eighth
+        if (pos >= seqlen) return;
+        WG9X_STAMP(0)
+        int q = pos + seqoff; q -= q >= seqlen ? seqlen : 0;
+        pos += SL;
+        int pi = 0, first = 0;
+        for (; pi < nprob; ++pi) {
+            const long NB = batch.p[pi].nblocks;
+            first = (int)((NB * xcd) >> 3);
+            const int cnt = (int)((NB * (xcd + 1)) >> 3) - first;
+            if (q < cnt) break;
+            q -= cnt;
+        }
+        if (pi >= nprob) return;               // (cannot happen: seqlen is the sum of the counts)
+        const WgProb& Pk = batch.p[pi];
+        const int tilesN = Pk.tilesN, tilesK = Pk.tilesK, groups = Pk.groups, mPerSplit = Pk.mPerSplit, Mtot = Pk.M;
+        const int Ng = Pk.Ng, Kpad = Pk.Kpad, Cg = Pk.Cg, CgReal = Pk.CgReal, KW = Pk.KW;
+        const int H = Pk.H, W = Pk.W, OH = Pk.OH, OW = Pk.OW, stride = Pk.stride, pad = Pk.pad;
+        const int ldx = Pk.ldx, ldy = Pk.ldy;
+        const unsigned short* const xbase = Pk.x;
+        const unsigned short* const dybase = Pk.dy;
+        int bid = first + q;
+        const int nt = bid % tilesN; bid /= tilesN;
+        const int kt = bid % tilesK; bid /= tilesK;
+        const int g = bid % groups;
+        const int sp = bid / groups;
+        const int n0 = nt * BN, k0 = kt * BK;
+        const int mbeg = sp * mPerSplit;
+        const int mend = min(Mtot, mbeg + mPerSplit);
+        const int nsteps = (mend - mbeg + MT - 1) / MT;
+        if (nsteps <= 0) { if (PERSIST) continue; else return; }
+
+        const bool pvalid = (n0 + dchunk * 8) < Ng;
+        const unsigned long pstep = pvalid ? (unsigned long)((long)MT * ldy * 2) : 0ul;
+        unsigned long pptr[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+            pptr[i] = pvalid ? (unsigned long)(dybase + ((long)(mbeg + drow + i * 8 * RPI) * ldy + Pk.yoff + g * Ng + n0 + dchunk * 8)) : zaddr;
+        const int kel = k0 + dchunk * 8;
+        const bool kvalid = kel < Kpad;
+        const int qtap = kel / Cg, qcc = kel - qtap * Cg;
+        const int qkh = qtap / KW, qkw = qtap - qkh * KW;
+        const int qdh = qkh - pad, qdw = qkw - pad;
+        const unsigned long qbase = (unsigned long)(xbase + (Pk.xoff + g * CgReal + qcc));
+        const bool plain = (Pk.KH == 1 && KW == 1 && pad == 0 && stride == 1);
+        const int ldx2 = ldx * 2;
+        const int dq = MT / OW, dr = MT - dq * OW;
+        const int sdr = stride * dr, sdq = stride * dq, OWs = OW * stride, OHs = OH * stride;
+        const int thrW = OWs + qdw, thrH = OHs + qdh;
+        const int dpix = sdq * W + sdr, cW = stride * W - OWs, cH = H * W - OHs * W;
+        int qih[IPW], qiw[IPW], qpix[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int m = mbeg + drow + i * 8 * RPI;
+            const int ow = m % OW, tq = m / OW, oh = tq % OH, b = tq / OH;
+            qih[i] = oh * stride + qdh; qiw[i] = ow * stride + qdw;
+            qpix[i] = plain ? m : (b * H + qih[i]) * W + qiw[i];
+        }
+        auto issueP = [&](int i, int slot, int mcur) {
+            const bool ok = (mcur + drow + i * 8 * RPI) < mend;
+            const unsigned long src = ok ? pptr[i] : zaddr;
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + (i * 8 + wave) * 1024)));
+            pptr[i] += pstep;
+        };
+        auto issueQ = [&](int i, int slot, int mcur) {
+            const bool ok = kvalid & ((mcur + drow + i * 8 * RPI) < mend) & ((unsigned)qih[i] < (unsigned)H) & ((unsigned)qiw[i] < (unsigned)W);
+            const unsigned off = (unsigned)__mul24(qpix[i], ldx2);
+            const unsigned long a = qbase + (unsigned long)off;
+            const unsigned long src = ok ? a : zaddr;
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + IMG + (i * 8 + wave) * 1024)));
+            qiw[i] += sdr;
+            const bool c1 = qiw[i] >= thrW;
+            qiw[i] -= c1 ? OWs : 0;
+            qih[i] += sdq + (c1 ? stride : 0);
+            const bool c2 = qih[i] >= thrH;
+            qih[i] -= c2 ? OHs : 0;
+            qpix[i] += dpix + (c1 ? cW : 0) + (c2 ? cH : 0);
+        };
+        auto issue = [&](int slot, int mcur) { issueP(0, slot, mcur); issueP(1, slot, mcur); issueQ(0, slot, mcur); issueQ(1, slot, mcur); };
+
+        float* const dbias = Pk.dbias;
+        const bool do_bias = (dbias != nullptr) && (kt == 0);
+        float bsum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+        issue(0, mbeg);
+        if (nsteps > 1) issue(1, mbeg + MT);
+        if (nsteps > 2) issue(2, mbeg + 2 * MT);
+        if (nsteps > 2) wg_wait_vmcnt<2 * LPT>(); else if (nsteps > 1) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        wg_u32x2_t afX[4][2], bfX[2][2], afY[4][2], bfY[2][2];
+        {
+            unsigned aa[4], ba[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aa[i] = abase[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ba[j] = bbase[j];
+            wg9_load_half<0>(aa, ba, afX, bfX);
+            wg9_wait_frags(afX, bfX);
+        }
+#define WG9_MMA(AF, BF, i, j)                                                                                                              \
+    WgMma32<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[i][j])
+#define WG9_TR(F, i, HS, ad) { F[i][0] = wg_tr<HS * 8192>(ad); F[i][1] = wg_tr<HS * 8192 + 2048>(ad); }
+#define WG9_SB __builtin_amdgcn_sched_barrier(0)
+        WG9X_STAMP(1)
+        WG9X_STAMP_CLK(4)
+        for (int it = 0; it < nsteps; ++it) {
+            const int rem = nsteps - 1 - it;
+            const bool more = rem >= 3;
+            const int s3 = (it + 3) & (SLOTS - 1), m3 = mbeg + (it + 3) * MT;
+            const unsigned so = (unsigned)((it & (SLOTS - 1)) * SBYTES);
+            const unsigned sn = (unsigned)(((it + 1) & (SLOTS - 1)) * SBYTES);
+            if (do_bias) {
+                const unsigned char* sP = smem + so;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const uint4 v = *(const uint4*)(sP + (brow + jj * 16) * RB + bpos * 16);
+                    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bsum[2 * e] += WgMma<F16>::cvt((unsigned short)(w4[e] & 0xffffu));
+                        bsum[2 * e + 1] += WgMma<F16>::cvt((unsigned short)(w4[e] >> 16));
+                    }
+                }
+            }
+            WG9_SB;
+            WG9_MMA(afX, bfX, 0, 0); WG9_TR(afY, 0, 1, abase[0] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 1, 0); WG9_TR(afY, 1, 1, abase[1] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 2, 0); WG9_TR(afY, 2, 1, abase[2] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 3, 0); WG9_TR(afY, 3, 1, abase[3] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 0, 1); WG9_TR(bfY, 0, 1, bbase[0] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 1, 1); WG9_TR(bfY, 1, 1, bbase[1] + so); WG9_SB;
+            WG9_MMA(afX, bfX, 2, 1); if (more) issueP(0, s3, m3); WG9_SB;
+            WG9_MMA(afX, bfX, 3, 1); if (more) issueP(1, s3, m3); WG9_SB;
+            if (rem >= 3) wg_wait_vmcnt<LPT + 2>(); else if (rem == 2) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+            wg9_wait_frags(afY, bfY);
+            __builtin_amdgcn_s_barrier();
+            WG9_SB;
+            WG9_MMA(afY, bfY, 0, 0); WG9_TR(afX, 0, 0, abase[0] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 1, 0); WG9_TR(afX, 1, 0, abase[1] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 2, 0); WG9_TR(afX, 2, 0, abase[2] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 3, 0); WG9_TR(afX, 3, 0, abase[3] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 0, 1); WG9_TR(bfX, 0, 0, bbase[0] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 1, 1); WG9_TR(bfX, 1, 0, bbase[1] + sn); WG9_SB;
+            WG9_MMA(afY, bfY, 2, 1); if (more) issueQ(0, s3, m3); WG9_SB;
+            WG9_MMA(afY, bfY, 3, 1); if (more) issueQ(1, s3, m3); WG9_SB;
+            wg9_wait_frags(afX, bfX);
+            WG9_SB;
+        }
+#undef WG9_MMA
+#undef WG9_TR
+#undef WG9_SB
+        WG9X_STAMP(2)
+        WG9X_STAMP_CLK(5)
+
+        float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
+        if (do_bias) {
+            __syncthreads();
+            float* const bred = (float*)smem;                  // [512 / LPR][BN]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bred[brow * BN + bchunk * 8 + e] = bsum[e];
+            __syncthreads();
+            if (t < BN) {
+                float v = 0.f;
+                for (int rg = 0; rg < 512 / LPR; ++rg) v += bred[rg * BN + t];
+                sBias[t] = v;
+            }
+            if (t < BN && n0 + t < Ng) {
+                if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
+                else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+            }
+        }
+        if (part) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                if (k >= Kpad) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        if (n < Ng) part[(long)(g * Ng + n) * Kpad + k] = acc[i][j][e];
+                    }
+                }
+            }
+        } else {
+            float* const dw = Pk.dw;
+            const long s_o = Pk.s_o, s_i = Pk.s_i, s_h = Pk.s_h, s_w = Pk.s_w;
+            const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + wk * 64 + j * 32 + lc;
+                if (k >= Kpad) continue;
+                const int tap = k / Cg, ci = k - tap * Cg;
+                if (ci >= CgReal) continue;
+                const int kh = tap / KW, kw = tap - kh * KW;
+                const long koff = (long)ci * s_i + (long)kh * s_h + (long)kw * s_w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        if (n < Ng) atomicAdd(dw + (long)(g * Ng + n) * s_o + koff, acc[i][j][e]);
+                    }
+                }
+            }
+        }
+#ifdef OCTA_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG9X_STAMP(3)
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && tl_item < WG9X_MAXIT) octa_diag_timeline_wg9x[blockIdx.x][0] = tl_item + 1;
+        ++tl_item;
+#endif
+        if (!PERSIST) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        __syncthreads();            // every wave is done with the ring (fragments, bias scratch) before the next block's DMA lands in it
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static unsigned wg_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 static int g_wg8_fold = 0;            // octa_tuning_set(4, 0 / 1)
@@ -842,11 +1165,186 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
     return OCTA_OK;
 }
 
+// ---- wgrad9x: per-class splits, XCD-interleaved sequences, optionally persistent (kernel comment above)
+static int g_wg9_sched = 0;             // octa_tuning_set(8, mode): 0 = wgrad9 (rounds of one split length), 1 = wgrad9x one block per workgroup, 2 = wgrad9x persistent
+static int wg9_sched_mode() {
+    static const int env = getenv("OCTA_WG9_SCHED") ? atoi(getenv("OCTA_WG9_SCHED")) : -1;
+    return env >= 0 ? env : g_wg9_sched;
+}
+static int wg_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// Stage-units until the last XCD is done.  Every XCD runs its own sequence (problem p contributes the x-th eighth of its nb[p] blocks
+// of len[p] stages, + E for prologue and epilogue) on SL slots: dealt statically (persistent) or to the slot that frees first.
+static int64_t wg9x_model(const std::vector<int64_t>& nb, const std::vector<int64_t>& len, const int* off, int SL, bool persist, int E) {
+    int64_t worst = 0;
+    std::vector<int64_t> seq, slot((size_t)SL);
+    for (int x = 0; x < 8; ++x) {
+        seq.clear();
+        for (size_t p = 0; p < nb.size(); ++p) {
+            const int64_t cnt = ((nb[p] * (x + 1)) >> 3) - ((nb[p] * x) >> 3);
+            seq.insert(seq.end(), (size_t)cnt, len[p] + E);
+        }
+        if (seq.empty()) continue;
+        if (off && off[x] > 0 && off[x] < (int)seq.size()) std::rotate(seq.begin(), seq.begin() + off[x], seq.end());
+        std::fill(slot.begin(), slot.end(), 0);
+        if (persist) {
+            for (size_t i = 0; i < seq.size(); ++i) slot[i % SL] += seq[i];
+        } else {
+            // list scheduling; the heap is the SL finish times
+            std::make_heap(slot.begin(), slot.end(), std::greater<int64_t>());
+            for (size_t i = 0; i < seq.size(); ++i) {
+                std::pop_heap(slot.begin(), slot.end(), std::greater<int64_t>());
+                slot.back() += seq[i];
+                std::push_heap(slot.begin(), slot.end(), std::greater<int64_t>());
+            }
+        }
+        worst = std::max(worst, *std::max_element(slot.begin(), slot.end()));
+    }
+    return worst;
+}
+static void wg9x_offsets(const std::vector<int64_t>& nb, int SL, int rot, int* len8, int* off8) {
+    for (int x = 0; x < 8; ++x) {
+        int64_t L = 0;
+        for (size_t p = 0; p < nb.size(); ++p) L += ((nb[p] * (x + 1)) >> 3) - ((nb[p] * x) >> 3);
+        len8[x] = (int)L;
+        const int64_t rounds = (L + SL - 1) / SL;
+        off8[x] = rot ? (int)(((rounds * x) / 8) * SL) : 0;     // XCD x starts x/8 of the way into its rounds
+        if (off8[x] >= len8[x]) off8[x] = 0;
+    }
+}
+
+template <int F16>
+static int wg9x_launch(std::vector<WgPlan>& plans, hipStream_t st, int mode) {
+    static const int E = getenv("OCTA_WG9X_EPI") ? atoi(getenv("OCTA_WG9X_EPI")) : 16;
+    static const int minlen = getenv("OCTA_WG9X_MINLEN") ? atoi(getenv("OCTA_WG9X_MINLEN")) : 24;
+    static const int rot = getenv("OCTA_WG9X_ROT") ? atoi(getenv("OCTA_WG9X_ROT")) : 1;
+    static const bool logit = getenv("OCTA_WG_LOG") != nullptr;
+    const bool persist = mode == 2;
+    const int SLmax = std::max(1, wg_num_cus() / 8);
+    size_t i0 = 0;
+    while (i0 < plans.size()) {
+        const size_t i1 = std::min(plans.size(), i0 + (size_t)WG_MAXP);
+        const size_t n = i1 - i0;
+        // long pixel axes first; problems with the same number of stages form a class and share a split
+        std::stable_sort(plans.begin() + i0, plans.begin() + i1, [](const WgPlan& a, const WgPlan& b) { return a.steps > b.steps; });
+        std::vector<int> cls(n), cfirst;
+        for (size_t i = 0; i < n; ++i) {
+            if (i == 0 || plans[i0 + i].steps != plans[i0 + i - 1].steps) cfirst.push_back((int)i);
+            cls[i] = (int)cfirst.size() - 1;
+        }
+        const int nc = (int)cfirst.size();
+        std::vector<int64_t> tiles(n), nb(n), len(n);
+        for (size_t i = 0; i < n; ++i) tiles[i] = (int64_t)plans[i0 + i].p.tilesN * plans[i0 + i].p.tilesK * plans[i0 + i].p.groups;
+        std::vector<int> split((size_t)nc, 1);
+        int len8[8], off8[8];
+        auto cost = [&]() {
+            for (size_t i = 0; i < n; ++i) {
+                const int64_t sp = split[cls[i]], steps = plans[i0 + i].steps;
+                const int64_t sps = (steps + sp - 1) / sp;
+                nb[i] = tiles[i] * ((steps + sps - 1) / sps);
+                len[i] = sps;
+            }
+            wg9x_offsets(nb, SLmax, rot, len8, off8);
+            return wg9x_model(nb, len, off8, SLmax, persist, E);
+        };
+        // the search is remembered per batch signature (a training step asks for the same few batches every time)
+        static std::mutex memo_mu;
+        static std::map<std::vector<int64_t>, std::vector<int>> memo;
+        std::vector<int64_t> key{(int64_t)persist, (int64_t)SLmax, (int64_t)E, (int64_t)minlen, (int64_t)rot, (int64_t)octa_deterministic()};
+        for (size_t i = 0; i < n; ++i) { key.push_back(tiles[i]); key.push_back(plans[i0 + i].steps); }
+        bool known = false;
+        {
+            std::lock_guard<std::mutex> lk(memo_mu);
+            auto it = memo.find(key);
+            if (it != memo.end()) { split = it->second; known = true; }
+        }
+        if (!known && !octa_deterministic()) {          // (deterministic mode: no M-split, one block per output tile)
+            // start from the best common target length (every class split to at most that many stages), then move one class at a time
+            int64_t best = cost();
+            std::vector<int> bsplit = split;
+            std::vector<int64_t> targets;
+            for (int c = 0; c < nc; ++c) {
+                const int64_t steps = plans[i0 + cfirst[c]].steps;
+                for (int64_t k = 1; k <= 64 && steps / k >= minlen; ++k) targets.push_back((steps + k - 1) / k);
+            }
+            std::sort(targets.begin(), targets.end());
+            targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+            for (int64_t Lt : targets) {
+                for (int c = 0; c < nc; ++c) {
+                    const int64_t steps = plans[i0 + cfirst[c]].steps;
+                    split[c] = (int)std::max<int64_t>(1, std::min<int64_t>((steps + Lt - 1) / Lt, std::max<int64_t>(1, std::min<int64_t>(64, steps / minlen))));
+                }
+                const int64_t v = cost();
+                if (v < best) { best = v; bsplit = split; }
+            }
+            split = bsplit;
+            for (int pass = 0; pass < 3; ++pass) {
+                bool moved = false;
+                for (int c = 0; c < nc; ++c) {
+                    const int64_t steps = plans[i0 + cfirst[c]].steps;
+                    const int smax = (int)std::max<int64_t>(1, std::min<int64_t>(64, steps / minlen));
+                    int bs = split[c];
+                    for (int sp = 1; sp <= smax; ++sp) {
+                        split[c] = sp;
+                        const int64_t v = cost();
+                        if (v < best) { best = v; bs = sp; moved = true; }
+                    }
+                    split[c] = bs;
+                }
+                if (!moved) break;
+            }
+        }
+        if (!known) { std::lock_guard<std::mutex> lk(memo_mu); memo[key] = split; }
+        (void)cost();                          // nb / len / len8 / off8 of the chosen splits
+        WgBatch batch;
+        WgSched sched;
+        batch.n = (int)n;
+        int maxlen = 0;
+        for (int x = 0; x < 8; ++x) { sched.len[x] = len8[x]; sched.off[x] = off8[x]; maxlen = std::max(maxlen, len8[x]); }
+        for (size_t i = 0; i < n; ++i) {
+            WgProb& p = plans[i0 + i].p;
+            p.mPerSplit = (int)(len[i] * 32);
+            p.splitM = (int)((p.M + p.mPerSplit - 1) / p.mPerSplit);
+            p.nblocks = (int)nb[i];
+            if ((int64_t)p.tilesN * p.tilesK * p.groups * p.splitM != nb[i]) OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_conv2d_wgrad_batch: internal: block count of problem %d", (int)i);
+            wg_take_fold(p, st);
+            p.blockStart = 0;
+            batch.p[i] = p;
+        }
+        if (maxlen <= 0 || maxlen >= (1 << 27)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_conv2d_wgrad_batch: bad grid %d", maxlen);
+        const int SL = persist ? std::min(SLmax, maxlen) : maxlen;
+        if (persist && SL < SLmax) {           // fewer blocks than slots: the start positions were computed for SLmax slots
+            std::vector<int64_t> nbv(nb.begin(), nb.end());
+            wg9x_offsets(nbv, SL, rot, sched.len, sched.off);
+        }
+        if (logit) {
+            fprintf(stderr, "wg9x launch mode %d slots %d model %lld :", mode, SL, (long long)wg9x_model(nb, len, sched.off, persist ? SL : SLmax, persist, E));
+            for (size_t i = 0; i < n; ++i) fprintf(stderr, " [tiles %lld steps %lld split %d len %lld]", (long long)tiles[i], (long long)plans[i0 + i].steps, batch.p[i].splitM, (long long)len[i]);
+            fprintf(stderr, "\n");
+        }
+        if (persist) wgrad9x_kernel<F16, 1><<<(unsigned)(8 * SL), 512, 0, st>>>(batch, sched);
+        else wgrad9x_kernel<F16, 0><<<(unsigned)(8 * SL), 512, 0, st>>>(batch, sched);
+        OCTA_CHECK_LAUNCH("wgrad9x");
+        octa_note_conv_kernel(persist ? (F16 ? "wgrad9x_kernel<f16,256x256,persistent>" : "wgrad9x_kernel<bf16,256x256,persistent>")
+                                      : (F16 ? "wgrad9x_kernel<f16,256x256>" : "wgrad9x_kernel<bf16,256x256>"));
+        i0 = i1;
+    }
+    return OCTA_OK;
+}
+
 static int g_wgrad_families = 3;     // bit 0: 256x128 / 128x256 tiles (wgrad8), bit 1: 256x256 tiles (wgrad9); octa_tuning_set(1, mask)
 void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
 void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 8) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 8 = wgrad9 schedule: 0 rounds of one split length, 1 per-class splits + XCD-interleaved sequences, 2 the same, persistent"); g_wg9_sched = value; return OCTA_OK; }
     if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }
     if (key == 6) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 6 = halo8 patch image: 1 packed (bank-conflict-free), 0 linear"); octa_set_halo8_packed(value); return OCTA_OK; }
     if (key == 5) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 5 = deterministic mode (0 / 1)"); octa_set_deterministic(value); return OCTA_OK; }
@@ -916,7 +1414,8 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, float*
         if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
         if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }
     }
-    if (!plans[0][2].empty()) { const int rc = wg9_launch<0>(plans[0][2], st); if (rc) return rc; }
-    if (!plans[1][2].empty()) { const int rc = wg9_launch<1>(plans[1][2], st); if (rc) return rc; }
+    const int sched_mode = wg9_sched_mode();
+    if (!plans[0][2].empty()) { const int rc = sched_mode ? wg9x_launch<0>(plans[0][2], st, sched_mode) : wg9_launch<0>(plans[0][2], st); if (rc) return rc; }
+    if (!plans[1][2].empty()) { const int rc = sched_mode ? wg9x_launch<1>(plans[1][2], st, sched_mode) : wg9_launch<1>(plans[1][2], st); if (rc) return rc; }
     return fold.close();          // ONE fold launch (per 16 jobs) behind every kernel of the batch that stored partial tiles
 }

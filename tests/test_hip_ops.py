@@ -1102,14 +1102,16 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
     check("res upshuffle", y, ref, t["rtol"], t["atol"] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("sched", [0, 1, 2])
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_wgrad_batch_vs_torch(dev, dtype, fold):
+def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
     """octa_conv2d_wgrad_batch: a mixed queue (both slab orientations of wgrad8, the 256 x 256 tiles of wgrad9, grouped convs,
     strided ones, a small-N job that falls through to the single-problem kernel, fused bias gradients) in ONE call against
     torch's CPU gradients.  fold: with the fold scratch registered the M-split jobs of every kernel family store
     partial tiles and the batch ends in fold launches (two of them: more than 16 jobs would need a third); the gradients must
-    also be bit-identical between two runs."""
+    also be bit-identical between two runs.  sched: the schedule of the 256 x 256 kernel (octa_tuning_set(8, .)): 0 = rounds of one
+    split length (wgrad9), 1 = per-class splits on XCD-interleaved sequences (wgrad9x), 2 = the same, persistent."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import WgradJob, lib
@@ -1149,8 +1151,11 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold):
     F_.set_wgrad_fold_workspace(ws)
     if fold:
         L.octa_tuning_set(4, 1)       # the batched kernels too (off by default: no gain in situ)
+    L.octa_tuning_set(8, sched)
     try:
         L.octa_conv2d_wgrad_batch(jobs, len(cases), *F_._fold_ws_args(), torch.cuda.current_stream().cuda_stream)
+        if sched and not fold:
+            assert "wgrad9x" in L.octa_last_conv_kernel().decode() and ("persistent" in L.octa_last_conv_kernel().decode()) == (sched == 2)
         first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in keep]
         if fold:
             for _, _, dw, db in keep:
@@ -1161,6 +1166,7 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold):
     finally:
         F_.set_wgrad_fold_workspace(None)
         L.octa_tuning_set(4, 0)
+        L.octa_tuning_set(8, 0)
     split_jobs = 0
     for j, ((xd, dyd, dw, db), (gw, gb)) in enumerate(zip(keep, want)):
         check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))

@@ -1,7 +1,7 @@
 """Same-process A/B of library tuning switches (octa_tuning_set) or environment-read host switches on the replayed B = 16, 400 x 400
 adversarial step: per round and configuration a fresh TrainStep is captured (the switches are read when a launch is RECORDED) and 30
 replays are timed; configurations alternate, the kernel choices are tuned once and shared.
-usage (GPU box): python tools/ab_tuning.py "7=0" "7=1" [rounds]        (KEY=VALUE[,KEY=VALUE...] per configuration; "" = defaults)"""
+usage (GPU box): python tools/ab_tuning.py "7=0" "7=1" ["7=1,6=0" ...] [rounds]        (KEY=VALUE[,KEY=VALUE...] per configuration; "" = defaults)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,9 +11,9 @@ from octave_amd import functional as F_
 from octave_amd._lib import lib
 from octave_amd.train import TrainStep, mask_pyramid
 
-DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 0}
-cfgs = [sys.argv[1], sys.argv[2]]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0}
+cfgs = [a for a in sys.argv[1:] if not a.isdigit()]
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 dev = torch.device("cuda", 0)
 B, H = 16, 400
 torch.manual_seed(0)
