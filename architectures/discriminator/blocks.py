@@ -38,12 +38,12 @@ class SpectralConv2d(Conv2d):
         self.register_buffer('weight_v', v)
         self.sn_eps = eps
 
-    def forward(self, x, w=None):
+    def forward(self, x, w=None, gate_out=None, gate_in=None):
         """`w`: the normalised weight when the caller ran this layer's power iteration together with other layers'
-        (functional.spectral_norm_batch); None: run it here."""
+        (functional.spectral_norm_batch); None: run it here.  gate_out / gate_in: functional.ActGate."""
         if w is None:
             w = F_.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, self.sn_eps)
-        return F_.conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.groups, self.act)
+        return F_.conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.groups, self.act, None, None, gate_out, gate_in)
 
 
 class InstanceNoise(nn.Module):
@@ -165,28 +165,37 @@ class DiscriminatorBlock(nn.Module):
     def forward(self, y: Sequence[Tensor]):
         dtype = self.compute_dtype or torch.float32
         feed = self.rng_feed
+        # every activation of the chain has exactly one consumer: that consumer's data gradient applies the activation's derivative
+        # in its own epilogue (functional.ActGate) and the 9 derivative launches of a backward pass disappear
+        gated = F_.act_gates_enabled() and torch.is_grad_enabled()
+        g_prev = F_.ActGate() if gated else None
+        a_prev = ACT_LEAKY02
         if self._has_noise:
             self.stack_0[0].compute_dtype = dtype
             s = self.stack_0[0](y[0], feed.next_noise(), True) if feed is not None else self.stack_0[0](y[0])
-            s = self.stack_0[1](s)
+            s = self.stack_0[1](s, gate_out=g_prev)
         else:
-            s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype))
+            s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype), gate_out=g_prev)
         # the spectral-norm convs' power iterations (independent of each other and of the activations): one batched call
         sn = [self.spectral_dict[f'spectral_{i}'][0] for i in range(self.depth)]
         wn = F_.spectral_norm_batch([(m.weight_orig, m.weight_u, m.weight_v) for m in sn], sn[0].training, sn[0].sn_eps, dtype) \
             if (_SN_BATCH and 1 <= self.depth <= 8 and all(m.training == sn[0].training and m.sn_eps == sn[0].sn_eps for m in sn)) else [None] * self.depth
         for i in range(self.depth):
             try:
-                s = self.squeeze_dict[f'squeeze_{i}'][0](s)
+                g_sq = F_.ActGate() if gated else None
+                sq = self.squeeze_dict[f'squeeze_{i}'][0]
+                s = sq(s, gate_out=g_sq, gate_in=(g_prev, a_prev, 0))
                 s = F_.DiscCatFn.apply(s, y[i + 1], True)      # the map goes into the squeeze output's pad channels
-                s = sn[i](s, wn[i])
+                g_prev, a_prev = (F_.ActGate() if gated else None), ACT_TANH
+                s = sn[i](s, wn[i], gate_out=g_prev, gate_in=(g_sq, ACT_SIGMOID, sq.out_channels))
             except Exception as e:
                 raise Exception(f'Exception raised in depth = {i}') from e
         fc = self.out[0]
+        g_last = (g_prev, a_prev) if self.depth > 0 else (g_prev, ACT_LEAKY02)
         if self._has_label_noise and feed is not None:
-            return F_.FullConvFn.apply(s, fc.weight, fc.bias, 1.0, feed.next_sign())
+            return F_.FullConvFn.apply(s, fc.weight, fc.bias, 1.0, feed.next_sign(), g_last)
         sign = self.out[2].draw_sign() if self._has_label_noise else 1.0
-        return F_.FullConvFn.apply(s, fc.weight, fc.bias, sign)
+        return F_.FullConvFn.apply(s, fc.weight, fc.bias, sign, None, g_last)
 
     def predict(self, y: List[Tensor]):
         return self.forward(y)

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 311
+#define OCTA_HIP_ABI_VERSION 312
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -140,6 +140,12 @@ int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* w_pac
  * separate 3-pass add kernel.  Runs on the generic and LDS-DMA kernels (not the 3x3 halo / resident-weight ones). */
 int octa_conv2d_dgrad_add(const octa_conv_desc* d, const void* dy, const void* w_packed_t,
                           const void* addend, int ldadd, void* dx, octa_stream_t stream);
+/* Data gradient of a conv whose INPUT was the output of a fused activation (the discriminator's LeakyReLU / sigmoid / tanh layers,
+ * reference architectures/discriminator/blocks.py:46-51, 91-110): dx = conv^T(dy) * f'(gate), gate = that activation's output (the
+ * tensor the conv read in forward, NHWC, ldgate elements per pixel, same dtype), gate_act an octa_act code.  The producing layer's
+ * backward then skips its derivative kernel (octa_act_bwd).  Runs on the generic 4-wave kernel (d->algo 4 / 5 / 6, else by size). */
+int octa_conv2d_dgrad_gated(const octa_conv_desc* d, const void* dy, const void* w_packed_t,
+                            const void* gate, int ldgate, int gate_act, void* dx, octa_stream_t stream);
 /* Strided data gradient as GEMM + col2im: Z[(b,oh,ow)][(ci*KH+kh)*KW+kw] = dy x W^T comes from
  * octa_conv2d_fwd (1x1, operand = the data-grad packed weight); this folds the overlapping taps:
  * dx[b,ih,iw,ci] = sum_{kh,kw : ih+pad-kh = stride*oh, ...} Z[...].  (discriminator/blocks.py:46,97)
@@ -155,6 +161,12 @@ int octa_pack_weight_dgrad_taps(const float* w, int64_t s_o, int64_t s_i, int64_
                                 int cout_pad, int dtype, octa_stream_t stream);
 int octa_col2im_taps(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW,
                      int cin_pad, int KH, int KW, int stride, int pad, int dtype, octa_stream_t stream);
+/* The same fold with the activation derivative of channels [0, gate_channels): dx[.., c] *= f'(gate[.., c]) (gate: the conv's own
+ * input, whose first gate_channels channels are an activation's output -- the squeeze conv's sigmoid under torch.cat, reference
+ * architectures/discriminator/blocks.py:91-95, 124). */
+int octa_col2im_taps_gated(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW,
+                           int cin_pad, int KH, int KW, int stride, int pad, int dtype, const void* gate, int ldgate,
+                           int gate_act, int gate_channels, octa_stream_t stream);
 /* dw[o,i,kh,kw] += sum_pixels dy * x   (fp32 gradient of the OIHW-logical parameter, addressed
  * through its element strides so OIHW-dense and channels-last storage both work; accumulated
  * with atomics, so the caller zeroes it once per step). */
@@ -501,6 +513,10 @@ int octa_fullconv_fwd(const void* x, const float* w, const float* bias, float* o
 int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw,
                       float* dbias, int B, int64_t n, int dtype, float sign, const float* sign_dev,
                       int dw_c, octa_stream_t stream);
+/* ... with dx multiplied by f'(x): x is the output of activation gate_act (the last tanh) and dx the gradient that reaches it. */
+int octa_fullconv_bwd_gated(const void* x, const float* w, const float* dout, void* dx, float* dw,
+                            float* dbias, int B, int64_t n, int dtype, float sign, const float* sign_dev,
+                            int dw_c, int gate_act, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: fused Adam over a flat fp32 parameter arena (train step a17).

@@ -32,6 +32,11 @@ struct ConvArgs {
     int vec_store;
     const void* addend;   // optional (data gradient): tensor of the OUTPUT's shape added in the epilogue (fan-out gradient sum)
     int ldadd;
+    // optional (data gradient, generic 4-wave kernel only): the result is the gradient that reaches an ACTIVATION's output; gate is that
+    // output (the tensor this conv read in forward, OUTPUT-shaped here) and the epilogue multiplies by f'(gate) -- the derivative
+    // kernel of the producing layer's backward disappears (octa_conv2d_dgrad_gated)
+    const void* gate;
+    int ldgate, gate_act;
     int vec16;            // 16-byte output stores are aligned: ldy, yoff (and the upshuffle channel count) are multiples of 8
     int NgSt;             // channels stored per group: Ng, or round8(Ng) when the pad channels are zero-filled here
     // BatchNorm statistics of the output, taken in the epilogue (octa_conv2d_fwd_stats; kernels that support it only):
@@ -147,6 +152,61 @@ __device__ __forceinline__ void addend_tile(V4 (&acc)[TN][TM], const ConvArgs& a
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (nb + e < a.Ng) acc[i][j][e] += DT<T>::ld(ad + (size_t)m * a.ldadd + cbase + nb + e);
+        }
+    }
+}
+
+// f'(y) of the fused activations, from the activation's OUTPUT (what octa_act_bwd multiplies by)
+__device__ __forceinline__ float act_gate(int act, float y) {
+    switch (act) {
+        case OCTA_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case OCTA_ACT_LEAKY02: return y > 0.f ? 1.f : 0.2f;
+        case OCTA_ACT_SIGMOID: return y * (1.f - y);
+        case OCTA_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+// Epilogue pre-pass of the gated data gradient: acc *= f'(gate[pixel][channel]) (after the addend: both are gradients of the same tensor)
+template <typename T, typename V4, int TN, int TM>
+__device__ __forceinline__ void gate_tile(V4 (&acc)[TN][TM], const ConvArgs& a, int mrow0, int ncol0, int g) {
+    if (!a.gate) return;
+    const T* __restrict__ gt = (const T*)a.gate;
+    const int cbase = g * a.Ng;
+    const bool vec = sizeof(T) == 2 && (a.ldgate & 3) == 0 && (cbase & 3) == 0 && (a.Ng & 3) == 0;
+    if (vec) {
+        // all loads first (8 bytes = the lane's 4 channels of a fragment), one wait; out-of-range fragments read a clamped address
+        uint2 raw[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = min(mrow0 + j * 16, a.M - 1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int nb = ncol0 + i * 16;
+                raw[i][j] = *(const uint2*)(gt + (size_t)m * a.ldgate + cbase + (nb < a.Ng ? nb : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if (mrow0 + j * 16 >= a.M || ncol0 + i * 16 >= a.Ng) continue;
+                float f[8];
+                unpack16<T>(make_uint4(raw[i][j].x, raw[i][j].y, 0u, 0u), f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] *= act_gate(a.gate_act, f[e]);
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mrow0 + j * 16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = ncol0 + i * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nb + e < a.Ng) acc[i][j][e] *= act_gate(a.gate_act, DT<T>::ld(gt + (size_t)m * a.ldgate + cbase + nb + e));
         }
     }
 }
@@ -339,6 +399,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     T* __restrict__ yb = (T*)a.y + a.yoff;
     bias_act_tile(acc, a, n0 + wn * TN * 16 + q * 4, g);
     addend_tile<T>(acc, a, m0 + wm * TM * 16 + r, n0 + wn * TN * 16 + q * 4, g);
+    gate_tile<T>(acc, a, m0 + wm * TM * 16 + r, n0 + wn * TN * 16 + q * 4, g);
     if constexpr (sizeof(T) == 2) {
         if (a.stats) stats_tile<BN>(acc, a, n0 + wn * TN * 16 + q * 4, n0, m0 + wm * TM * 16 + r, g, (float*)&sA[0][0], blockIdx.x + blockIdx.y * gridDim.x);
     }
@@ -987,6 +1048,7 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
     a.act = d->act; a.mode = 0; a.upshuffle = d->upshuffle; a.CoutT = d->upshuffle ? d->Cout / 4 : 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->yoff % 4 == 0) && (d->ldy % 4 == 0) && (!d->upshuffle || a.CoutT % 4 == 0);
     a.addend = nullptr; a.ldadd = 0;
+    a.gate = nullptr; a.ldgate = 0; a.gate_act = 0;
     a.vec16 = (d->yoff % 8 == 0) && (d->ldy % 8 == 0) && (!d->upshuffle || a.CoutT % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = stats; a.stats_shift = shift; a.stats_rep = replicas; a.stats_ctot = d->Cout;
@@ -1004,7 +1066,8 @@ static int conv2d_fwd_impl(const octa_conv_desc* d, const void* x, const void* w
                                  : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo, fused);
 }
 
-static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, const void* addend, int ldadd, octa_stream_t stream) {
+static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, const void* addend, int ldadd, octa_stream_t stream,
+                             const void* gate = nullptr, int ldgate = 0, int gate_act = 0) {
     int rc = check_desc(d, "octa_conv2d_dgrad");
     if (rc) return rc;
     OCTA_REQUIRE(dy && wt && dx, "octa_conv2d_dgrad: null pointer");
@@ -1025,6 +1088,7 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
     a.act = 0; a.mode = 1; a.upshuffle = 0; a.CoutT = 0;
     a.vec_store = (a.Ng % 4 == 0) && (d->xoff % 4 == 0) && (d->ldx % 4 == 0);
     a.addend = addend; a.ldadd = ldadd;
+    a.gate = gate; a.ldgate = ldgate; a.gate_act = gate_act;
     a.vec16 = (d->xoff % 8 == 0) && (d->ldx % 8 == 0);
     a.NgSt = a.Ng;
     a.stats = nullptr; a.stats_shift = nullptr; a.stats_rep = 0; a.stats_ctot = 0;
@@ -1035,9 +1099,22 @@ static int conv2d_dgrad_impl(const octa_conv_desc* d, const void* dy, const void
         OCTA_REQUIRE(d->groups == 1 && d->xoff + (a.Ng + 7) / 8 * 8 <= d->ldx, "octa_conv2d_dgrad: zero_pad needs groups == 1 and xoff + round8(Cin) <= ldx");
         a.NgSt = (a.Ng + 7) / 8 * 8;
     }
+    if (gate) {
+        // only the generic 4-wave kernel's epilogue knows the gate: an explicit tile choice (algo 4 / 5 / 6) keeps the launch there
+        const int algo = (d->algo >= 4 && d->algo <= 6) ? d->algo : (a.Ng > 64 ? 5 : 6);
+        return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream, algo)
+             : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, algo)
+                                     : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, algo);
+    }
     return d->dtype == OCTA_F32 ? launch_igemm<float>(a, d->groups, (hipStream_t)stream)
          : d->dtype == OCTA_BF16 ? launch_igemm<bf16_t>(a, d->groups, (hipStream_t)stream, d->algo)
                                  : launch_igemm<f16_t>(a, d->groups, (hipStream_t)stream, d->algo);
+}
+extern "C" int octa_conv2d_dgrad_gated(const octa_conv_desc* d, const void* dy, const void* wt, const void* gate, int ldgate, int gate_act, void* dx,
+                                       octa_stream_t stream) {
+    OCTA_REQUIRE(gate != nullptr && ldgate > 0 && gate_act >= 0 && gate_act <= OCTA_ACT_TANH, "octa_conv2d_dgrad_gated: gate / ldgate / activation code");
+    OCTA_REQUIRE(d && d->Cin % d->groups == 0 && ldgate >= d->Cin, "octa_conv2d_dgrad_gated: ldgate %d < Cin", ldgate);
+    return conv2d_dgrad_impl(d, dy, wt, dx, nullptr, 0, stream, gate, ldgate, gate_act);
 }
 extern "C" int octa_conv2d_dgrad(const octa_conv_desc* d, const void* dy, const void* wt, void* dx, octa_stream_t stream) {
     return conv2d_dgrad_impl(d, dy, wt, dx, nullptr, 0, stream);
@@ -1084,7 +1161,8 @@ extern "C" int octa_pack_weight_dgrad_taps(const float* w, int64_t s_o, int64_t 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_taps_kernel(const T* __restrict__ z, int ldz, T* __restrict__ dx, int lddx, int B, int H, int W, int OH,
-                                                          int OW, int cin_pad, int KH, int KW, int stride, int pad) {
+                                                          int OW, int cin_pad, int KH, int KW, int stride, int pad,
+                                                          const T* __restrict__ gate, int ldgate, int gate_act, int gate_ch) {
     constexpr int EPC = DT<T>::EPC;
     const int cpc = cin_pad / EPC;                        // 16-byte chunks per pixel
     const int64_t total = (int64_t)B * H * W * cpc;
@@ -1113,11 +1191,30 @@ __global__ __launch_bounds__(256) void col2im_taps_kernel(const T* __restrict__ 
                 for (int e = 0; e < EPC; ++e) acc[e] += v[e];
             }
         }
+        if (gate && ck * EPC < gate_ch) {
+            // channels < gate_ch are the output of an activation (the squeeze conv's sigmoid): its derivative here, not in a kernel of its own
+            float gv[EPC];
+            unpack16<T>(*(const uint4*)(gate + ((int64_t)(b * H + ih) * W + iw) * ldgate + ck * EPC), gv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) if (ck * EPC + e < gate_ch) acc[e] *= act_gate(gate_act, gv[e]);
+        }
         *(uint4*)(dx + ((int64_t)(b * H + ih) * W + iw) * lddx + ck * EPC) = pack16<T>(acc);
     }
 }
+static int col2im_taps_impl(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int cin_pad, int KH, int KW,
+                            int stride, int pad, int dtype, const void* gate, int ldgate, int gate_act, int gate_ch, octa_stream_t stream);
 extern "C" int octa_col2im_taps(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int cin_pad, int KH, int KW,
                                 int stride, int pad, int dtype, octa_stream_t stream) {
+    return col2im_taps_impl(z, ldz, dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad, dtype, nullptr, 0, 0, 0, stream);
+}
+extern "C" int octa_col2im_taps_gated(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int cin_pad, int KH, int KW,
+                                      int stride, int pad, int dtype, const void* gate, int ldgate, int gate_act, int gate_channels, octa_stream_t stream) {
+    OCTA_REQUIRE(gate && ldgate >= cin_pad && ldgate % 8 == 0 && gate_act >= 0 && gate_act <= OCTA_ACT_TANH && gate_channels > 0 && gate_channels <= cin_pad,
+                 "octa_col2im_taps_gated: gate tensor (ldgate >= cin_pad, %% 8), activation code, 0 < gate_channels <= cin_pad");
+    return col2im_taps_impl(z, ldz, dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad, dtype, gate, ldgate, gate_act, gate_channels, stream);
+}
+static int col2im_taps_impl(const void* z, int ldz, void* dx, int lddx, int B, int H, int W, int OH, int OW, int cin_pad, int KH, int KW,
+                            int stride, int pad, int dtype, const void* gate, int ldgate, int gate_act, int gate_ch, octa_stream_t stream) {
     OCTA_REQUIRE(z && dx && B > 0 && stride > 0, "octa_col2im_taps: bad arguments");
     const int epc = dtype == OCTA_F32 ? 4 : 8;
     OCTA_REQUIRE(cin_pad > 0 && cin_pad % 8 == 0 && lddx >= cin_pad && lddx % epc == 0 && ldz % epc == 0 && ldz >= KH * KW * cin_pad,
@@ -1125,9 +1222,9 @@ extern "C" int octa_col2im_taps(const void* z, int ldz, void* dx, int lddx, int 
     const int64_t total = (int64_t)B * H * W * (cin_pad / epc);
     const int blocks = (int)(cdiv64(total, 256) > 131072 ? 131072 : cdiv64(total, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == OCTA_F32) col2im_taps_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
-    else if (dtype == OCTA_BF16) col2im_taps_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
-    else if (dtype == OCTA_F16) col2im_taps_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)z, ldz, (f16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad);
+    if (dtype == OCTA_F32) col2im_taps_kernel<float><<<blocks, 256, 0, st>>>((const float*)z, ldz, (float*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad, (const float*)gate, ldgate, gate_act, gate_ch);
+    else if (dtype == OCTA_BF16) col2im_taps_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)z, ldz, (bf16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad, (const bf16_t*)gate, ldgate, gate_act, gate_ch);
+    else if (dtype == OCTA_F16) col2im_taps_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)z, ldz, (f16_t*)dx, lddx, B, H, W, OH, OW, cin_pad, KH, KW, stride, pad, (const f16_t*)gate, ldgate, gate_act, gate_ch);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_col2im_taps: bad dtype");
     OCTA_CHECK_LAUNCH("col2im_taps");
     return OCTA_OK;

@@ -511,7 +511,7 @@ extern "C" int octa_fullconv_fwd(const void* x, const float* w, const float* bia
 template <typename T>
 __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dout,
                                                            T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int B, int64_t n,
-                                                           float sign, const float* __restrict__ sign_dev, int dw_c) {
+                                                           float sign, const float* __restrict__ sign_dev, int dw_c, int gate_act) {
     if (sign_dev) sign *= sign_dev[0];
     const int64_t hw = dw_c > 0 ? n / dw_c : 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -519,8 +519,15 @@ __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__
         float g = 0.f;
         for (int b = 0; b < B; ++b) {
             const float d = sign * dout[b];
-            if (dx) DT<T>::st(dx + b * n + i, d * wi);
-            g += d * DT<T>::ld(x + b * n + i);
+            const float xv = DT<T>::ld(x + b * n + i);
+            // gate_act: x is the output of that activation and dx the gradient that reaches it -- times f'(x) here (octa_fullconv_bwd_gated)
+            float gt = 1.f;
+            if (gate_act == OCTA_ACT_TANH) gt = 1.f - xv * xv;
+            else if (gate_act == OCTA_ACT_SIGMOID) gt = xv * (1.f - xv);
+            else if (gate_act == OCTA_ACT_LEAKY02) gt = xv > 0.f ? 1.f : 0.2f;
+            else if (gate_act == OCTA_ACT_RELU) gt = xv > 0.f ? 1.f : 0.f;
+            if (dx) DT<T>::st(dx + b * n + i, d * wi * gt);
+            g += d * xv;
         }
         if (dw) dw[dw_c > 0 ? (i % dw_c) * hw + i / dw_c : i] += g;      // dw_c: dw is [C][HW] (the parameter's own OIHW order)
     }
@@ -530,14 +537,21 @@ __global__ __launch_bounds__(256) void fullconv_bwd_kernel(const T* __restrict__
         dbias[0] += s;
     }
 }
+extern "C" int octa_fullconv_bwd_gated(const void* x, const float* w, const float* dout, void* dx, float* dw, float* dbias, int B, int64_t n,
+                                       int dtype, float sign, const float* sign_dev, int dw_c, int gate_act, octa_stream_t stream);
 extern "C" int octa_fullconv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw, float* dbias, int B, int64_t n,
                                  int dtype, float sign, const float* sign_dev, int dw_c, octa_stream_t stream) {
+    return octa_fullconv_bwd_gated(x, w, dout, dx, dw, dbias, B, n, dtype, sign, sign_dev, dw_c, 0, stream);
+}
+extern "C" int octa_fullconv_bwd_gated(const void* x, const float* w, const float* dout, void* dx, float* dw, float* dbias, int B, int64_t n,
+                                       int dtype, float sign, const float* sign_dev, int dw_c, int gate_act, octa_stream_t stream) {
     OCTA_REQUIRE(x && w && dout && B > 0 && n > 0 && dw_c >= 0 && (dw_c == 0 || n % dw_c == 0), "octa_fullconv_bwd: bad arguments");
+    OCTA_REQUIRE(gate_act >= 0 && gate_act <= OCTA_ACT_TANH, "octa_fullconv_bwd_gated: activation code");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)(cdiv64(n, 256) > 2048 ? 2048 : cdiv64(n, 256));
-    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
-    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
-    else if (dtype == OCTA_F16) fullconv_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, w, dout, (f16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c);
+    if (dtype == OCTA_F32) fullconv_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)x, w, dout, (float*)dx, dw, dbias, B, n, sign, sign_dev, dw_c, gate_act);
+    else if (dtype == OCTA_BF16) fullconv_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, w, dout, (bf16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c, gate_act);
+    else if (dtype == OCTA_F16) fullconv_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, w, dout, (f16_t*)dx, dw, dbias, B, n, sign, sign_dev, dw_c, gate_act);
     else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_fullconv_bwd: bad dtype");
     OCTA_CHECK_LAUNCH("fullconv_bwd");
     return OCTA_OK;

@@ -556,19 +556,21 @@ def _choose_algo(kind: str, d, launch) -> int:
         return 0
     cg = d.cin_g_pad if kind in ("fwd", "fwd_stats") else d.cout_g_pad
     cands = [1, 4, 5, 6]            # heuristic (incl. the 3x3 halo kernels), then the explicit 4-wave tiles
-    if cg % 64 == 0 and d.KH * d.KW <= 32 and (kind in ("fwd", "fwd_stats") or d.stride == 1):
+    if kind == "dgrad_gated":
+        cands = [4, 5, 6]           # (only the generic kernel's epilogue applies an activation gate)
+    elif cg % 64 == 0 and d.KH * d.KW <= 32 and (kind in ("fwd", "fwd_stats") or d.stride == 1):
         cands += [2, 3, 8]          # 8-wave LDS-DMA kernel, both slab orientations; its 4-wave 128x128 form
     if kind == "fwd_stats":
         pass                        # (the resident-weight, pointwise-GEMM and 2-D patch kernels cannot take the statistics along)
-    elif kind != "dgrad_add" and cg in (32, 64) and d.groups in (1, 2, 4, 8) and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
+    elif kind not in ("dgrad_add", "dgrad_gated") and cg in (32, 64) and d.groups in (1, 2, 4, 8) and d.stride == 1 and ((d.KH == 3 and d.pad == 1) or (d.KH == 1 and d.pad == 0)):
         cands += [7]                # resident-weight persistent kernel (ineligible shapes fall back to the heuristic)
-    if kind != "fwd_stats" and cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
+    if kind not in ("fwd_stats", "dgrad_gated") and cg % 64 == 0 and d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.groups == 1 and os.environ.get("OCTA_NO_PWGEMM") != "1":
         cands += [9, 10, 11]        # persistent pointwise GEMM (pwgemm.hpp): 256x128, 128x256, 128x128 tiles, cross-tile pipelined
-    if kind not in ("dgrad_add", "fwd_stats") and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
+    if kind not in ("dgrad_add", "fwd_stats", "dgrad_gated") and cg % 64 == 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and os.environ.get("OCTA_NO_HALO8") != "1":
         cands += [12]               # 8-wave 3x3 kernel, 2-D pixel patch per tile (halo8.hpp)
         if os.environ.get("OCTA_NO_HALO16") != "1":
             cands += [13, 14]       # ... on v_mfma_f32_16x16x32 (halo16.hpp) / with a persistent tile loop (halo16p.hpp)
-    best, best_t = 1, None
+    best, best_t = cands[0], None
     if len(cands) > 1:
         for c in cands:
             d.algo = c
@@ -620,10 +622,17 @@ def _launch_fwd(d, x, wp, bias, y, stats: Optional["ConvStats"] = None):
     L.octa_conv2d_fwd(ctypes.byref(d), px, pw, pb, py, st)
 
 
-def _launch_dgrad(d, dy, wt, dx, addend=None):
+def _launch_dgrad(d, dy, wt, dx, addend=None, gate=None):
     L, st = lib(), _st()
     pdy, pw, pdx = _p(dy), _p(wt), _p(dx)
     _set_conv_ws(d)
+    if gate is not None:
+        # dx = conv^T(dy) * f'(gate) in the generic kernel's epilogue (small layers: the library picks the tile by size)
+        gx, ldg, gact, _ = gate
+        pg = _p(gx)
+        d.algo = _choose_algo("dgrad_gated", d, lambda: L.octa_conv2d_dgrad_gated(ctypes.byref(d), pdy, pw, pg, ldg, gact, pdx, st))
+        L.octa_conv2d_dgrad_gated(ctypes.byref(d), pdy, pw, pg, ldg, gact, pdx, st)
+        return
     if addend is not None:
         # dx = conv^T(dy) + addend in the kernel's epilogue (the generic / LDS-DMA kernels; tuned as its own shape class)
         pa, lda = _p(addend), nhwc_ld(addend)
@@ -714,9 +723,19 @@ def raw_conv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad:
 _COL2IM_TAPS = os.environ.get("OCTA_NO_COL2IM_TAPS") is None
 
 
-def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int, addend: Optional[Tensor] = None) -> Tensor:
+def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int, addend: Optional[Tensor] = None, gate=None):
     """Data gradient of a conv.  `addend` (a tensor of x's shape) is summed into the result: in the kernel's epilogue on
-    the direct path, as a separate add on the GEMM + col2im / densified ones."""
+    the direct path, as a separate add on the GEMM + col2im / densified ones.
+    `gate` = (x, act, channels): x (the conv's saved input) is the output of activation `act` on its first `channels` channels
+    (0: all) and the caller wants dx * f'(x); the return value is then (dx, applied) -- applied False where the path that ran has no
+    gated epilogue and the caller must fall back to octa_act_bwd in the producer."""
+    if gate is not None:
+        dx, applied = _raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend, gate)
+        return dx, applied
+    return _raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend, None)[0]
+
+
+def _raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups: int, addend: Optional[Tensor], gate):
     B, Cin, H, W = xshape
     if addend is not None:
         if tuple(addend.shape) != tuple(xshape):
@@ -724,8 +743,9 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         direct = not (stride > 1 and groups == 1 and (Cin * w.shape[2] * w.shape[3]) % 8 == 0) and \
             not _densify(groups, Cin, w.shape[0], w.shape[2], w.shape[3], stride, pad, H, W, dy.dtype)
         if not direct:
-            return raw_conv_dgrad(dy, w, xshape, stride, pad, groups) + addend.to(dy.dtype)
+            return raw_conv_dgrad(dy, w, xshape, stride, pad, groups) + addend.to(dy.dtype), False
         addend = to_nhwc(addend, dtype=dy.dtype)
+        gate = None                       # (no epilogue takes both)
     Cout, Cin_g, KH, KW = w.shape
     OH, OW = dy.shape[2], dy.shape[3]
     need = round8(Cout // groups) if groups == 1 else Cout
@@ -744,7 +764,8 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         wt = _packed(w, "dgrad_dense", dy.dtype, groups, d.cout_g_pad)
         _launch_dgrad(d, dy, wt, dx)
         _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
-        return dx
+        return dx, False
+    gop = _gate_operand(gate, dy.dtype)
     d = _desc(B, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad, groups, nhwc_ld(dx), ldy, dy.dtype)
     if col2im and Cin <= 16 and _COL2IM_TAPS:
         # few input channels (the discriminator's 15-channel inputs): tap-major N axis, the fold moves 16-byte channel vectors
@@ -755,8 +776,13 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         dz = _desc(B, OH, OW, OH, OW, d.cout_g_pad, N, 1, 1, 1, 0, 1, ldy, N, dy.dtype)
         _launch_fwd(dz, dy, wt, None, z)
         _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
+        if gop is not None and gop[1] >= cp and gop[1] % 8 == 0:
+            gx, ldg, gact, gch = gop
+            lib().octa_col2im_taps_gated(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, cp, KH, KW, stride, pad, _dt(dy), _p(gx), ldg, gact,
+                                         gch if gch > 0 else Cin, _st())
+            return dx, True
         lib().octa_col2im_taps(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, cp, KH, KW, stride, pad, _dt(dy), _st())
-        return dx
+        return dx, False
     wt = _packed(w, "dgrad", dy.dtype, groups, d.cout_g_pad)
     d.zero_pad = int(zp)
     if col2im:
@@ -768,10 +794,13 @@ def raw_conv_dgrad(dy: Tensor, w: Tensor, xshape, stride: int, pad: int, groups:
         _launch_fwd(dz, dy, wt, None, z)
         _record("fwd", dz, (_p(dy), _p(wt), None, _p(z)), (dy, wt, z))
         lib().octa_col2im(_p(z), N, _p(dx), nhwc_ld(dx), B, H, W, OH, OW, Cin, KH, KW, stride, pad, _dt(dy), _st())
-        return dx
+        return dx, False
+    if gop is not None and addend is None and (gop[3] == 0 or gop[3] >= Cin) and gop[1] >= Cin:
+        _launch_dgrad(d, dy, wt, dx, None, gop)
+        return dx, True
     _launch_dgrad(d, dy, wt, dx, addend)
     _record("dgrad", d, (_p(dy), _p(wt), _p(dx)), (dy, wt, dx))
-    return dx
+    return dx, False
 
 
 # ----------------------------------------------------------------------------- deferred weight gradients
@@ -1042,6 +1071,35 @@ def _ret(p: Tensor, buf: Tensor) -> Optional[Tensor]:
 
 
 # ============================================================================= autograd Functions
+class ActGate:
+    """Shared by a conv with a fused activation (the producer) and the ONE op that consumes its output.  The consumer's backward
+    multiplies its data gradient by the activation's derivative in its own epilogue (octa_conv2d_dgrad_gated,
+    octa_col2im_taps_gated, octa_fullconv_bwd_gated: it holds the activation's output anyway, as its saved input) and sets
+    `done`; the producer's backward then skips its derivative kernel (octa_act_bwd).  Only valid when nothing else reads the
+    producer's output (the discriminator's chain, blocks.py): a gate is multiplicative, so EVERY contribution would have to be gated."""
+    __slots__ = ("done",)
+
+    def __init__(self):
+        self.done = False
+
+
+_ACT_GATES = os.environ.get("OCTA_NO_ACT_GATE") is None
+
+
+def act_gates_enabled() -> bool:
+    return _ACT_GATES
+
+
+def _gate_operand(gate, dy_dtype):
+    """(tensor, ld, act, channels) of a gate request if the consumer's saved input can serve as the gate as it is (NHWC, compute dtype)."""
+    if gate is None or not _ACT_GATES:
+        return None
+    gx, gact, gch = gate
+    if gx is None or gx.dtype != dy_dtype or gx.dim() != 4 or gx.stride(1) != 1:
+        return None
+    return gx, nhwc_ld(gx), int(gact), int(gch)
+
+
 class GradHolder:
     """Carries the gradient of one consumer of a tensor to the conv that consumes the same tensor, so that the conv's data
     gradient can add it in its epilogue (fan-out gradient sum without autograd's separate add kernel)."""
@@ -1083,10 +1141,12 @@ class Conv2dFn(Function):
     """nn.Conv2d (+ fused activation).  Weight OIHW-logical fp32 parameter, any strides."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, groups, act, holder=None, stats=None):
+    def forward(ctx, x, w, bias, stride, pad, groups, act, holder=None, stats=None, gate_out=None, gate_in=None):
         _require_gpu(x)
         y = raw_conv_fwd(x, w, bias, stride, pad, groups, act, stats=stats)
         ctx.holder = holder
+        ctx.gate_out = gate_out          # ActGate of THIS conv's fused activation (its consumer may apply the derivative)
+        ctx.gate_in = gate_in            # (ActGate, act, channels) of the activation that produced x: this conv's dgrad applies it
         ctx.side = _IN_SIDE              # a side-branch conv: its backward launches must not use the tail-split scratch either
         ctx.cfg = (stride, pad, groups, act, tuple(x.shape))
         ctx.has_bias = bias is not None
@@ -1102,19 +1162,28 @@ class Conv2dFn(Function):
         if ctx.w_pre is not None:
             w._octa_packed = ctx.w_pre
         stride, pad, groups, act, xshape = ctx.cfg
-        if act != ACT_NONE:
-            dy = raw_act_bwd(y, dy, act)
+        if act != ACT_NONE and not (ctx.gate_out is not None and ctx.gate_out.done):
+            dy = raw_act_bwd(y, dy, act)         # (gate done: the consumer's data gradient already carries f'(y))
         addend = None
         if ctx.holder is not None:
             ctx.holder.consumed = True
             addend, ctx.holder.grad = ctx.holder.grad, None
             if addend is not None and ctx.holder.event is not None:
                 torch.cuda.current_stream().wait_event(ctx.holder.event)      # parked on another stream (side branches)
-        if ctx.side:
-            with no_splitk():
-                dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
-        else:
-            dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend) if ctx.needs_input_grad[0] else None
+        gate = None
+        if ctx.gate_in is not None and ctx.gate_in[0] is not None and addend is None:
+            gate = (x, ctx.gate_in[1], ctx.gate_in[2])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.side:
+                with no_splitk():
+                    dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend)
+            elif gate is not None:
+                dx, applied = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, None, gate=gate)
+                if applied:
+                    ctx.gate_in[0].done = True
+            else:
+                dx = raw_conv_dgrad(dy, w, xshape, stride, pad, groups, addend)
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         b = ctx.bias_ref
@@ -1130,11 +1199,11 @@ class Conv2dFn(Function):
             raw_colsum(dy, db)
         if want_b:
             db = _ret(b, db)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE, grad_holder=None, stats=None):
-    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act, grad_holder, stats)
+def conv2d(x, w, bias=None, stride=1, pad=0, groups=1, act=ACT_NONE, grad_holder=None, stats=None, gate_out=None, gate_in=None):
+    return Conv2dFn.apply(x, w, bias, stride, pad, groups, act, grad_holder, stats, gate_out, gate_in)
 
 
 class ConvTranspose2x2Fn(Function):
@@ -1939,7 +2008,8 @@ class FullConvFn(Function):
     """Conv2d whose kernel covers the whole map (blocks.py:68-72) = one dot product per sample."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, sign, sign_dev=None):
+    def forward(ctx, x, w, bias, sign, sign_dev=None, gate_in=None):
+        ctx.gate_in = gate_in            # (ActGate, act) of the activation that produced x (the last tanh): applied in this op's backward
         x = dense_nhwc(x)
         B, C, H, W = x.shape
         if tuple(w.shape) != (1, C, H, W):
@@ -1962,14 +2032,18 @@ class FullConvFn(Function):
         dx = nhwc_empty(B, C, H, W, x.dtype, x.device)
         w, bias = ctx.refs
         sw, sb = _sink(w), _sink(bias)
+        gact = 0
+        if ctx.gate_in is not None and ctx.gate_in[0] is not None and _ACT_GATES:
+            gact = int(ctx.gate_in[1])
+            ctx.gate_in[0].done = True
         if sw is not None and sw.is_contiguous() and (not ctx.has_bias or sb is not None):
             # gradient sinks: += straight into the (1, C, H, W) parameter gradient and the bias gradient
-            lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(sw), _p(sb), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, _st())
-            return dx, None, None, None, None
+            lib().octa_fullconv_bwd_gated(_p(x), _p(wp), _p(dout), _p(dx), _p(sw), _p(sb), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, gact, _st())
+            return dx, None, None, None, None, None
         dw = torch.zeros((1, C, H, W), dtype=torch.float32, device=x.device)
         db = torch.zeros((1,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        lib().octa_fullconv_bwd(_p(x), _p(wp), _p(dout), _p(dx), _p(dw), _p(db), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, _st())
-        return dx, dw, db, None, None
+        lib().octa_fullconv_bwd_gated(_p(x), _p(wp), _p(dout), _p(dx), _p(dw), _p(db), B, H * W * C, _dt(x), ctx.sign, _p(sign_dev), C, gact, _st())
+        return dx, dw, db, None, None, None
 
 
 # ----------------------------------------------------------------------------- the rest of the public surface

@@ -49,8 +49,8 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("octave_amd.Conv2d: dilation 1 and zero padding only")
         self.act = act
 
-    def forward(self, x, grad_holder=None, stats=None):
-        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act, grad_holder, stats)
+    def forward(self, x, grad_holder=None, stats=None, gate_out=None, gate_in=None):
+        return F_.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self.act, grad_holder, stats, gate_out, gate_in)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

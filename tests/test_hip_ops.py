@@ -1239,3 +1239,121 @@ def test_conv_bn_fused_statistics_vs_separate_pass(dev, case, dtype):
         rel = (a[i].double() - b[i].double()).norm().item() / max(b[i].double().norm().item(), 1e-30)
         assert rel <= 1e-2, (nm, rel)
     print(f"[conv+bn stats {case}] kernel {a[7][0]}")
+
+
+# ----------------------------------------------------------------------------------------- round 5: activation derivative in the consumer's data gradient
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["leaky", "sigmoid", "tanh"])
+def test_gated_data_gradients_match_dgrad_then_act_bwd(dev, dtype, act):
+    """octa_conv2d_dgrad_gated / octa_col2im_taps_gated / octa_fullconv_bwd_gated (functional.ActGate): dx * f'(x) in the consumer's
+    epilogue against the unfused pair (data gradient, then octa_act_bwd on the producer's output), and against the closed form in
+    float64 -- the discriminator's three consumers: a 1x1 squeeze conv, the 15-channel k4 s2 conv behind torch.cat (only the first
+    13 channels are an activation's output), the full-extent head."""
+    from octave_amd import functional as F_
+    from octave_amd._lib import ACT_LEAKY02, ACT_SIGMOID, ACT_TANH
+    code = {"leaky": ACT_LEAKY02, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH}[act]
+    gen = torch.Generator().manual_seed(17)
+
+    def act_out(shape):
+        z = torch.randn(shape, generator=gen)
+        y = {"leaky": torch.nn.functional.leaky_relu(z, 0.2), "sigmoid": torch.sigmoid(z), "tanh": torch.tanh(z)}[act]
+        return y.to(dtype).float()          # the values the kernels see
+
+    def fprime(y):
+        y = y.double()
+        return {"leaky": torch.where(y > 0, 1.0, 0.2), "sigmoid": y * (1 - y), "tanh": 1 - y * y}[act]
+
+    t = TOL[dtype]
+    # (a) 1x1 conv 24 -> 13 (its data gradient reaches the 24-channel activation output), 64-channel variant too
+    for Cin, Cout, H, W in ((24, 13, 9, 11), (64, 13, 12, 10), (136, 13, 7, 5)):
+        x = act_out((2, Cin, H, W))
+        w = torch.randn(Cout, Cin, 1, 1, generator=gen) * 0.2
+        dy = torch.randn(2, Cout, H, W, generator=gen).to(dtype).float()
+        xd = F_.to_nhwc(x.to(dev), dtype=dtype, cpad=F_.round8(Cin))
+        dyd = F_.to_nhwc(dy.to(dev), dtype=dtype, cpad=F_.round8(Cout))
+        wd = w.to(dev)
+        dx_f, applied = F_.raw_conv_dgrad(dyd, wd, (2, Cin, H, W), 1, 0, 1, None, gate=(xd, code, 0))
+        assert applied
+        dx_u = F_.raw_act_bwd(xd, F_.raw_conv_dgrad(dyd, wd, (2, Cin, H, W), 1, 0, 1), code)
+        want = torch.nn.functional.conv_transpose2d(dy.double(), w.double().to(dtype).double() if dtype != torch.float32 else w.double()) * fprime(x)
+        scale = float(want.abs().max())
+        check(f"gated 1x1 {Cin} vs closed form", dx_f[:, :Cin], want, t["rtol"], t["atol"] * scale)
+        check(f"gated 1x1 {Cin} vs unfused", dx_f[:, :Cin], dx_u[:, :Cin], 2 * t["rtol"], 2 * t["atol"] * scale)
+    # (b) k4 s2 p1 conv on 15 channels (13 gated + 2 map channels): the tap GEMM + gated fold
+    B, Cin, H, W, Cout = 2, 15, 12, 16, 40
+    x = torch.cat((act_out((B, 13, H, W)), torch.randn(B, 2, H, W, generator=gen).to(dtype).float()), 1)
+    w = torch.randn(Cout, Cin, 4, 4, generator=gen) * 0.1
+    OH, OW = H // 2, W // 2
+    dy = torch.randn(B, Cout, OH, OW, generator=gen).to(dtype).float()
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype, cpad=16)
+    dyd = F_.to_nhwc(dy.to(dev), dtype=dtype, cpad=F_.round8(Cout))
+    wd = w.to(dev)
+    dx_f, applied = F_.raw_conv_dgrad(dyd, wd, (B, Cin, H, W), 2, 1, 1, None, gate=(xd, code, 13))
+    assert applied
+    wq = w.to(dtype).double() if dtype != torch.float32 else w.double()
+    raw = torch.nn.functional.conv_transpose2d(dy.double(), wq, stride=2, padding=1)
+    g = torch.ones_like(raw)
+    g[:, :13] = fprime(x[:, :13])
+    want = raw * g
+    scale = float(want.abs().max())
+    check("gated k4s2 fold vs closed form", dx_f[:, :Cin], want, 2 * t["rtol"], 2 * t["atol"] * scale)
+    # (c) the full-extent head: dx = sign * dout * w * f'(x)
+    B, C, H, W = 3, 16, 5, 6
+    x = act_out((B, C, H, W))
+    wfc = torch.randn(1, C, H, W, generator=gen)
+    xd = F_.to_nhwc(x.to(dev), dtype=dtype)
+    res = {}
+    for gated in (True, False):
+        xr = xd.clone().requires_grad_(True)
+        wr = wfc.to(dev).requires_grad_(True)
+        gate = (F_.ActGate(), code) if gated else None
+        out = F_.FullConvFn.apply(xr, wr, None, -1.0, None, gate)
+        out.backward(torch.ones_like(out) * 0.5)
+        res[gated] = (xr.grad.clone(), wr.grad.clone(), None if gate is None else gate[0].done)
+    assert res[True][2] is True
+    want = (-0.5 * wfc.double()).expand(B, C, H, W) * fprime(x)
+    check("gated head dx vs closed form", res[True][0], want, t["rtol"], t["atol"] * float(want.abs().max()))
+    check("gated head dx vs unfused", res[True][0], F_.raw_act_bwd(xd, res[False][0], code), 2 * t["rtol"], 2 * t["atol"] * float(want.abs().max()))
+    assert torch.equal(res[True][1], res[False][1])          # the weight gradient does not see the gate
+
+
+def test_discriminator_backward_without_derivative_kernels(dev):
+    """The discriminator's chain with ActGate on: no octa_act_bwd launch in its backward, gradients equal (to bf16 rounding) to the
+    chain with the gates off."""
+    import importlib
+    from octave_amd import functional as F_
+    from architectures.discriminator.blocks import DiscriminatorBlock
+    torch.manual_seed(3)
+    B, H = 2, 64
+    net = DiscriminatorBlock(torch.Size((B, 2, H, H)), True, depth=4).to(dev).train()
+    net.compute_dtype = torch.bfloat16
+    maps = [torch.rand(B, 2, H >> i, H >> i, device=dev, requires_grad=True) for i in range(5)]
+    grads = {}
+    calls = {}
+    orig = F_.raw_act_bwd
+    try:
+        for on in (True, False):
+            n = [0]
+
+            def counting(y, dy, act, _n=n):
+                _n[0] += 1
+                return orig(y, dy, act)
+            F_.raw_act_bwd = counting
+            F_._ACT_GATES = on
+            st = {k: v.clone() for k, v in net.state_dict().items()}
+            torch.manual_seed(11)
+            net.zero_grad(set_to_none=True)
+            for m in maps:
+                m.grad = None
+            out = net(maps)
+            (out.float() ** 2).sum().backward()
+            calls[on] = n[0]
+            grads[on] = [m.grad.clone() for m in maps] + [p.grad.clone() for p in net.parameters()]
+            net.load_state_dict(st)          # the power iteration moved u / v: same state for the second run
+    finally:
+        F_.raw_act_bwd = orig
+        F_._ACT_GATES = True
+    assert calls[True] == 0 and calls[False] == 9, calls
+    for i, (a, b) in enumerate(zip(grads[True], grads[False])):
+        scale = float(b.abs().max()) + 1e-12
+        check(f"discriminator gradient {i}", a, b, 5e-2, 2e-2 * scale)
