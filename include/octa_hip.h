@@ -558,7 +558,8 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * key 8: schedule of the 256 x 256 weight-gradient kernel: 0 (default) = rounds of workgroups with one split length for the whole
  * batch (wgrad9); 1 = every class of problems its own split, blocks dealt to the XCDs in eighths, XCDs started at different
  * positions of their sequences (wgrad9x); 2 = the same with one persistent workgroup per CU.  Same sums, different atomic order;
- * no gain measured in situ (the launch is power-limited: DESIGN.md 3.12). */
+ * no gain measured in situ (the launch is power-limited: DESIGN.md 3.12).  key 9: MFMA shape of the 256 x 256 weight-gradient kernel:
+ * 0 = v_mfma_f32_32x32x16 (wgrad9), 1 = v_mfma_f32_16x16x32 at the same wave tile (wgrad9s). */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -697,6 +697,294 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 //     PERSIST = 0: one position per workgroup, gridDim.x = 8 * (longest XCD sequence).
 // blockIdx & 7 is used as the XCD label (a performance assumption only: every position is processed exactly once whatever the
 // placement).
+// wgrad9s: wgrad9 on v_mfma_f32_16x16x32 (round 5; octa_tuning_set(9, 1)).  3.12 showed a long wgrad9 launch to be power-limited
+// (in-kernel clock 1.35-1.6 GHz): under that cap the 16x16x32 shape is the one the guide measures 1.12-1.15x ahead of 32x32x16
+// (MI355X_MICROARCH.md, DVFS give-back 7).  Same batch interface, tile (256 x 256, 8 waves of 128(N) x 64(K)), 32-pixel stages, 4-slot
+// ring, DMA roles, zero page and epilogue protocol as wgrad9; what differs:
+//   * a stage is ONE k32 step: 8 A blocks x 4 B blocks of 16 channels = 32 MFMAs per wave, cut into two sub-steps by the A blocks
+//     (A0 = blocks 0-3, A1 = 4-7) around the stage barrier.  Sub-step 0 runs A0 x B and fetches A1 (8 transposed reads) and the dy
+//     half of the DMA; sub-step 1 runs A1 x B and fetches A0 and B of stage it + 1 (16 reads) and the x half of the DMA.  B is
+//     double-buffered across stages (the loop is unrolled by two): 64 fragment registers + 128 accumulators;
+//   * lane (r = lane & 15, gq = lane >> 4) reads pixel rows 8 gq + (r >> 2) (+ 4) of a 16-channel block, so one 32-lane half touches
+//     rows {0..3, 8..11}: the 32-byte pair index is XOR-ed with f(m) = (m & 3) | ((m >> 3) & 1) << 2 (wgrad8's involution) instead of
+//     wgrad9's (m & 3) << 1, in the fragment addresses, the DMA source chunks and the bias reads alike;
+//   * a 16x16 accumulator register is 4 rows x 64 bytes of the gradient tensor (the 32x32 form: 2 x 128 bytes).
+__device__ __forceinline__ void wg9s_wait16(wg_u32x2_t (&a)[4][2], wg_u32x2_t (&b)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]),
+                   "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1])
+                 :: "memory");
+}
+__device__ __forceinline__ void wg9s_wait8(wg_u32x2_t (&a)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1])
+                 :: "memory");
+}
+
+template <int F16>
+__global__ __launch_bounds__(512) void wgrad9s_kernel(const WgBatch batch) {
+    constexpr int BN = 256, BK = 256, MT = 32, SLOTS = 4;
+    constexpr int RB = 512, IMG = MT * RB, SBYTES = 2 * IMG;
+    constexpr int LPR = 32, RPI = 2, IPW = 2;
+    constexpr int LPT = 2 * IPW;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SLOTS * SBYTES + BN * 4];
+    float* const sBias = (float*)(smem + SLOTS * SBYTES);
+
+    const int total = gridDim.x, Lb = blockIdx.x;
+    const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
+    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jq;
+    int pi = 0;
+    for (int i = 1; i < batch.n; ++i) if (batch.p[i].blockStart <= Lp) pi = i;
+    const WgProb& Pk = batch.p[pi];
+    const int tilesN = Pk.tilesN, tilesK = Pk.tilesK, groups = Pk.groups, mPerSplit = Pk.mPerSplit, Mtot = Pk.M;
+    const int Ng = Pk.Ng, Kpad = Pk.Kpad, Cg = Pk.Cg, CgReal = Pk.CgReal, KW = Pk.KW;
+    const int H = Pk.H, W = Pk.W, OH = Pk.OH, OW = Pk.OW, stride = Pk.stride, pad = Pk.pad;
+    const int ldx = Pk.ldx, ldy = Pk.ldy;
+    const unsigned short* const xbase = Pk.x;
+    const unsigned short* const dybase = Pk.dy;
+    int bid = Lp - Pk.blockStart;
+    const int nt = bid % tilesN; bid /= tilesN;
+    const int kt = bid % tilesK; bid /= tilesK;
+    const int g = bid % groups;
+    const int sp = bid / groups;
+    const int n0 = nt * BN, k0 = kt * BK;
+    const int mbeg = sp * mPerSplit;
+    const int mend = min(Mtot, mbeg + mPerSplit);
+    const int nsteps = (mend - mbeg + MT - 1) / MT;
+    if (nsteps <= 0) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave >> 2, wk = wave & 3;                       // 2 x 4 waves of 128(N) x 64(K)
+    const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
+
+    // ---- DMA roles: as wgrad9, with the 16x16x32 involution (a lane's rows differ by 16: same f)
+    const int drow = wave * RPI + lane / LPR;
+    const int dpos = lane % LPR;
+    const int df_ = (drow & 3) | (((drow >> 3) & 1) << 2);
+    const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
+    const bool pvalid = (n0 + dchunk * 8) < Ng;
+    const unsigned long pstep = pvalid ? (unsigned long)((long)MT * ldy * 2) : 0ul;
+    unsigned long pptr[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+        pptr[i] = pvalid ? (unsigned long)(dybase + ((long)(mbeg + drow + i * 8 * RPI) * ldy + Pk.yoff + g * Ng + n0 + dchunk * 8)) : zaddr;
+    const int kel = k0 + dchunk * 8;
+    const bool kvalid = kel < Kpad;
+    const int qtap = kel / Cg, qcc = kel - qtap * Cg;
+    const int qkh = qtap / KW, qkw = qtap - qkh * KW;
+    const int qdh = qkh - pad, qdw = qkw - pad;
+    const unsigned long qbase = (unsigned long)(xbase + (Pk.xoff + g * CgReal + qcc));
+    const bool plain = (Pk.KH == 1 && KW == 1 && pad == 0 && stride == 1);
+    const int ldx2 = ldx * 2;
+    const int dq = MT / OW, dr = MT - dq * OW;
+    const int sdr = stride * dr, sdq = stride * dq, OWs = OW * stride, OHs = OH * stride;
+    const int thrW = OWs + qdw, thrH = OHs + qdh;
+    const int dpix = sdq * W + sdr, cW = stride * W - OWs, cH = H * W - OHs * W;
+    int qih[IPW], qiw[IPW], qpix[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int m = mbeg + drow + i * 8 * RPI;
+        const int ow = m % OW, tq = m / OW, oh = tq % OH, b = tq / OH;
+        qih[i] = oh * stride + qdh; qiw[i] = ow * stride + qdw;
+        qpix[i] = plain ? m : (b * H + qih[i]) * W + qiw[i];
+    }
+    const unsigned sbase = wg_lds_addr(smem);
+    auto issueP = [&](int i, int slot, int mcur) {
+        const bool ok = (mcur + drow + i * 8 * RPI) < mend;
+        const unsigned long src = ok ? pptr[i] : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + (i * 8 + wave) * 1024)));
+        pptr[i] += pstep;
+    };
+    auto issueQ = [&](int i, int slot, int mcur) {
+        const bool ok = kvalid & ((mcur + drow + i * 8 * RPI) < mend) & ((unsigned)qih[i] < (unsigned)H) & ((unsigned)qiw[i] < (unsigned)W);
+        const unsigned off = (unsigned)__mul24(qpix[i], ldx2);
+        const unsigned long a = qbase + (unsigned long)off;
+        const unsigned long src = ok ? a : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + IMG + (i * 8 + wave) * 1024)));
+        qiw[i] += sdr;
+        const bool c1 = qiw[i] >= thrW;
+        qiw[i] -= c1 ? OWs : 0;
+        qih[i] += sdq + (c1 ? stride : 0);
+        const bool c2 = qih[i] >= thrH;
+        qih[i] -= c2 ? OHs : 0;
+        qpix[i] += dpix + (c1 ? cW : 0) + (c2 ? cH : 0);
+    };
+    auto issue = [&](int slot, int mcur) { issueP(0, slot, mcur); issueP(1, slot, mcur); issueQ(0, slot, mcur); issueQ(1, slot, mcur); };
+
+    wg_f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (wg_f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- transposed fragment addressing (slot 0): lane (r, gq) reads pixel rows 8 gq + (r >> 2) and + 4 of 16-channel block b
+    const int r = lane & 15, gq = lane >> 4;
+    const int frow = 8 * gq + (r >> 2);
+    const int fr = (frow & 3) | (((frow >> 3) & 1) << 2);
+    const int cb = (r & 3) * 8;
+    unsigned abase[8], bbase[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abase[i] = sbase + (unsigned)(frow * RB + (((wn * 8 + i) ^ fr) << 5) + cb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bbase[j] = sbase + (unsigned)(IMG + frow * RB + (((wk * 4 + j) ^ fr) << 5) + cb);
+
+    float* const dbias = Pk.dbias;
+    const bool do_bias = (dbias != nullptr) && (kt == 0);
+    const int brow = t / LPR, bpos = t % LPR;
+    const int bf_ = (brow & 3) | (((brow >> 3) & 1) << 2);
+    const int bchunk = (((bpos >> 1) ^ bf_) << 1) | (bpos & 1);
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    if (do_bias && t < BN) sBias[t] = 0.f;
+
+    issue(0, mbeg);
+    if (nsteps > 1) issue(1, mbeg + MT);
+    if (nsteps > 2) issue(2, mbeg + 2 * MT);
+    if (nsteps > 2) wg_wait_vmcnt<2 * LPT>(); else if (nsteps > 1) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    wg_u32x2_t a0[4][2], a1[4][2], bE[4][2], bO[4][2];
+#define WG9S_TR(F, i, ad) { F[i][0] = wg_tr<0>(ad); F[i][1] = wg_tr<2048>(ad); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) WG9S_TR(a0, i, abase[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) WG9S_TR(bE, j, bbase[j]);
+    wg9s_wait16(a0, bE);
+#define WG9S_MMA(AF, BF, i, ai, j)                                                                                                         \
+    WgMma<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[ai][j])
+#define WG9S_SB __builtin_amdgcn_sched_barrier(0)
+    // one stage; BC: this stage's B fragments, BN_: the set the next stage's are fetched into
+#define WG9S_STAGE(BC, BN_)                                                                                                                \
+    {                                                                                                                                      \
+        const int rem = nsteps - 1 - it;                                                                                                   \
+        const bool more = rem >= 3;                                                                                                        \
+        const int s3 = (it + 3) & (SLOTS - 1), m3 = mbeg + (it + 3) * MT;                                                                  \
+        const unsigned so = (unsigned)((it & (SLOTS - 1)) * SBYTES);                                                                       \
+        const unsigned sn = (unsigned)(((it + 1) & (SLOTS - 1)) * SBYTES);                                                                 \
+        if (do_bias) {                                                                                                                     \
+            const unsigned char* sP = smem + so;                                                                                           \
+            _Pragma("unroll")                                                                                                              \
+            for (int jj = 0; jj < 2; ++jj) {                                                                                               \
+                const uint4 v = *(const uint4*)(sP + (brow + jj * 16) * RB + bpos * 16);                                                   \
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};                                                                               \
+                _Pragma("unroll")                                                                                                          \
+                for (int e = 0; e < 4; ++e) {                                                                                              \
+                    bsum[2 * e] += WgMma<F16>::cvt((unsigned short)(w4[e] & 0xffffu));                                                     \
+                    bsum[2 * e + 1] += WgMma<F16>::cvt((unsigned short)(w4[e] >> 16));                                                     \
+                }                                                                                                                          \
+            }                                                                                                                              \
+        }                                                                                                                                  \
+        WG9S_SB;                                                                                                                           \
+        /* sub-step 0: A0 x B; fetch A1 (blocks 4-7) of this stage; the dy half of the DMA */                                              \
+        WG9S_MMA(a0, BC, 0, 0, 0); WG9S_TR(a1, 0, abase[4] + so); WG9S_SB;                                                                 \
+        WG9S_MMA(a0, BC, 1, 1, 0); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 2, 2, 0); WG9S_TR(a1, 1, abase[5] + so); WG9S_SB;                                                                 \
+        WG9S_MMA(a0, BC, 3, 3, 0); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 0, 0, 1); WG9S_TR(a1, 2, abase[6] + so); WG9S_SB;                                                                 \
+        WG9S_MMA(a0, BC, 1, 1, 1); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 2, 2, 1); WG9S_TR(a1, 3, abase[7] + so); WG9S_SB;                                                                 \
+        WG9S_MMA(a0, BC, 3, 3, 1); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 0, 0, 2); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 1, 1, 2); if (more) issueP(0, s3, m3); WG9S_SB;                                                                   \
+        WG9S_MMA(a0, BC, 2, 2, 2); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 3, 3, 2); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 0, 0, 3); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 1, 1, 3); if (more) issueP(1, s3, m3); WG9S_SB;                                                                   \
+        WG9S_MMA(a0, BC, 2, 2, 3); WG9S_SB;                                                                                                \
+        WG9S_MMA(a0, BC, 3, 3, 3); WG9S_SB;                                                                                                \
+        if (rem >= 3) wg_wait_vmcnt<LPT + 2>(); else if (rem == 2) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();                          \
+        wg9s_wait8(a1);                                                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                                      \
+        WG9S_SB;                                                                                                                           \
+        /* sub-step 1: A1 x B; fetch A0 and B of stage it + 1 (its slot has landed: the barrier above); the x half of the DMA */           \
+        WG9S_MMA(a1, BC, 0, 4, 0); WG9S_TR(a0, 0, abase[0] + sn); WG9S_SB;                                                                 \
+        WG9S_MMA(a1, BC, 1, 5, 0); WG9S_TR(a0, 1, abase[1] + sn); WG9S_SB;                                                                 \
+        WG9S_MMA(a1, BC, 2, 6, 0); WG9S_TR(a0, 2, abase[2] + sn); WG9S_SB;                                                                 \
+        WG9S_MMA(a1, BC, 3, 7, 0); WG9S_TR(a0, 3, abase[3] + sn); WG9S_SB;                                                                 \
+        WG9S_MMA(a1, BC, 0, 4, 1); WG9S_TR(BN_, 0, bbase[0] + sn); WG9S_SB;                                                                \
+        WG9S_MMA(a1, BC, 1, 5, 1); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 2, 6, 1); WG9S_TR(BN_, 1, bbase[1] + sn); WG9S_SB;                                                                \
+        WG9S_MMA(a1, BC, 3, 7, 1); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 0, 4, 2); WG9S_TR(BN_, 2, bbase[2] + sn); WG9S_SB;                                                                \
+        WG9S_MMA(a1, BC, 1, 5, 2); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 2, 6, 2); WG9S_TR(BN_, 3, bbase[3] + sn); WG9S_SB;                                                                \
+        WG9S_MMA(a1, BC, 3, 7, 2); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 0, 4, 3); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 1, 5, 3); if (more) issueQ(0, s3, m3); WG9S_SB;                                                                   \
+        WG9S_MMA(a1, BC, 2, 6, 3); WG9S_SB;                                                                                                \
+        WG9S_MMA(a1, BC, 3, 7, 3); if (more) issueQ(1, s3, m3); WG9S_SB;                                                                   \
+        wg9s_wait16(a0, BN_);                                                                                                              \
+        WG9S_SB;                                                                                                                           \
+    }
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
+    for (int it = 0; it < nsteps; ++it) {
+        WG9S_STAGE(bE, bO)
+        if (++it >= nsteps) break;
+        WG9S_STAGE(bO, bE)
+    }
+#undef WG9S_STAGE
+#undef WG9S_MMA
+#undef WG9S_TR
+#undef WG9S_SB
+    OCTA_STAMP_END(octa_diag_stamps_wgrad9)
+
+    float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
+    if (do_bias) {
+        __syncthreads();
+        float* const bred = (float*)smem;                  // [512 / LPR][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[brow * BN + bchunk * 8 + e] = bsum[e];
+        __syncthreads();
+        if (t < BN) {
+            float v = 0.f;
+            for (int rg = 0; rg < 512 / LPR; ++rg) v += bred[rg * BN + t];
+            sBias[t] = v;
+        }
+        if (t < BN && n0 + t < Ng) {
+            if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
+            else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        }
+    }
+    // D[row = n (4 gq + e)][col = k (r)] of 16x16 block (i, j)
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk * 64 + j * 16 + r;
+            if (k >= Kpad) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wn * 128 + i * 16 + gq * 4 + e;
+                    if (n < Ng) part[(long)(g * Ng + n) * Kpad + k] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    float* const dw = Pk.dw;
+    const long s_o = Pk.s_o, s_i = Pk.s_i, s_h = Pk.s_h, s_w = Pk.s_w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + r;
+        if (k >= Kpad) continue;
+        const int tap = k / Cg, ci = k - tap * Cg;
+        if (ci >= CgReal) continue;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const long koff = (long)ci * s_i + (long)kh * s_h + (long)kw * s_w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wn * 128 + i * 16 + gq * 4 + e;
+                if (n < Ng) atomicAdd(dw + (long)(g * Ng + n) * s_o + koff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
 #ifdef OCTA_DIAG_STAMPS
 // timeline of the wgrad9x workgroups (diagnostic build only): [workgroup][0] = items stamped, then per item 4 x s_memrealtime (100 MHz):
 // item begin, main loop begin, main loop end, epilogue drained (the diagnostic build waits for its atomics there), and s_memtime (shader
@@ -1095,6 +1383,11 @@ static int wg8_launch(std::vector<WgPlan>& plans, int variant, hipStream_t st) {
     return OCTA_OK;
 }
 
+static int g_wg9_shape16 = 0;          // octa_tuning_set(9, 0 / 1): 1 = the 256 x 256 kernel on v_mfma_f32_16x16x32 (wgrad9s)
+static int wg9_shape16() {
+    static const int env = getenv("OCTA_WG9_SHAPE16") ? atoi(getenv("OCTA_WG9_SHAPE16")) : -1;
+    return env >= 0 ? env : g_wg9_shape16;
+}
 static int g_wg9_ablate = 0;           // octa_tuning_set(2, mask): timing-only ablation build of wgrad9 (tools/wgrad_micro.py)
 // 256 x 256 tiles (wgrad9): one launch per batch, 32-pixel stages
 template <int F16>
@@ -1156,10 +1449,12 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
                 case 29: wgrad9_kernel<0, 1, 29><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
                 default: OCTA_FAIL(OCTA_ERR_BAD_ARG, "wgrad9 ablation %d is not built", g_wg9_ablate);
             }
-        } else if (stagger) wgrad9_kernel<F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        } else if (wg9_shape16()) wgrad9s_kernel<F16><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        else if (stagger) wgrad9_kernel<F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
         else wgrad9_kernel<F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
         OCTA_CHECK_LAUNCH("wgrad9");
-        octa_note_conv_kernel(F16 ? "wgrad9_kernel<f16,256x256>" : "wgrad9_kernel<bf16,256x256>");
+        octa_note_conv_kernel(wg9_shape16() ? (F16 ? "wgrad9s_kernel<f16,256x256,16x16x32>" : "wgrad9s_kernel<bf16,256x256,16x16x32>")
+                                            : (F16 ? "wgrad9_kernel<f16,256x256>" : "wgrad9_kernel<bf16,256x256>"));
         i0 = i1;
     }
     return OCTA_OK;
@@ -1344,6 +1639,7 @@ void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
 void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 9) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 9 = MFMA shape of the 256 x 256 weight-gradient kernel: 0 = 32x32x16 (wgrad9), 1 = 16x16x32 (wgrad9s)"); g_wg9_shape16 = value; return OCTA_OK; }
     if (key == 8) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 8 = wgrad9 schedule: 0 rounds of one split length, 1 per-class splits + XCD-interleaved sequences, 2 the same, persistent"); g_wg9_sched = value; return OCTA_OK; }
     if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }
     if (key == 6) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 6 = halo8 patch image: 1 packed (bank-conflict-free), 0 linear"); octa_set_halo8_packed(value); return OCTA_OK; }

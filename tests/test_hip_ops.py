@@ -1102,7 +1102,7 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
     check("res upshuffle", y, ref, t["rtol"], t["atol"] * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3])
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
@@ -1111,7 +1111,8 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
     torch's CPU gradients.  fold: with the fold scratch registered the M-split jobs of every kernel family store
     partial tiles and the batch ends in fold launches (two of them: more than 16 jobs would need a third); the gradients must
     also be bit-identical between two runs.  sched: the schedule of the 256 x 256 kernel (octa_tuning_set(8, .)): 0 = rounds of one
-    split length (wgrad9), 1 = per-class splits on XCD-interleaved sequences (wgrad9x), 2 = the same, persistent."""
+    split length (wgrad9), 1 = per-class splits on XCD-interleaved sequences (wgrad9x), 2 = the same, persistent; 3 = wgrad9's schedule
+    on v_mfma_f32_16x16x32 (wgrad9s, octa_tuning_set(9, 1))."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import WgradJob, lib
@@ -1151,11 +1152,14 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
     F_.set_wgrad_fold_workspace(ws)
     if fold:
         L.octa_tuning_set(4, 1)       # the batched kernels too (off by default: no gain in situ)
-    L.octa_tuning_set(8, sched)
+    L.octa_tuning_set(8, sched if sched < 3 else 0)
+    L.octa_tuning_set(9, 1 if sched == 3 else 0)
     try:
         L.octa_conv2d_wgrad_batch(jobs, len(cases), *F_._fold_ws_args(), torch.cuda.current_stream().cuda_stream)
-        if sched and not fold:
+        if sched in (1, 2) and not fold:
             assert "wgrad9x" in L.octa_last_conv_kernel().decode() and ("persistent" in L.octa_last_conv_kernel().decode()) == (sched == 2)
+        if sched == 3 and not fold:
+            assert "wgrad9s" in L.octa_last_conv_kernel().decode()
         first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in keep]
         if fold:
             for _, _, dw, db in keep:
@@ -1167,6 +1171,7 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
         F_.set_wgrad_fold_workspace(None)
         L.octa_tuning_set(4, 0)
         L.octa_tuning_set(8, 0)
+        L.octa_tuning_set(9, 0)
     split_jobs = 0
     for j, ((xd, dyd, dw, db), (gw, gb)) in enumerate(zip(keep, want)):
         check(f"wgrad batch job {j} {cases[j]}", dw, gw, 0, 3e-4 * float(gw.abs().max()))

@@ -22,7 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p
 echo "write pass done"
 cd $R
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json
-python3 tools/stats_summary.py $OUT/stats/k_kernel_stats.csv 9 > $OUT/stats_summary.txt
+python3 tools/stats_summary.py $OUT/stats/k_kernel_stats.csv 11 > $OUT/stats_summary.txt
 python3 tools/trace_last_step.py $OUT/stats/k_kernel_trace.csv > $OUT/last_step.txt 2>&1 || true
 rm -f $OUT/fetch/*kernel_trace.csv $OUT/write/*kernel_trace.csv $OUT/stats/*kernel_trace.csv
 ls -la $OUT $OUT/stats | head -30
