@@ -2305,7 +2305,8 @@ extern "C" int octa_colsum(const void* src, int64_t rows, int C, int ld, int off
         OCTA_CHECK_LAUNCH("colsum_vec");
         return OCTA_OK;
     }
-    int rpb = (int)cdiv64(rows, 512);
+    static const int cs_slabs = getenv("OCTA_COLSUM_SLABS") ? std::max(16, atoi(getenv("OCTA_COLSUM_SLABS"))) : 512;
+    int rpb = (int)cdiv64(rows, cs_slabs);
     if (rpb < 64) rpb = 64;
     if (octa_deterministic()) { OCTA_REQUIRE(rows < (1ll << 31), "octa_colsum: too many rows for the deterministic path"); rpb = (int)rows; }
     dim3 grid(cdiv(C, 64), (unsigned)cdiv64(rows, rpb)), block(64, 4);

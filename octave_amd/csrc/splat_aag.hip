@@ -1306,7 +1306,8 @@ static int aag_fwd_launch(const void* x, const float* w, const float* bias, void
     const int lpp = aag_lpp(C / DT<T>::EPC, cpl);
     const int ppb = 256 / lpp;
     int64_t nb = cdiv64(npix, ppb);
-    if (nb > 4096) nb = 4096;
+    static const int fcap = getenv("OCTA_AAG_FWD_BLOCKS") ? std::max(64, atoi(getenv("OCTA_AAG_FWD_BLOCKS"))) : 4096;
+    if (nb > fcap) nb = fcap;
     const size_t sh = (size_t)K * C * sizeof(float);
 #define AAG_F(CPLV) aag_fwd_kernel<T, K, CPLV><<<(int)nb, 256, sh, st>>>((const T*)x, w, bias, (T*)masked, y, npix, HW, C, lpp, mode)
     if (cpl <= 1) AAG_F(1); else if (cpl <= 2) AAG_F(2); else if (cpl <= 4) AAG_F(4);
@@ -1320,7 +1321,8 @@ static int64_t aag_bwd_blocks(int64_t npix, int ppb) {
     // wide, low-resolution gates (1024 channels at 25 x 25: 4 pixels per block round) came out at 157 workgroups on 256 CUs with
     // 16 dependent rounds each: at least one workgroup per CU while a workgroup still has two rounds (one loop iteration)
     if (nb < 256) { const int64_t nb2 = cdiv64(npix, (int64_t)ppb * 2); nb = nb2 < 256 ? nb2 : 256; }
-    if (nb > 1024) nb = 1024;
+    static const int cap = getenv("OCTA_AAG_BWD_BLOCKS") ? std::max(64, atoi(getenv("OCTA_AAG_BWD_BLOCKS"))) : 1024;
+    if (nb > cap) nb = cap;
     return nb < 1 ? 1 : nb;
 }
 template <typename T, int K>
