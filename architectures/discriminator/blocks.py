@@ -19,6 +19,7 @@ from octave_amd.layers import Conv2d
 
 
 _SN_BATCH = os.environ.get("OCTA_SN_BATCH", "1") != "0"      # one batched power iteration per discriminator call
+_S2D_CONV0 = os.environ.get("OCTA_S2D_CONV0", "1") != "0"    # first conv on the space-to-depth image of its input (round 5)
 
 
 class SpectralConv2d(Conv2d):
@@ -67,15 +68,18 @@ class InstanceNoise(nn.Module):
             return torch.normal(mean=self.mean, std=self.std, size=self.size, out=out)
         return torch.normal(mean=self.mean, std=self.std, size=self.size)
 
-    def forward(self, x: Tensor, noise_dev: Tensor = None, fed: bool = False):
+    def forward(self, x: Tensor, noise_dev: Tensor = None, fed: bool = False, s2d: bool = False):
         """`fed=True`: the (H, W) plane was drawn by the caller (same CPU-generator order) and already lives on
-        the device (hipGraph replay); otherwise it is drawn here exactly like the reference."""
+        the device (hipGraph replay); otherwise it is drawn here exactly like the reference.  `s2d`: emit the space-to-depth
+        layout the k4 s2 p1 conv behind this module reads as a k2 s1 conv (functional.NoiseClipS2dFn)."""
         if fed:
             nz = noise_dev if self.is_training else None
         else:
             noise = self.draw()                  # drawn even when not added (ref :150-151)
             nz = noise.to(x.device, non_blocking=True) if self.is_training else None
         dtype = self.compute_dtype or torch.float32
+        if s2d:
+            return F_.NoiseClipS2dFn.apply(x, nz, dtype, self.clipping)
         return F_.NoiseClipFn.apply(x, nz, dtype, self.clipping)
 
 
@@ -172,8 +176,17 @@ class DiscriminatorBlock(nn.Module):
         a_prev = ACT_LEAKY02
         if self._has_noise:
             self.stack_0[0].compute_dtype = dtype
-            s = self.stack_0[0](y[0], feed.next_noise(), True) if feed is not None else self.stack_0[0](y[0])
-            s = self.stack_0[1](s, gate_out=g_prev)
+            c0 = self.stack_0[1]
+            # the first conv (k4 s2 p1 on 2 channels) as a k2 s1 conv on the space-to-depth image of its input: 8 real channels
+            # per pixel instead of 2 padded to 8 (a quarter of the input bytes and of the MFMA K; its data gradient is an ordinary
+            # stride-1 one instead of a tap GEMM + fold)
+            s2d = (_S2D_CONV0 and y[0].is_cuda and c0.kernel_size == (4, 4) and c0.stride == (2, 2) and c0.padding == (1, 1) and c0.groups == 1
+                   and (4 * c0.in_channels) % 8 == 0 and y[0].shape[2] % 2 == 0 and y[0].shape[3] % 2 == 0)
+            s = self.stack_0[0](y[0], feed.next_noise(), True, s2d) if feed is not None else self.stack_0[0](y[0], None, False, s2d)
+            if s2d:
+                s = F_.conv2d(s, F_.s2d_weight(c0.weight), c0.bias, 1, 0, 1, c0.act, None, None, g_prev, None)
+            else:
+                s = c0(s, gate_out=g_prev)
         else:
             s = self.stack_0[0](F_.ToNhwcFn.apply(y[0], dtype), gate_out=g_prev)
         # the spectral-norm convs' power iterations (independent of each other and of the activations): one batched call

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 312
+#define OCTA_HIP_ABI_VERSION 313
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -471,6 +471,15 @@ int octa_noise_clip_fwd(const float* src, const int64_t* src_strides, const floa
 /* dsrc[b,c,h,w] (dense NCHW fp32) = mask ? ddst[b,h,w,c] : 0 */
 int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask, float* dsrc, int B, int C,
                         int H, int W, int dtype, octa_stream_t stream);
+/* The same, written space-to-depth for the k4 s2 p1 conv behind it (blocks.py:46): dst is NHWC [B][H/2+1][W/2+1][ld >= 4C],
+ * dst[b,Y,X,(dy*2+dx)*C+c] = clip(src[b,c,2Y+dy-1,2X+dx-1] + noise, 0, 1) (0 outside the image; channels [4C, ld) zeroed); that conv is
+ * then a k2 s1 p0 conv with weight w2[o,(dy*2+dx)*C+c,i,j] = w[o,c,2i+dy,2j+dx] -- same sums, no padded channels (2 -> 8 before).
+ * mask as above (NCHW of the ORIGINAL geometry).  H, W even. */
+int octa_noise_clip_s2d_fwd(const float* src, const int64_t* src_strides, const float* noise, void* dst,
+                            uint8_t* mask, int B, int C, int H, int W, int ld, int dtype, int clip, octa_stream_t stream);
+/* dsrc[b,c,h,w] (dense NCHW fp32) = mask ? ddst[b,(h+1)/2,(w+1)/2,(((h+1)&1)*2+((w+1)&1))*C+c] : 0 */
+int octa_noise_clip_s2d_bwd(const void* ddst, int ld, const uint8_t* mask, float* dsrc, int B, int C,
+                            int H, int W, int dtype, octa_stream_t stream);
 /* Spectral norm (torch.nn.utils.spectral_norm, 1 power iteration; blocks.py:105-108).
  * w: fp32 [Cout][K] dense (OIHW flattened).  Updates u,v in place when do_power_iter, writes
  * sigma[0] and w_sn = w / sigma.  uv_saved (optional, Cout + K floats) receives the u then v this call

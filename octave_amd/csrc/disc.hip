@@ -91,6 +91,81 @@ extern "C" int octa_noise_clip_bwd(const void* ddst, int ld, const uint8_t* mask
     return OCTA_OK;
 }
 
+// ---- InstanceNoise + clip, written SPACE-TO-DEPTH for the k4 s2 p1 conv that follows (round 5): that conv on [H][W][C] is a k2 s1 p0
+// conv on dst[b][Y][X][(dy*2+dx)*C + c] = v[b][c][2Y+dy-1][2X+dx-1] (0 outside the image), Y <= H/2, X <= W/2 -- for C = 2 the eight
+// channels of a pixel are all real (the plain layout pads 2 channels to 8: 4x the bytes and 4x the MFMA K of the first discriminator conv)
+template <typename T>
+__global__ __launch_bounds__(256) void noise_clip_s2d_fwd_kernel(const float* __restrict__ src, Strides4 s, const float* __restrict__ noise,
+                                                                 T* __restrict__ dst, uint8_t* __restrict__ mask, int B, int C, int H, int W, int ld, int clip) {
+    const int H2 = H / 2 + 1, W2 = W / 2 + 1;
+    const int64_t total = (int64_t)B * H2 * W2 * 4;            // thread = (pixel of the s2d image, quadrant)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int qd = (int)(i & 3);
+        int64_t p = i >> 2;
+        const int X = (int)(p % W2); p /= W2;
+        const int Y = (int)(p % H2);
+        const int b = (int)(p / H2);
+        const int h = 2 * Y + (qd >> 1) - 1, w = 2 * X + (qd & 1) - 1;
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        const float nz = (noise && in) ? noise[h * W + w] : 0.f;
+        T* o = dst + (((int64_t)b * H2 + Y) * W2 + X) * ld + qd * C;
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            if (in) {
+                v = src[b * s.b + c * s.c + h * s.h + w * s.w] + nz;
+                uint8_t m = 1;
+                if (clip) { m = (v >= 0.f && v <= 1.f) ? 1 : 0; v = fminf(fmaxf(v, 0.f), 1.f); }
+                if (mask) mask[(((int64_t)b * C + c) * H + h) * W + w] = m;
+            }
+            DT<T>::st(o + c, v);
+        }
+        if (qd == 3) for (int c = 4 * C; c < ld; ++c) DT<T>::st(dst + (((int64_t)b * H2 + Y) * W2 + X) * ld + c, 0.f);
+    }
+}
+extern "C" int octa_noise_clip_s2d_fwd(const float* src, const int64_t* ss, const float* noise, void* dst, uint8_t* mask, int B, int C, int H, int W,
+                                       int ld, int dtype, int clip, octa_stream_t stream) {
+    OCTA_REQUIRE(src && ss && dst && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ld >= 4 * C, "octa_noise_clip_s2d_fwd: even H / W, ld >= 4 C");
+    Strides4 s{ss[0], ss[1], ss[2], ss[3]};
+    const int64_t total = (int64_t)B * (H / 2 + 1) * (W / 2 + 1) * 4;
+    const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) noise_clip_s2d_fwd_kernel<float><<<blocks, 256, 0, st>>>(src, s, noise, (float*)dst, mask, B, C, H, W, ld, clip);
+    else if (dtype == OCTA_BF16) noise_clip_s2d_fwd_kernel<bf16_t><<<blocks, 256, 0, st>>>(src, s, noise, (bf16_t*)dst, mask, B, C, H, W, ld, clip);
+    else if (dtype == OCTA_F16) noise_clip_s2d_fwd_kernel<f16_t><<<blocks, 256, 0, st>>>(src, s, noise, (f16_t*)dst, mask, B, C, H, W, ld, clip);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_noise_clip_s2d_fwd: bad dtype");
+    OCTA_CHECK_LAUNCH("noise_clip_s2d_fwd");
+    return OCTA_OK;
+}
+// dsrc[b,c,h,w] (dense NCHW fp32) = mask ? ddst[b][(h+1)/2][(w+1)/2][(((h+1)&1)*2 + ((w+1)&1))*C + c] : 0
+template <typename T>
+__global__ __launch_bounds__(256) void noise_clip_s2d_bwd_kernel(const T* __restrict__ ddst, int ld, const uint8_t* __restrict__ mask,
+                                                                 float* __restrict__ dsrc, int B, int C, int H, int W) {
+    const int H2 = H / 2 + 1, W2 = W / 2 + 1;
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C);
+        const int b = (int)(i / ((int64_t)W * H * C));
+        const int Y = (h + 1) >> 1, X = (w + 1) >> 1, qd = (((h + 1) & 1) << 1) | ((w + 1) & 1);
+        const float d = DT<T>::ld(ddst + (((int64_t)b * H2 + Y) * W2 + X) * ld + qd * C + c);
+        dsrc[i] = (!mask || mask[i]) ? d : 0.f;
+    }
+}
+extern "C" int octa_noise_clip_s2d_bwd(const void* ddst, int ld, const uint8_t* mask, float* dsrc, int B, int C, int H, int W, int dtype,
+                                       octa_stream_t stream) {
+    OCTA_REQUIRE(ddst && dsrc && H % 2 == 0 && W % 2 == 0 && ld >= 4 * C, "octa_noise_clip_s2d_bwd: bad arguments");
+    const int64_t total = (int64_t)B * C * H * W;
+    const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OCTA_F32) noise_clip_s2d_bwd_kernel<float><<<blocks, 256, 0, st>>>((const float*)ddst, ld, mask, dsrc, B, C, H, W);
+    else if (dtype == OCTA_BF16) noise_clip_s2d_bwd_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)ddst, ld, mask, dsrc, B, C, H, W);
+    else if (dtype == OCTA_F16) noise_clip_s2d_bwd_kernel<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)ddst, ld, mask, dsrc, B, C, H, W);
+    else OCTA_FAIL(OCTA_ERR_BAD_ARG, "octa_noise_clip_s2d_bwd: bad dtype");
+    OCTA_CHECK_LAUNCH("noise_clip_s2d_bwd");
+    return OCTA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ spectral norm (single block)
 __device__ float block_total(float v, float* red) {   // all threads get the block-wide sum
     v = wave_sum(v);

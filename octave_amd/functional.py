@@ -1786,6 +1786,43 @@ class NoiseClipFn(Function):
         return g, None, None, None
 
 
+class NoiseClipS2dFn(Function):
+    """InstanceNoise (+clip) written SPACE-TO-DEPTH for the k4 s2 p1 conv behind it (blocks.py:42-46): (B, C, H, W) fp32 ->
+    NHWC (B, 4C, H/2+1, W/2+1) with channel (dy*2+dx)*C + c of pixel (Y, X) = the value at (2Y+dy-1, 2X+dx-1), zero outside the
+    image.  That conv is then a k2 s1 p0 conv (s2d_weight): same sums, no channel padding (2 -> 8 channels in the plain layout:
+    4x the bytes and 4x the MFMA K of the discriminator's first layer)."""
+
+    @staticmethod
+    def forward(ctx, y, noise, dtype, clip=True):
+        _require_gpu(y)
+        y = y.float()
+        B, C, H, W = y.shape
+        out = nhwc_empty(B, 4 * C, H // 2 + 1, W // 2 + 1, dtype, y.device, pad_written=True)
+        mask = torch.empty((B, C, H, W), dtype=torch.uint8, device=y.device)
+        lib().octa_noise_clip_s2d_fwd(_p(y), _strides4(y), _p(noise), _p(out), _p(mask), B, C, H, W, nhwc_ld(out), _dt(dtype), int(bool(clip)), _st())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        (mask,) = ctx.saved_tensors
+        B, C, H, W = mask.shape
+        d = to_nhwc(d)
+        g = torch.empty((B, C, H, W), dtype=torch.float32, device=d.device)
+        lib().octa_noise_clip_s2d_bwd(_p(d), nhwc_ld(d), _p(mask), _p(g), B, C, H, W, _dt(d), _st())
+        return g, None, None, None
+
+
+def s2d_weight(w: Tensor) -> Tensor:
+    """(O, C, 4, 4) weight of a k4 s2 p1 conv -> (O, 4C, 2, 2) weight of the equivalent k2 s1 p0 conv on NoiseClipS2dFn's output:
+    w2[o, (dy*2+dx)*C + c, i, j] = w[o, c, 2i+dy, 2j+dx].  Plain tensor ops: autograd carries the gradient back to w."""
+    O, C, KH, KW = w.shape
+    if (KH, KW) != (4, 4):
+        raise OctaError("s2d_weight: 4 x 4 kernels only")
+    return w.reshape(O, C, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(O, 4 * C, 2, 2)
+
+
 class ToNhwcFn(Function):
     """NCHW fp32 map -> NHWC activation of `dtype` (buffer padded to a multiple of 8 channels)."""
 

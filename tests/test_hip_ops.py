@@ -1362,3 +1362,35 @@ def test_discriminator_backward_without_derivative_kernels(dev):
     for i, (a, b) in enumerate(zip(grads[True], grads[False])):
         scale = float(b.abs().max()) + 1e-12
         check(f"discriminator gradient {i}", a, b, 5e-2, 2e-2 * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminator_first_conv_on_the_space_to_depth_image(dev, dtype):
+    """The first discriminator conv (k4 s2 p1 on 2 channels) as a k2 s1 conv on NoiseClipS2dFn's output (OCTA_S2D_CONV0, default on)
+    against the plain layout: logits, map gradients and every parameter gradient (fp32: 1e-5; bf16: rounding of two summation orders)."""
+    from octave_amd import functional as F_
+    import architectures.discriminator.blocks as blk
+    torch.manual_seed(5)
+    B, H = 2, 64
+    net = blk.DiscriminatorBlock(torch.Size((B, 2, H, H)), True, depth=4).to(dev).train()
+    net.compute_dtype = dtype
+    maps = [torch.rand(B, 2, H >> i, H >> i, device=dev, requires_grad=True) for i in range(5)]
+    res = {}
+    try:
+        for on in (True, False):
+            blk._S2D_CONV0 = on
+            st = {k: v.clone() for k, v in net.state_dict().items()}
+            torch.manual_seed(11)
+            net.zero_grad(set_to_none=True)
+            for m in maps:
+                m.grad = None
+            out = net(maps)
+            (out.float() ** 2).sum().backward()
+            res[on] = [out.detach().clone()] + [m.grad.clone() for m in maps] + [p.grad.clone() for p in net.parameters()]
+            net.load_state_dict(st)
+    finally:
+        blk._S2D_CONV0 = True
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        scale = float(b.abs().max()) + 1e-12
+        check(f"s2d vs plain, tensor {i}", a, b, tol, tol * scale)

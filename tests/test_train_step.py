@@ -754,12 +754,14 @@ def test_packed_operands_follow_the_optimiser_eager_and_graph():
     weights after eager steps AND after replayed steps (the refresh is part of the captured Adam graph)."""
     from octave_amd import functional as F_
     from octave_amd.train import TrainStep, mask_pyramid
+    import architectures.discriminator.blocks as blk
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     B, H = 4, 64
     net = _net(B, H, dev, seed_fill=False)
     x, ys, real = _inputs(B, H, dev)
     pyr = mask_pyramid(real)
+    s2d_was, blk._S2D_CONV0 = blk._S2D_CONV0, False      # conv_0 in its plain k4 s2 form: the layer whose Parameter owns a dgrad_taps operand
     st = TrainStep(net, lr=1e-3, compute_dtype=torch.bfloat16)
 
     def check(tag):
@@ -789,6 +791,7 @@ def test_packed_operands_follow_the_optimiser_eager_and_graph():
         kinds, bad = check("graph")
         assert not bad, bad
     finally:
+        blk._S2D_CONV0 = s2d_was
         st.close()
 
 
