@@ -697,6 +697,288 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 //     PERSIST = 0: one position per workgroup, gridDim.x = 8 * (longest XCD sequence).
 // blockIdx & 7 is used as the XCD label (a performance assumption only: every position is processed exactly once whatever the
 // placement).
+// wgrad9a: wgrad9 with FOUR waves of 128(N) x 128(K) per workgroup -- one wave per SIMD, 256 accumulator registers in the unified file
+// (round 5; octa_tuning_set(9, 2)).  Why: per 32-pixel stage a workgroup of wgrad9 reads 96 KB of fragments from LDS and its LDS-DMA
+// writes 32 KB, and 128 KB per 1024 matrix-pipe cycles IS the LDS bandwidth of a CU (128 B / clk): the kernel sits on the LDS roofline at
+// 100 % MFMA, which is why it saturates near 58-60 %.  A 128 x 128 wave tile needs (4 + 4) fragment blocks per 16 MFMAs instead of
+// (4 + 2) per 8: 64 KB of fragment reads per stage, -25 % LDS traffic.  Same LDS image, DMA image, ring, barrier protocol and epilogue
+// mapping as wgrad9; a wave now issues 8 LDS-DMA instructions per stage and interleaves one transposed read pair with every MFMA.
+__device__ __forceinline__ void wg9s_wait16(wg_u32x2_t (&a)[4][2], wg_u32x2_t (&b)[4][2]);
+template <int HS>
+__device__ __forceinline__ void wg9a_load_half(const unsigned (&aa)[4], const unsigned (&ba)[4], wg_u32x2_t (&af)[4][2], wg_u32x2_t (&bf)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i][0] = wg_tr<HS * 8192>(aa[i]); af[i][1] = wg_tr<HS * 8192 + 2048>(aa[i]); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bf[j][0] = wg_tr<HS * 8192>(ba[j]); bf[j][1] = wg_tr<HS * 8192 + 2048>(ba[j]); }
+}
+
+template <int F16>
+__global__ __launch_bounds__(256) void wgrad9a_kernel(const WgBatch batch) {
+    constexpr int BN = 256, BK = 256, MT = 32, SLOTS = 4;
+    constexpr int RB = 512, IMG = MT * RB, SBYTES = 2 * IMG;
+    constexpr int LPR = 32, RPI = 2, IPW = 4;                      // lanes per row, rows per DMA instruction, instructions per wave and image
+    constexpr int LPT = 2 * IPW;                                   // DMA instructions per wave and stage (8)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SLOTS * SBYTES + BN * 4];
+    float* const sBias = (float*)(smem + SLOTS * SBYTES);
+
+    const int total = gridDim.x, Lb = blockIdx.x;
+    const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
+    const int Lp = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jq;
+    int pi = 0;
+    for (int i = 1; i < batch.n; ++i) if (batch.p[i].blockStart <= Lp) pi = i;
+    const WgProb& Pk = batch.p[pi];
+    const int tilesN = Pk.tilesN, tilesK = Pk.tilesK, groups = Pk.groups, mPerSplit = Pk.mPerSplit, Mtot = Pk.M;
+    const int Ng = Pk.Ng, Kpad = Pk.Kpad, Cg = Pk.Cg, CgReal = Pk.CgReal, KW = Pk.KW;
+    const int H = Pk.H, W = Pk.W, OH = Pk.OH, OW = Pk.OW, stride = Pk.stride, pad = Pk.pad;
+    const int ldx = Pk.ldx, ldy = Pk.ldy;
+    const unsigned short* const xbase = Pk.x;
+    const unsigned short* const dybase = Pk.dy;
+    int bid = Lp - Pk.blockStart;
+    const int nt = bid % tilesN; bid /= tilesN;
+    const int kt = bid % tilesK; bid /= tilesK;
+    const int g = bid % groups;
+    const int sp = bid / groups;
+    const int n0 = nt * BN, k0 = kt * BK;
+    const int mbeg = sp * mPerSplit;
+    const int mend = min(Mtot, mbeg + mPerSplit);
+    const int nsteps = (mend - mbeg + MT - 1) / MT;
+    if (nsteps <= 0) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave >> 1, wk = wave & 1;                       // 2 x 2 waves of 128(N) x 128(K)
+    const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
+
+    // ---- DMA roles: instruction i of this wave fills LDS rows (i*4 + wave)*2 + lane/32 of an image (a lane's rows differ by 8: same f)
+    const int drow = wave * RPI + lane / LPR;
+    const int dpos = lane % LPR;
+    const int df_ = (drow & 3) << 1;
+    const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
+    const bool pvalid = (n0 + dchunk * 8) < Ng;
+    const unsigned long pstep = pvalid ? (unsigned long)((long)MT * ldy * 2) : 0ul;
+    unsigned long pptr[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+        pptr[i] = pvalid ? (unsigned long)(dybase + ((long)(mbeg + drow + i * 4 * RPI) * ldy + Pk.yoff + g * Ng + n0 + dchunk * 8)) : zaddr;
+    const int kel = k0 + dchunk * 8;
+    const bool kvalid = kel < Kpad;
+    const int qtap = kel / Cg, qcc = kel - qtap * Cg;
+    const int qkh = qtap / KW, qkw = qtap - qkh * KW;
+    const int qdh = qkh - pad, qdw = qkw - pad;
+    const unsigned long qbase = (unsigned long)(xbase + (Pk.xoff + g * CgReal + qcc));
+    const bool plain = (Pk.KH == 1 && KW == 1 && pad == 0 && stride == 1);
+    const int ldx2 = ldx * 2;
+    const int dq = MT / OW, dr = MT - dq * OW;
+    const int sdr = stride * dr, sdq = stride * dq, OWs = OW * stride, OHs = OH * stride;
+    const int thrW = OWs + qdw, thrH = OHs + qdh;
+    const int dpix = sdq * W + sdr, cW = stride * W - OWs, cH = H * W - OHs * W;
+    int qih[IPW], qiw[IPW], qpix[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int m = mbeg + drow + i * 4 * RPI;
+        const int ow = m % OW, tq = m / OW, oh = tq % OH, b = tq / OH;
+        qih[i] = oh * stride + qdh; qiw[i] = ow * stride + qdw;
+        qpix[i] = plain ? m : (b * H + qih[i]) * W + qiw[i];
+    }
+    const unsigned sbase = wg_lds_addr(smem);
+    auto issueP = [&](int i, int slot, int mcur) {
+        const bool ok = (mcur + drow + i * 4 * RPI) < mend;
+        const unsigned long src = ok ? pptr[i] : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + (i * 4 + wave) * 1024)));
+        pptr[i] += pstep;
+    };
+    auto issueQ = [&](int i, int slot, int mcur) {
+        const bool ok = kvalid & ((mcur + drow + i * 4 * RPI) < mend) & ((unsigned)qih[i] < (unsigned)H) & ((unsigned)qiw[i] < (unsigned)W);
+        const unsigned off = (unsigned)__mul24(qpix[i], ldx2);
+        const unsigned long a = qbase + (unsigned long)off;
+        const unsigned long src = ok ? a : zaddr;
+        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SBYTES + IMG + (i * 4 + wave) * 1024)));
+        qiw[i] += sdr;
+        const bool c1 = qiw[i] >= thrW;
+        qiw[i] -= c1 ? OWs : 0;
+        qih[i] += sdq + (c1 ? stride : 0);
+        const bool c2 = qih[i] >= thrH;
+        qih[i] -= c2 ? OHs : 0;
+        qpix[i] += dpix + (c1 ? cW : 0) + (c2 ? cH : 0);
+    };
+    auto issue = [&](int slot, int mcur) {
+        issueP(0, slot, mcur); issueP(1, slot, mcur); issueP(2, slot, mcur); issueP(3, slot, mcur);
+        issueQ(0, slot, mcur); issueQ(1, slot, mcur); issueQ(2, slot, mcur); issueQ(3, slot, mcur);
+    };
+
+    wg_f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- transposed fragment addressing as in wgrad9: block b = 32 channels = pairs 2 b, 2 b + 1
+    const int r = lane & 15, gq = lane >> 4;
+    const int frow = 8 * (gq >> 1) + (r >> 2);
+    const int fr = ((r >> 2) & 3) << 1;
+    const int cb = (r & 3) * 8;
+    unsigned abase[4], bbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = sbase + (unsigned)(frow * RB + ((((wn * 4 + i) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bbase[j] = sbase + (unsigned)(IMG + frow * RB + ((((wk * 4 + j) * 2 + (gq & 1)) ^ fr) << 5) + cb);
+
+    // ---- fused bias gradient (k-tile 0 only): thread = (16-byte chunk position, rows brow + 8 jj) of the dy stage image
+    float* const dbias = Pk.dbias;
+    const bool do_bias = (dbias != nullptr) && (kt == 0);
+    const int brow = t / LPR, bpos = t % LPR;                      // brow 0 .. 7
+    const int bf_ = (brow & 3) << 1;
+    const int bchunk = (((bpos >> 1) ^ bf_) << 1) | (bpos & 1);
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    if (do_bias && t < BN) sBias[t] = 0.f;
+
+    issue(0, mbeg);
+    if (nsteps > 1) issue(1, mbeg + MT);
+    if (nsteps > 2) issue(2, mbeg + 2 * MT);
+    if (nsteps > 2) wg_wait_vmcnt<2 * LPT>(); else if (nsteps > 1) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    wg_u32x2_t afX[4][2], bfX[4][2], afY[4][2], bfY[4][2];
+    wg9a_load_half<0>(abase, bbase, afX, bfX);
+    wg9s_wait16(afX, bfX);
+#define WG9A_MMA(AF, BF, i, j)                                                                                                             \
+    WgMma32<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[i][j])
+#define WG9A_TR(F, i, HS, ad) { F[i][0] = wg_tr<HS * 8192>(ad); F[i][1] = wg_tr<HS * 8192 + 2048>(ad); }
+#define WG9A_SB __builtin_amdgcn_sched_barrier(0)
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
+    for (int it = 0; it < nsteps; ++it) {
+        const int rem = nsteps - 1 - it;
+        const bool more = rem >= 3;
+        const int s3 = (it + 3) & (SLOTS - 1), m3 = mbeg + (it + 3) * MT;
+        const unsigned so = (unsigned)((it & (SLOTS - 1)) * SBYTES);
+        const unsigned sn = (unsigned)(((it + 1) & (SLOTS - 1)) * SBYTES);
+        if (do_bias) {
+            const unsigned char* sP = smem + so;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint4 v = *(const uint4*)(sP + (brow + jj * 8) * RB + bpos * 16);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += WgMma<F16>::cvt((unsigned short)(w4[e] & 0xffffu));
+                    bsum[2 * e + 1] += WgMma<F16>::cvt((unsigned short)(w4[e] >> 16));
+                }
+            }
+        }
+        WG9A_SB;
+        // ---- half-stage 0 (fragments X): 16 MFMAs; behind them the 8 fragment blocks of half-stage 1 (Y) and the dy half of the DMA
+        WG9A_MMA(afX, bfX, 0, 0); WG9A_TR(afY, 0, 1, abase[0] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 1, 0); WG9A_TR(afY, 1, 1, abase[1] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 2, 0); WG9A_TR(afY, 2, 1, abase[2] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 3, 0); WG9A_TR(afY, 3, 1, abase[3] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 0, 1); WG9A_TR(bfY, 0, 1, bbase[0] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 1, 1); WG9A_TR(bfY, 1, 1, bbase[1] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 2, 1); WG9A_TR(bfY, 2, 1, bbase[2] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 3, 1); WG9A_TR(bfY, 3, 1, bbase[3] + so); WG9A_SB;
+        WG9A_MMA(afX, bfX, 0, 2); if (more) issueP(0, s3, m3); WG9A_SB;
+        WG9A_MMA(afX, bfX, 1, 2); WG9A_SB;
+        WG9A_MMA(afX, bfX, 2, 2); if (more) issueP(1, s3, m3); WG9A_SB;
+        WG9A_MMA(afX, bfX, 3, 2); WG9A_SB;
+        WG9A_MMA(afX, bfX, 0, 3); if (more) issueP(2, s3, m3); WG9A_SB;
+        WG9A_MMA(afX, bfX, 1, 3); WG9A_SB;
+        WG9A_MMA(afX, bfX, 2, 3); if (more) issueP(3, s3, m3); WG9A_SB;
+        WG9A_MMA(afX, bfX, 3, 3); WG9A_SB;
+        if (rem >= 3) wg_wait_vmcnt<LPT + IPW>(); else if (rem == 2) wg_wait_vmcnt<LPT>(); else wg_wait_vmcnt<0>();   // stage it + 1 has landed (this wave's part)
+        wg9s_wait16(afY, bfY);
+        __builtin_amdgcn_s_barrier();
+        WG9A_SB;
+        // ---- half-stage 1 (fragments Y); fetch half-stage 0 of stage it + 1 (X); the x half of the DMA
+        WG9A_MMA(afY, bfY, 0, 0); WG9A_TR(afX, 0, 0, abase[0] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 1, 0); WG9A_TR(afX, 1, 0, abase[1] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 2, 0); WG9A_TR(afX, 2, 0, abase[2] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 3, 0); WG9A_TR(afX, 3, 0, abase[3] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 0, 1); WG9A_TR(bfX, 0, 0, bbase[0] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 1, 1); WG9A_TR(bfX, 1, 0, bbase[1] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 2, 1); WG9A_TR(bfX, 2, 0, bbase[2] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 3, 1); WG9A_TR(bfX, 3, 0, bbase[3] + sn); WG9A_SB;
+        WG9A_MMA(afY, bfY, 0, 2); if (more) issueQ(0, s3, m3); WG9A_SB;
+        WG9A_MMA(afY, bfY, 1, 2); WG9A_SB;
+        WG9A_MMA(afY, bfY, 2, 2); if (more) issueQ(1, s3, m3); WG9A_SB;
+        WG9A_MMA(afY, bfY, 3, 2); WG9A_SB;
+        WG9A_MMA(afY, bfY, 0, 3); if (more) issueQ(2, s3, m3); WG9A_SB;
+        WG9A_MMA(afY, bfY, 1, 3); WG9A_SB;
+        WG9A_MMA(afY, bfY, 2, 3); if (more) issueQ(3, s3, m3); WG9A_SB;
+        WG9A_MMA(afY, bfY, 3, 3); WG9A_SB;
+        wg9s_wait16(afX, bfX);
+        WG9A_SB;
+        // (the 256 accumulators fill the AGPR half of the register file exactly: naming them here keeps the allocator from routing two
+        // blocks through scratch around the back edge)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+    }
+#undef WG9A_MMA
+#undef WG9A_TR
+#undef WG9A_SB
+    OCTA_STAMP_END(octa_diag_stamps_wgrad9)
+
+    float* const part = Pk.part ? Pk.part + (long)sp * Pk.part_slice : nullptr;
+    if (do_bias) {
+        __syncthreads();
+        float* const bred = (float*)smem;                  // [256 / LPR][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[brow * BN + bchunk * 8 + e] = bsum[e];
+        __syncthreads();
+        if (t < BN) {
+            float v = 0.f;
+            for (int rg = 0; rg < 256 / LPR; ++rg) v += bred[rg * BN + t];
+            sBias[t] = v;
+        }
+        if (t < BN && n0 + t < Ng) {
+            if (part) part[(long)groups * Ng * Kpad + g * Ng + n0 + t] = sBias[t];
+            else atomicAdd(dbias + g * Ng + n0 + t, sBias[t]);
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk * 128 + j * 32 + (lane & 31);
+            if (k >= Kpad) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_barrier(0);          // one block at a time: the accumulators leave the AGPRs 16 at a time, not all 256 at once
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (n < Ng) part[(long)(g * Ng + n) * Kpad + k] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    float* const dw = Pk.dw;
+    const long s_o = Pk.s_o, s_i = Pk.s_i, s_h = Pk.s_h, s_w = Pk.s_w;
+    const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 128 + j * 32 + lc;
+        if (k >= Kpad) continue;
+        const int tap = k / Cg, ci = k - tap * Cg;
+        if (ci >= CgReal) continue;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const long koff = (long)ci * s_i + (long)kh * s_h + (long)kw * s_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);              // (as above)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (n < Ng) atomicAdd(dw + (long)(g * Ng + n) * s_o + koff, acc[i][j][e]);
+            }
+        }
+    }
+}
+
 // wgrad9s: wgrad9 on v_mfma_f32_16x16x32 (round 5; octa_tuning_set(9, 1)).  3.12 showed a long wgrad9 launch to be power-limited
 // (in-kernel clock 1.35-1.6 GHz): under that cap the 16x16x32 shape is the one the guide measures 1.12-1.15x ahead of 32x32x16
 // (MI355X_MICROARCH.md, DVFS give-back 7).  Same batch interface, tile (256 x 256, 8 waves of 128(N) x 64(K)), 32-pixel stages, 4-slot
@@ -1449,11 +1731,13 @@ static int wg9_launch(std::vector<WgPlan>& plans, hipStream_t st) {
                 case 29: wgrad9_kernel<0, 1, 29><<<(unsigned)nblk, 512, 0, st>>>(batch); break;
                 default: OCTA_FAIL(OCTA_ERR_BAD_ARG, "wgrad9 ablation %d is not built", g_wg9_ablate);
             }
-        } else if (wg9_shape16()) wgrad9s_kernel<F16><<<(unsigned)nblk, 512, 0, st>>>(batch);
+        } else if (wg9_shape16() == 2) wgrad9a_kernel<F16><<<(unsigned)nblk, 256, 0, st>>>(batch);
+        else if (wg9_shape16()) wgrad9s_kernel<F16><<<(unsigned)nblk, 512, 0, st>>>(batch);
         else if (stagger) wgrad9_kernel<F16, 1><<<(unsigned)nblk, 512, 0, st>>>(batch);
         else wgrad9_kernel<F16, 0><<<(unsigned)nblk, 512, 0, st>>>(batch);
         OCTA_CHECK_LAUNCH("wgrad9");
-        octa_note_conv_kernel(wg9_shape16() ? (F16 ? "wgrad9s_kernel<f16,256x256,16x16x32>" : "wgrad9s_kernel<bf16,256x256,16x16x32>")
+        octa_note_conv_kernel(wg9_shape16() == 2 ? (F16 ? "wgrad9a_kernel<f16,256x256,4 waves>" : "wgrad9a_kernel<bf16,256x256,4 waves>")
+                              : wg9_shape16() ? (F16 ? "wgrad9s_kernel<f16,256x256,16x16x32>" : "wgrad9s_kernel<bf16,256x256,16x16x32>")
                                             : (F16 ? "wgrad9_kernel<f16,256x256>" : "wgrad9_kernel<bf16,256x256>"));
         i0 = i1;
     }
@@ -1639,7 +1923,7 @@ void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
 void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
-    if (key == 9) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 9 = MFMA shape of the 256 x 256 weight-gradient kernel: 0 = 32x32x16 (wgrad9), 1 = 16x16x32 (wgrad9s)"); g_wg9_shape16 = value; return OCTA_OK; }
+    if (key == 9) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 9 = MFMA shape of the 256 x 256 weight-gradient kernel: 0 = 32x32x16 (wgrad9), 1 = 16x16x32 (wgrad9s), 2 = 32x32x16 with four waves of 128 x 128 (wgrad9a)"); g_wg9_shape16 = value; return OCTA_OK; }
     if (key == 8) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 8 = wgrad9 schedule: 0 rounds of one split length, 1 per-class splits + XCD-interleaved sequences, 2 the same, persistent"); g_wg9_sched = value; return OCTA_OK; }
     if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }
     if (key == 6) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 6 = halo8 patch image: 1 packed (bank-conflict-free), 0 linear"); octa_set_halo8_packed(value); return OCTA_OK; }

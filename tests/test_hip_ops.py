@@ -1102,7 +1102,7 @@ def test_resident_weight_upshuffle_vs_torch(dev, dtype):
     check("res upshuffle", y, ref, t["rtol"], t["atol"] * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 3])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
@@ -1112,7 +1112,7 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
     partial tiles and the batch ends in fold launches (two of them: more than 16 jobs would need a third); the gradients must
     also be bit-identical between two runs.  sched: the schedule of the 256 x 256 kernel (octa_tuning_set(8, .)): 0 = rounds of one
     split length (wgrad9), 1 = per-class splits on XCD-interleaved sequences (wgrad9x), 2 = the same, persistent; 3 = wgrad9's schedule
-    on v_mfma_f32_16x16x32 (wgrad9s, octa_tuning_set(9, 1))."""
+    on v_mfma_f32_16x16x32 (wgrad9s, octa_tuning_set(9, 1)); 4 = four waves of 128 x 128 per workgroup (wgrad9a, octa_tuning_set(9, 2))."""
     import ctypes
     from octave_amd import functional as F_
     from octave_amd._lib import WgradJob, lib
@@ -1153,13 +1153,13 @@ def test_wgrad_batch_vs_torch(dev, dtype, fold, sched):
     if fold:
         L.octa_tuning_set(4, 1)       # the batched kernels too (off by default: no gain in situ)
     L.octa_tuning_set(8, sched if sched < 3 else 0)
-    L.octa_tuning_set(9, 1 if sched == 3 else 0)
+    L.octa_tuning_set(9, {3: 1, 4: 2}.get(sched, 0))
     try:
         L.octa_conv2d_wgrad_batch(jobs, len(cases), *F_._fold_ws_args(), torch.cuda.current_stream().cuda_stream)
         if sched in (1, 2) and not fold:
             assert "wgrad9x" in L.octa_last_conv_kernel().decode() and ("persistent" in L.octa_last_conv_kernel().decode()) == (sched == 2)
-        if sched == 3 and not fold:
-            assert "wgrad9s" in L.octa_last_conv_kernel().decode()
+        if sched in (3, 4) and not fold:
+            assert ("wgrad9s" if sched == 3 else "wgrad9a") in L.octa_last_conv_kernel().decode()
         first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in keep]
         if fold:
             for _, _, dw, db in keep:
