@@ -698,10 +698,10 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(const WgBatch batch) {
 // blockIdx & 7 is used as the XCD label (a performance assumption only: every position is processed exactly once whatever the
 // placement).
 // wgrad9a: wgrad9 with FOUR waves of 128(N) x 128(K) per workgroup -- one wave per SIMD, 256 accumulator registers in the unified file
-// (round 5; octa_tuning_set(9, 2)).  Why: per 32-pixel stage a workgroup of wgrad9 reads 96 KB of fragments from LDS and its LDS-DMA
-// writes 32 KB, and 128 KB per 1024 matrix-pipe cycles IS the LDS bandwidth of a CU (128 B / clk): the kernel sits on the LDS roofline at
-// 100 % MFMA, which is why it saturates near 58-60 %.  A 128 x 128 wave tile needs (4 + 4) fragment blocks per 16 MFMAs instead of
-// (4 + 2) per 8: 64 KB of fragment reads per stage, -25 % LDS traffic.  Same LDS image, DMA image, ring, barrier protocol and epilogue
+// (round 5; octa_tuning_set(9, 2)).  Why it was tried: per 32-pixel stage a workgroup of wgrad9 reads 96 KB of fragments from LDS (96 B / clk
+// at full MFMA rate: 37 % of the LDS array) and issues those reads between its MFMAs.  A 128 x 128 wave tile needs (4 + 4) fragment blocks per
+// 16 MFMAs instead of (4 + 2) per 8: -25 % fragment reads per FLOP, one read pair per MFMA.  Measured 9-22 % SLOWER: with one
+// wave per SIMD nothing covers a wave's barrier and vmcnt waits.  Same LDS image, DMA image, ring, barrier protocol and epilogue
 // mapping as wgrad9; a wave now issues 8 LDS-DMA instructions per stage and interleaves one transposed read pair with every MFMA.
 __device__ __forceinline__ void wg9s_wait16(wg_u32x2_t (&a)[4][2], wg_u32x2_t (&b)[4][2]);
 template <int HS>
