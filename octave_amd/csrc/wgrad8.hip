@@ -1759,6 +1759,7 @@ static int wg_num_cus() {
     }
     return n;
 }
+#include "wgrad2d.hpp"
 // Stage-units until the last XCD is done.  Every XCD runs its own sequence (problem p contributes the x-th eighth of its nb[p] blocks
 // of len[p] stages, + E for prologue and epilogue) on SL slots: dealt statically (persistent) or to the slot that frees first.
 static int64_t wg9x_model(const std::vector<int64_t>& nb, const std::vector<int64_t>& len, const int* off, int SL, bool persist, int E) {
@@ -1923,6 +1924,7 @@ void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
 void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
+    if (key == 10) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 10 = 3x3 stride-1 weight gradients of exact 5 x 25 geometries on the 2-D patch kernel (0 / 1)"); g_wg2d = value; return OCTA_OK; }
     if (key == 9) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 9 = MFMA shape of the 256 x 256 weight-gradient kernel: 0 = 32x32x16 (wgrad9), 1 = 16x16x32 (wgrad9s), 2 = 32x32x16 with four waves of 128 x 128 (wgrad9a)"); g_wg9_shape16 = value; return OCTA_OK; }
     if (key == 8) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 8 = wgrad9 schedule: 0 rounds of one split length, 1 per-class splits + XCD-interleaved sequences, 2 the same, persistent"); g_wg9_sched = value; return OCTA_OK; }
     if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }
@@ -1947,7 +1949,9 @@ static int wg8_variant(const octa_wgrad_job& j) {
 }
 extern "C" size_t octa_wgrad_job_class(const octa_wgrad_job* job) {
     static const bool off = getenv("OCTA_NO_WGRAD8") != nullptr;
-    if (!job || off || !wg8_eligible(*job)) return 0;
+    if (!job || off) return 0;
+    if (wg2d_eligible(*job)) return 4;            // the 2-D patch kernel: its own flush group (one launch per job)
+    if (!wg8_eligible(*job)) return 0;
     return 1 + wg8_variant(*job);
 }
 
@@ -1966,6 +1970,11 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, float*
     } fold(st, ws_bytes > 0 ? ws : nullptr, ws_bytes / 4);
     for (int i = 0; i < n; ++i) {
         const octa_wgrad_job& j = jobs[i];
+        if (!off && wg2d_eligible(j)) {
+            const int rc = wg2d_launch(j, st);
+            if (rc) return rc;
+            continue;
+        }
         if (off || !wg8_eligible(j)) {
             const int rc = octa_conv2d_wgrad(&j.d, j.x, j.dy, j.dw, j.dw_strides, j.dbias, stream);
             if (rc) return rc;

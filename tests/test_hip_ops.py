@@ -1394,3 +1394,37 @@ def test_discriminator_first_conv_on_the_space_to_depth_image(dev, dtype):
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         scale = float(b.abs().max()) + 1e-12
         check(f"s2d vs plain, tensor {i}", a, b, tol, tol * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wgrad2d_patch_kernel_vs_torch(dev, dtype):
+    """wgrad2d (octa_tuning_set(10, 1)): the 2-D patch weight-gradient kernel for 3x3 stride-1 layers of exact 5 x 25 geometries, one job per
+    launch through octa_conv2d_wgrad_batch, against torch's CPU gradients: one patch, several patches with an M-split, two image
+    columns of patches, a grouped layer, an N tail (384 output channels = 1.5 tiles), 96 input channels (3 slices)."""
+    import ctypes
+    from octave_amd import functional as F_
+    from octave_amd._lib import WgradJob, lib
+    L = lib()
+    cases = [(2, 64, 10, 25, 256, 1), (4, 64, 25, 50, 256, 1), (1, 32, 5, 50, 128, 1), (2, 128, 10, 25, 512, 2), (2, 96, 5, 25, 384, 1), (3, 64, 15, 100, 256, 1)]
+    gen = torch.Generator().manual_seed(21)
+    L.octa_tuning_set(10, 1)
+    try:
+        for (B, Cin, H, W, Cout, g) in cases:
+            x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+            dy = torch.randn(B, Cout, H, W, generator=gen).to(dtype).float()
+            xd, dyd = F_.to_nhwc(x.to(dev), dtype=dtype, cpad=Cin if g > 1 else F_.round8(Cin)), F_.to_nhwc(dy.to(dev), dtype=dtype, cpad=Cout)
+            dw = torch.zeros(Cout, Cin // g, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+            d = F_._desc(B, H, W, H, W, Cin, Cout, 3, 3, 1, 1, g, F_.nhwc_ld(xd), F_.nhwc_ld(dyd), dtype)
+            jobs = (WgradJob * 1)()
+            ctypes.memmove(ctypes.byref(jobs[0].d), ctypes.byref(d), ctypes.sizeof(d))
+            jobs[0].x, jobs[0].dy, jobs[0].dw, jobs[0].dbias = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None
+            for a in range(4):
+                jobs[0].dw_strides[a] = dw.stride(a)
+            assert int(L.octa_wgrad_job_class(ctypes.byref(jobs[0]))) == 4
+            L.octa_conv2d_wgrad_batch(jobs, 1, None, 0, torch.cuda.current_stream().cuda_stream)
+            assert "wgrad2d" in L.octa_last_conv_kernel().decode()
+            wr = torch.zeros(Cout, Cin // g, 3, 3, requires_grad=True)
+            torch.nn.functional.conv2d(x, wr, None, 1, 1, 1, g).backward(dy)
+            check(f"wgrad2d {(B, Cin, H, W, Cout, g)}", dw, wr.grad, 0, 3e-4 * float(wr.grad.abs().max()))
+    finally:
+        L.octa_tuning_set(10, 0)

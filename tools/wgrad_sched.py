@@ -1,7 +1,7 @@
 """The four wgrad9 launches of one training step (BASELINE config 1: B = 16, 400 x 400, bf16; compositions read from an
 OCTA_WG_LOG=1 run of bench.py), replayed with random operands under the three schedules of the 256 x 256 weight-gradient kernel
 (octa_tuning_set(8, mode): 0 = rounds of one split length, 1 = per-class splits + XCD-interleaved sequences, one block per
-workgroup, 2 = the same, persistent; mode 3 here = schedule 0 on v_mfma_f32_16x16x32, octa_tuning_set(9, 1); mode 4 = four waves of 128 x 128, octa_tuning_set(9, 2)).  Every timing is one launch behind a 512 MB cache-evicting sweep, the modes alternating;
+workgroup, 2 = the same, persistent; mode 3 here = schedule 0 on v_mfma_f32_16x16x32, octa_tuning_set(9, 1); mode 4 = four waves of 128 x 128, octa_tuning_set(9, 2); mode 5 = the bias-free 3x3 layers on the 2-D patch kernel wgrad2d, octa_tuning_set(10, 1)).  Every timing is one launch behind a 512 MB cache-evicting sweep, the modes alternating;
 results of modes 1 / 2 are checked against mode 0 first.
 Usage: python tools/wgrad_sched.py [check] [time] [rounds=N]"""
 import ctypes, os, sys
@@ -84,7 +84,7 @@ def main():
         if "check" in args:
             ref = None
             for m in [0] + [m for m in modes if m]:
-                L.octa_tuning_set(8, m if m < 3 else 0); L.octa_tuning_set(9, {3: 1, 4: 2}.get(m, 0))
+                L.octa_tuning_set(8, m if m < 3 else 0); L.octa_tuning_set(9, {3: 1, 4: 2}.get(m, 0)); L.octa_tuning_set(10, 1 if m == 5 else 0)
                 for t in dws:
                     t.zero_()
                 for t in dbs:
@@ -107,7 +107,7 @@ def main():
             kn = {}
             for rnd in range(rounds):
                 for m in modes:
-                    L.octa_tuning_set(8, m if m < 3 else 0); L.octa_tuning_set(9, {3: 1, 4: 2}.get(m, 0))
+                    L.octa_tuning_set(8, m if m < 3 else 0); L.octa_tuning_set(9, {3: 1, 4: 2}.get(m, 0)); L.octa_tuning_set(10, 1 if m == 5 else 0)
                     evict.zero_()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -122,7 +122,7 @@ def main():
                 tot[m] += med
                 out.append(f"mode {m}: median {med:7.1f} us min {v[0]:7.1f} ({fl / med / 1e6:6.1f} TF/s)")
             print(f"{lname:26s} | " + " | ".join(out), flush=True)
-    L.octa_tuning_set(8, 0); L.octa_tuning_set(9, 0)
+    L.octa_tuning_set(8, 0); L.octa_tuning_set(9, 0); L.octa_tuning_set(10, 0)
     if "time" in args:
         print("sum of medians: " + ", ".join(f"mode {m}: {tot[m]:.1f} us" for m in modes), flush=True)
     print("ALL OK" if ok else "FAILURES", flush=True)
