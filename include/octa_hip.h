@@ -569,9 +569,10 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * positions of their sequences (wgrad9x); 2 = the same with one persistent workgroup per CU.  Same sums, different atomic order;
  * no gain measured in situ (the launch is power-limited: DESIGN.md 3.12).  key 9: MFMA shape of the 256 x 256 weight-gradient kernel:
  * 0 = v_mfma_f32_32x32x16 (wgrad9), 1 = v_mfma_f32_16x16x32 at the same wave tile (wgrad9s), 2 = 32x32x16 with FOUR waves of 128 x 128 per
- * workgroup, 256 accumulator registers per lane (wgrad9a: a quarter fewer LDS fragment reads per FLOP).  key 10: 1 = bias-free 3x3 stride-1
- * layers with H % 5 == 0, W % 25 == 0, Cin / groups % 32 == 0 run on the 2-D patch weight-gradient kernel (wgrad2d: one input patch shared by the
- * nine taps); 0 (default: measured slower). */
+ * workgroup, 256 accumulator registers per lane (wgrad9a: a quarter fewer LDS fragment reads per FLOP).  key 10: bias-free 3x3 stride-1
+ * layers with H % 5 == 0, W % 25 == 0, Cin / groups % 32 == 0 on the 2-D patch weight-gradient kernel (wgrad2d: one input patch shared by the
+ * nine taps): 0 = never, 1 = every such layer, 2 (default) = the ungrouped ones with >= 256 channels on either side, where it is measured ahead of
+ * wgrad9. */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

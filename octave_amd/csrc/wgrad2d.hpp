@@ -28,14 +28,14 @@ struct Wg2dArgs {
     int parts, ppp;            // M-split: workgroup part handles patches [part * ppp, min(npatch, (part + 1) * ppp))
     float* partws; long part_slice;      // optional private partial tiles (deterministic mode / fold): part p stores to partws + p * part_slice
     int Kpad;                  // 9 * Cg (layout of the partial tiles: [g * Ng + n][Kpad])
-    int abl;                   // timing-only ablations (OCTA_WG2D_ABL; results are wrong): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads, 8 = no epilogue
+    int rot, rot2;             // start offset (patches) per ci-tile / per co-tile inside the part
 };
 
 template <int F16>
 __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
     constexpr int PH = 5, PW = 25, NPIX = PH * PW, PR = PW + 2, PROWS = (PH + 2) * PR;     // 125 tile pixels, 27-pixel patch rows, 189 patch rows
-    constexpr int DYIMG = 128 * 512, PIMG = 192 * 64, SLOT = DYIMG + PIMG;                 // 64 KB + 12 KB
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SLOT];
+    constexpr int DYHALF = 64 * 512, PIMG = 192 * 64, POFF = 4 * DYHALF;                   // ring of four 32 KB half-images of dy, then two 12 KB patch slots
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * DYHALF + 2 * PIMG];
 
     const int total = gridDim.x, Lb = blockIdx.x;
     const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
@@ -46,55 +46,78 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
     const int part = bid / a.groups;
     const int n0 = tn * 256, c0 = tc * 32;
     const int pbeg = part * a.ppp, pend = min(a.npatch, pbeg + a.ppp);
-    if (pbeg >= pend) return;
+    const int nst = pend - pbeg;                                       // stages (= patches) of this workgroup
+    if (nst <= 0) return;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave & 3, kh = wave >> 2;
+    const bool dywave = wave < 8;                                      // waves 0-7 fill the dy ring, waves 8-11 the patch slots
     const unsigned long zaddr = (unsigned long)(const void*)wg8_zero_page;
     const unsigned sbase = wg_lds_addr(smem);
     const int H = a.H, W = a.W, ldx = a.ldx, ldy = a.ldy, Ng = a.Ng;
 
-    // ---- DMA roles.  dy image: instruction I = wave + 12 k (k = 0 .. 5, I < 64) fills rows 2 I, 2 I + 1 (32 lanes of 16 bytes each);
-    // (2 I + lane / 32) & 3 does not depend on k, so the involution's source chunk is one value per lane.
-    const int dhalf = lane >> 5, dpos = lane & 31;
-    const int p0 = 2 * wave + dhalf;                                   // tile pixel (= image row) of instruction k = 0; + 24 per k
-    const int df_ = (p0 & 3) << 1;
-    const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
-    const bool nvalid = (n0 + dchunk * 8) < Ng;
-    const unsigned long dyb = (unsigned long)(a.dy + (a.yoff + g * Ng + n0 + dchunk * 8));
-    // x patch: instruction `wave` fills patch rows 16 wave + lane / 4 (4 lanes of 16 bytes = the 32-channel slice)
-    const int q = 16 * wave + (lane >> 2);
-    const int qy = q / PR, qx = q - qy * PR;
-    const bool qrow_ok = q < PROWS;
-    const unsigned long xb = (unsigned long)(a.x + (a.xoff + g * a.Cg + c0 + (lane & 3) * 8));
+    // ---- DMA roles: one register set for both (a spill here is reloaded by scratch_load, whose compiler-placed s_waitcnt vmcnt(0) would wait for every
+    // LDS-DMA in flight).  dy half-image (64 rows): instruction I = wave + 8 k (k = 0 .. 3) of a dy wave fills local rows 2 I, 2 I + 1;
+    // (2 I + lane / 32) & 3 does not depend on k, so the involution's source chunk is one value per lane.  x patch: instruction I = (wave - 8) + 4 j
+    // (j = 0 .. 2) of a patch wave fills patch rows 16 I + lane / 4 (4 lanes of 16 bytes = the slice)
+    unsigned long gbase;               // the lane's first byte of row 0 of its tensor
+    int r0;                            // its row in instruction 0: + 16 per k (dy), + 64 per j (patch)
+    bool lane_ok = true;
+    if (dywave) {
+        const int dpos = lane & 31;
+        r0 = 2 * wave + (lane >> 5);
+        const int df_ = (r0 & 3) << 1;
+        const int dchunk = (((dpos >> 1) ^ df_) << 1) | (dpos & 1);
+        lane_ok = (n0 + dchunk * 8) < Ng;
+        gbase = (unsigned long)(a.dy + (a.yoff + g * Ng + n0 + dchunk * 8));
+    } else {
+        r0 = 16 * (wave & 3) + (lane >> 2);
+        gbase = (unsigned long)(a.x + (a.xoff + g * a.Cg + c0 + (lane & 3) * 8));
+    }
+    const unsigned ldy2 = (unsigned)ldy * 2u, ldx2 = (unsigned)ldx * 2u;
 
-    int pidx = pbeg;
-    int pb = pidx / (a.ty * a.tx);
-    int prem = pidx - pb * (a.ty * a.tx);
-    int pyi = prem / a.tx, pxi = prem - pyi * a.tx;
-    // One DMA instruction each.  The dy instructions of a stage are issued one per k16 step of the PREVIOUS stage (issue_dy, k = 0 .. 5) and the
-    // patch instruction behind step 6, not as one burst behind the barrier: the LDS-DMA path of a CU sustains ~25-40 GB/s with a ~1 us
-    // issue-to-landed latency (MI355X_MICROARCH.md, ldsdma-fill), and a 76 KB burst followed by a wait left it idle most of the stage
-    // (4.3 us per stage with nothing else in the loop).
-    int nbase = 0, npy = 0, npx = 0;                                   // next stage: first pixel of its patch; (row, column) of this lane's next dy row
-    auto begin_next = [&](int b, int yi, int xi) { nbase = (b * H + yi * PH) * W + xi * PW; npy = p0 / PW; npx = p0 - (p0 / PW) * PW; };
-    auto issue_dy = [&](int k, int slot) {
-        if (wave + 12 * k < 64) {
-            const bool ok = nvalid && (p0 + 24 * k) < NPIX;
-            const unsigned long src = ok ? dyb + (unsigned long)((unsigned)(nbase + npy * W + npx) * (unsigned)(ldy * 2)) : zaddr;   // (host: tensor < 4 GB)
-            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SLOT + (wave + 12 * k) * 1024)));
+    // The workgroups of one part read the same dy tiles and patches; walking them in lockstep puts every CU of the XCD on the same L2 lines at the
+    // same moment, so each ci-tile starts `rot` patches further on and wraps round inside the part
+    struct Pc { int b, y, x, i; };
+    auto at = [&](int i) { Pc c; c.i = i; c.b = i / (a.ty * a.tx); const int rem = i - c.b * (a.ty * a.tx); c.y = rem / a.tx; c.x = rem - c.y * a.tx; return c; };
+    const Pc cbeg = at(pbeg);
+    auto adv = [&](Pc c) {
+        if (++c.i == pend) return cbeg;
+        if (++c.x == a.tx) { c.x = 0; if (++c.y == a.ty) { c.y = 0; ++c.b; } }
+        return c;
+    };
+    const Pc c0p = at(pbeg + (tc * a.rot + tn * a.rot2) % nst);
+    Pc c1 = adv(c0p), c2 = adv(c1);
+
+    // one half-image of dy: 4 instructions of this (dy) wave.  p / 25 = (p * 41) >> 10 for p < 128
+    auto issue_dy_half = [&](Pc c, int h, int slot) {
+        const int base = (c.b * H + c.y * PH) * W + c.x * PW;
+        int rr = r0;
+        asm volatile("" : "+v"(rr));                                   // recompute the rows' offsets here: hoisted out of the loop they cost 8 registers, and spills
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 64 * h + 16 * k + rr, py = (p * 41) >> 10, px = p - py * PW;
+            const bool ok = lane_ok && p < NPIX;
+            const unsigned long src = ok ? gbase + (unsigned long)((unsigned)(base + py * W + px) * ldy2) : zaddr;            // (host: tensor < 4 GB)
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * DYHALF + (wave + 8 * k) * 1024)));
         }
-        if (npx >= 1) { npy += 1; npx -= 1; } else { npx += 24; }      // + 24 pixels: one row down, one column back
     };
-    auto issue_patch = [&](int slot, int b, int yi, int xi) {
-        const int y = yi * PH - 1 + qy, xx = xi * PW - 1 + qx;
-        const bool ok = qrow_ok && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const unsigned long src = ok ? xb + (unsigned long)((unsigned)((b * H + y) * W + xx) * (unsigned)(ldx * 2)) : zaddr;
-        wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(slot * SLOT + DYIMG + wave * 1024)));
+    // the 7 x 27 patch of a stage: 3 instructions of this (patch) wave.  q / 27 = (q * 19) >> 9 for q < 192
+    auto issue_patch = [&](Pc c, int slot) {
+        int rr = r0;
+        asm volatile("" : "+v"(rr));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = rr + 64 * j, qy = (q * 19) >> 9, qx = q - qy * PR;
+            const int y = c.y * PH - 1 + qy, xx = c.x * PW - 1 + qx;
+            const bool ok = q < PROWS && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned long src = ok ? gbase + (unsigned long)((unsigned)((c.b * H + y) * W + xx) * ldx2) : zaddr;
+            wg_glds16((const void*)src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)(POFF + slot * PIMG + ((wave & 3) + 4 * j) * 1024)));
+        }
     };
 
-    // ---- fragment addressing (slot 0, step 0)
+    // ---- fragment addressing (ring slot 0 / patch slot 0, step 0 of a half)
     const int r = lane & 15, gq = lane >> 4;
     const int frow = 8 * (gq >> 1) + (r >> 2);
     const int fr = ((r >> 2) & 3) << 1;
@@ -102,9 +125,9 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
     unsigned abase[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = sbase + (unsigned)(frow * 512 + ((((wm * 2 + i) * 2 + (gq & 1)) ^ fr) << 5) + cb);
-    const unsigned pbase = sbase + (unsigned)(DYIMG + kh * PR * 64 + (gq & 1) * 32 + cb);
-    // patch row of the tile pixels this lane reads: step s, read h -> pixel 16 s + frow + 4 h; one byte each.  Pixels >= 125 (the padding of the
-    // last step) read patch row 0: their dy rows are zero, and row 0 + 27 kh + kw is real, finite data (a row index past the image would not be)
+    const unsigned pbase = sbase + (unsigned)(POFF + kh * PR * 64 + (gq & 1) * 32 + cb);
+    // patch row of the tile pixels this lane reads: step s (0 .. 7 over the stage), read h -> pixel 16 s + frow + 4 h; one byte each.  Pixels >= 125
+    // (the padding of the last step) read patch row 0: their dy rows are zero, and row 0 + 27 kh + kw is real, finite data
     unsigned tab[4];
 #pragma unroll
     for (int w4 = 0; w4 < 4; ++w4) {
@@ -127,20 +150,25 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    begin_next(pb, pyi, pxi);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) issue_dy(k, 0);
-    issue_patch(0, pb, pyi, pxi);
-    wg_wait_vmcnt<0>();
+    // ---- prologue: halves (0, 0), (0, 1), (1, 0) and the patch of stage 0; half (0, 0) and the patch must have landed
+    if (dywave) {
+        issue_dy_half(c0p, 0, 0);
+        issue_dy_half(c0p, 1, 1);
+        if (nst > 1) { issue_dy_half(c1, 0, 2); wg_wait_vmcnt<8>(); } else wg_wait_vmcnt<4>();
+    } else {
+        issue_patch(c0p, 0);
+        wg_wait_vmcnt<0>();
+    }
 
     wg_u32x2_t aX[2][2], bX[3][2], aY[2][2], bY[3][2];
-#define WG2D_LOAD(AF, BF, S, so)                                                                                                            \
-    if (!(a.abl & 4)) {                                                                                                                     \
-        const unsigned tw_ = tab[(S) >> 1];                                                                                                 \
-        const unsigned r0_ = (tw_ >> (16 * ((S) & 1))) & 0xffu, r1_ = (tw_ >> (16 * ((S) & 1) + 8)) & 0xffu;                                \
-        const unsigned b0_ = pbase + (so) + r0_ * 64u, b1_ = pbase + (so) + r1_ * 64u;                                                      \
-        AF[0][0] = wg_tr<(S) * 8192>(abase[0] + (so)); AF[0][1] = wg_tr<(S) * 8192 + 2048>(abase[0] + (so));                                \
-        AF[1][0] = wg_tr<(S) * 8192>(abase[1] + (so)); AF[1][1] = wg_tr<(S) * 8192 + 2048>(abase[1] + (so));                                \
+    // S8: step of the stage (0 .. 7, selects the patch rows); the dy rows are those of step S8 & 3 of the half-image at byte offset `dof`
+#define WG2D_LOAD(AF, BF, S8, dof, pof)                                                                                                      \
+    {                                                                                                                                       \
+        const unsigned tw_ = tab[(S8) >> 1];                                                                                                \
+        const unsigned r0_ = (tw_ >> (16 * ((S8) & 1))) & 0xffu, r1_ = (tw_ >> (16 * ((S8) & 1) + 8)) & 0xffu;                              \
+        const unsigned b0_ = pbase + (pof) + r0_ * 64u, b1_ = pbase + (pof) + r1_ * 64u;                                                    \
+        AF[0][0] = wg_tr<((S8) & 3) * 8192>(abase[0] + (dof)); AF[0][1] = wg_tr<((S8) & 3) * 8192 + 2048>(abase[0] + (dof));                \
+        AF[1][0] = wg_tr<((S8) & 3) * 8192>(abase[1] + (dof)); AF[1][1] = wg_tr<((S8) & 3) * 8192 + 2048>(abase[1] + (dof));                \
         BF[0][0] = wg_tr<0>(b0_); BF[0][1] = wg_tr<0>(b1_);                                                                                 \
         BF[1][0] = wg_tr<64>(b0_); BF[1][1] = wg_tr<64>(b1_);                                                                               \
         BF[2][0] = wg_tr<128>(b0_); BF[2][1] = wg_tr<128>(b1_);                                                                             \
@@ -149,43 +177,54 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                     \
                  : "+v"(AF[0][0]), "+v"(AF[0][1]), "+v"(AF[1][0]), "+v"(AF[1][1]), "+v"(BF[0][0]), "+v"(BF[0][1]), "+v"(BF[1][0]), "+v"(BF[1][1]), \
                    "+v"(BF[2][0]), "+v"(BF[2][1]) :: "memory")
-#define WG2D_MMA1(AF, BF, i, j)                                                                                                             \
-    if (!(a.abl & 2)) WgMma32<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[i][j])
 #define WG2D_MMA6(AF, BF)                                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) WG2D_MMA1(AF, BF, i, j)
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                                       \
+            WgMma32<F16>::run(make_uint4(AF[i][0].x, AF[i][0].y, AF[i][1].x, AF[i][1].y), make_uint4(BF[j][0].x, BF[j][0].y, BF[j][1].x, BF[j][1].y), acc[i][j])
 #define WG2D_SB __builtin_amdgcn_sched_barrier(0)
-    for (int st = 0;; ++st) {
-        const unsigned so = (unsigned)((st & 1) * SLOT);
-        const int ns = (st + 1) & 1;
-        __builtin_amdgcn_s_barrier();                  // stage st has landed (every wave waited for its part), stage st - 1 is read out
-        ++pidx;
-        const bool has_next = pidx < pend && !(a.abl & 1);
-        if (++pxi == a.tx) { pxi = 0; if (++pyi == a.ty) { pyi = 0; ++pb; } }
-        if (has_next) begin_next(pb, pyi, pxi);
+
+    OCTA_STAMP_DECL;
+    OCTA_STAMP_BEGIN;
+    for (int S = 0; S < nst; ++S) {
+        const unsigned d0 = (unsigned)(((2 * S) & 3) * DYHALF), d1 = d0 + DYHALF;       // ring slots of this stage's halves ({0, 1} or {2, 3})
+        const unsigned po = (unsigned)((S & 1) * PIMG);
+        // ---- half 0.  Barrier: half (S, 0) and the patch of S have landed (every wave waited for its part); half (S - 1, 1) is read out, so its
+        // ring slot takes half (S + 1, 1) and the other patch slot the patch of S + 1
+        __builtin_amdgcn_s_barrier();
+        if (S + 1 < nst) {
+            if (dywave) issue_dy_half(c1, 1, (2 * S + 3) & 3);
+            else issue_patch(c1, (S + 1) & 1);
+        }
         WG2D_SB;
-        // (reads of step s + 1, then the six MFMAs of step s: interleaving one read pair behind every MFMA, wgrad9's recipe, measured 15 % SLOWER
-        // here -- three waves per SIMD already fill each other's gaps)
-        WG2D_LOAD(aX, bX, 0, so); WG2D_WAIT(aX, bX); WG2D_SB;
-        WG2D_LOAD(aY, bY, 1, so); if (has_next) issue_dy(0, ns); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
-        WG2D_LOAD(aX, bX, 2, so); if (has_next) issue_dy(1, ns); WG2D_SB; WG2D_MMA6(aY, bY); WG2D_SB; WG2D_WAIT(aX, bX); WG2D_SB;
-        WG2D_LOAD(aY, bY, 3, so); if (has_next) issue_dy(2, ns); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
-        WG2D_LOAD(aX, bX, 4, so); if (has_next) issue_dy(3, ns); WG2D_SB; WG2D_MMA6(aY, bY); WG2D_SB; WG2D_WAIT(aX, bX); WG2D_SB;
-        WG2D_LOAD(aY, bY, 5, so); if (has_next) issue_dy(4, ns); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
-        WG2D_LOAD(aX, bX, 6, so); if (has_next) issue_dy(5, ns); WG2D_SB; WG2D_MMA6(aY, bY); WG2D_SB; WG2D_WAIT(aX, bX); WG2D_SB;
-        WG2D_LOAD(aY, bY, 7, so); if (has_next) issue_patch(ns, pb, pyi, pxi); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
+        WG2D_LOAD(aX, bX, 0, d0, po); WG2D_WAIT(aX, bX); WG2D_SB;
+        WG2D_LOAD(aY, bY, 1, d0, po); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
+        WG2D_LOAD(aX, bX, 2, d0, po); WG2D_SB; WG2D_MMA6(aY, bY); WG2D_SB; WG2D_WAIT(aX, bX); WG2D_SB;
+        WG2D_LOAD(aY, bY, 3, d0, po); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
         WG2D_MMA6(aY, bY); WG2D_SB;
-        wg_wait_vmcnt<0>();                            // this wave's part of stage st + 1
-        if (pidx >= pend) break;
+        // half (S, 1) must have landed: behind it in this wave's queue are the halves (S + 1, 0) and (S + 1, 1), four instructions each
+        if (dywave) { if (S + 1 < nst) wg_wait_vmcnt<8>(); else wg_wait_vmcnt<0>(); }
+        // ---- half 1.  Barrier: half (S, 0) is read out: its ring slot takes half (S + 2, 0)
+        __builtin_amdgcn_s_barrier();
+        if (dywave && S + 2 < nst) issue_dy_half(c2, 0, (2 * S + 4) & 3);
+        WG2D_SB;
+        WG2D_LOAD(aX, bX, 4, d1, po); WG2D_WAIT(aX, bX); WG2D_SB;
+        WG2D_LOAD(aY, bY, 5, d1, po); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
+        WG2D_LOAD(aX, bX, 6, d1, po); WG2D_SB; WG2D_MMA6(aY, bY); WG2D_SB; WG2D_WAIT(aX, bX); WG2D_SB;
+        WG2D_LOAD(aY, bY, 7, d1, po); WG2D_SB; WG2D_MMA6(aX, bX); WG2D_SB; WG2D_WAIT(aY, bY); WG2D_SB;
+        WG2D_MMA6(aY, bY); WG2D_SB;
+        // half (S + 1, 0) and the patch of S + 1 must have landed: behind the former are the halves (S + 1, 1) and (S + 2, 0)
+        if (dywave) {
+            if (S + 2 < nst) wg_wait_vmcnt<8>(); else if (S + 1 < nst) wg_wait_vmcnt<4>(); else wg_wait_vmcnt<0>();
+        } else wg_wait_vmcnt<0>();
+        c1 = c2; c2 = adv(c2);
     }
-#undef WG2D_MMA1
+    OCTA_STAMP_END(octa_diag_stamps_wgrad9);
 #undef WG2D_LOAD
 #undef WG2D_WAIT
 #undef WG2D_MMA6
 #undef WG2D_SB
 
     // ---- epilogue: block (i, j): column ci = lane & 31 of tap (kh, j), rows co = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    if (a.abl & 8) { if (acc[0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
     const int lc = lane & 31, lh = lane >> 5;
     const int ci = c0 + lc;
     if (a.partws) {
@@ -219,14 +258,19 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static int g_wg2d = 0;                  // octa_tuning_set(10, 0 / 1): 3x3 stride-1 weight gradients of exact 5 x 25 geometries on wgrad2d
+// octa_tuning_set(10, v): 3x3 stride-1 weight gradients of exact 5 x 25 geometries on wgrad2d: 0 = never, 1 = every geometry the kernel takes,
+// 2 (default) = where it is measured ahead of wgrad9 (ungrouped, >= 256 channels either side: the decoder's 3x3 layers, profiles/r05_wgrad2d.txt)
+static int g_wg2d = 2;
 static int wg2d_on() {
     static const int env = getenv("OCTA_WGRAD2D") ? atoi(getenv("OCTA_WGRAD2D")) : -1;
     return env >= 0 ? env : g_wg2d;
 }
 static bool wg2d_eligible(const octa_wgrad_job& j) {
     const octa_conv_desc& d = j.d;
-    if (!wg2d_on() || octa_deterministic()) return false;
+    const int mode = wg2d_on();
+    if (!mode || octa_deterministic()) return false;
+    static const int minc = getenv("OCTA_WG2D_MINC") ? atoi(getenv("OCTA_WG2D_MINC")) : 1024;
+    if (mode == 2 && (d.groups != 1 || d.Cout < 256 || d.Cin < minc)) return false;
     if (d.dtype != OCTA_BF16 && d.dtype != OCTA_F16) return false;
     if (d.upshuffle || !j.x || !j.dy || !j.dw || j.dbias) return false;
     if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.OH != d.H || d.OW != d.W) return false;
@@ -250,7 +294,8 @@ static int wg2d_launch(const octa_wgrad_job& j, hipStream_t st) {
     a.tilesN = cdiv(a.Ng, 256); a.tilesC = a.Cg / 32;
     a.ty = d.H / 5; a.tx = d.W / 25; a.npatch = d.B * a.ty * a.tx;
     a.partws = nullptr; a.part_slice = 0; a.Kpad = 9 * a.Cg;
-    a.abl = getenv("OCTA_WG2D_ABL") ? atoi(getenv("OCTA_WG2D_ABL")) : 0;
+    static const int rot = getenv("OCTA_WG2D_ROT") ? atoi(getenv("OCTA_WG2D_ROT")) : 1, rot2 = getenv("OCTA_WG2D_ROT2") ? atoi(getenv("OCTA_WG2D_ROT2")) : 0;
+    a.rot = rot; a.rot2 = rot2;
     const int64_t tiles = (int64_t)a.groups * a.tilesN * a.tilesC;
     // M-split: minimise rounds x (stages + E) over the number of parts; E ~ the epilogue (96 KB of float atomics per workgroup) + prologue in stages
     static const int E = getenv("OCTA_WG2D_EPI") ? atoi(getenv("OCTA_WG2D_EPI")) : 8;

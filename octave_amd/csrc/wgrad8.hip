@@ -1924,7 +1924,7 @@ void octa_set_deterministic(int on);   // api.cpp
 void octa_set_halo8_packed(int on);    // conv.hip
 void octa_set_rev_walk(int on);        // api.cpp
 extern "C" int octa_tuning_set(int key, int value) {
-    if (key == 10) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 10 = 3x3 stride-1 weight gradients of exact 5 x 25 geometries on the 2-D patch kernel (0 / 1)"); g_wg2d = value; return OCTA_OK; }
+    if (key == 10) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 10 = 3x3 stride-1 weight gradients of exact 5 x 25 geometries on the 2-D patch kernel (0 never / 1 every eligible geometry / 2 where it pays)"); g_wg2d = value; return OCTA_OK; }
     if (key == 9) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 9 = MFMA shape of the 256 x 256 weight-gradient kernel: 0 = 32x32x16 (wgrad9), 1 = 16x16x32 (wgrad9s), 2 = 32x32x16 with four waves of 128 x 128 (wgrad9a)"); g_wg9_shape16 = value; return OCTA_OK; }
     if (key == 8) { OCTA_REQUIRE(value >= 0 && value <= 2, "octa_tuning_set: key 8 = wgrad9 schedule: 0 rounds of one split length, 1 per-class splits + XCD-interleaved sequences, 2 the same, persistent"); g_wg9_sched = value; return OCTA_OK; }
     if (key == 7) { OCTA_REQUIRE(value == 0 || value == 1, "octa_tuning_set: key 7 = first-pass reductions walk their tensor end first (0 / 1)"); octa_set_rev_walk(value); return OCTA_OK; }

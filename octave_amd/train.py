@@ -26,6 +26,54 @@ from ._lib import lib
 from .layers import defer_bn_counters, flush_bn_counters
 
 
+def overlapping_stream(ref: Optional[torch.cuda.Stream] = None, tries: int = 6) -> torch.cuda.Stream:
+    """A new stream whose kernels really run BESIDE `ref`'s (default: the current stream).  HIP spreads its streams over a few hardware
+    queues (four by default) in creation order, and two streams that share a queue are served in order: a side stream drawn blindly
+    serialises with the main stream one time in four (measured on the captured B = 16, 400 x 400 step: 24.8 ms, and 25.5 ms for every fourth
+    TrainStep built in one process -- the discriminator's graph then waits behind the backward pass; profiles/r05_stream_probe.txt).
+    Probe: one spin kernel on each stream at the same time must take about as long as one alone; the first candidate that passes is
+    returned, the last one (with a warning) if none does.  OCTA_STREAM_PROBE=0 returns a plain new stream."""
+    if os.environ.get("OCTA_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream()
+    ref = ref if ref is not None else torch.cuda.current_stream()
+
+    def timed(cycles: int, other: Optional[torch.cuda.Stream]) -> float:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(ref):
+            e0.record(ref)
+            if other is not None:
+                other.wait_event(e0)
+            torch.cuda._sleep(cycles)
+            if other is not None:
+                with torch.cuda.stream(other):
+                    torch.cuda._sleep(cycles)
+                    done = torch.cuda.Event()
+                    done.record(other)
+                ref.wait_event(done)
+            e1.record(ref)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    cycles = 200_000
+    timed(cycles, None)
+    t1 = min(timed(cycles, None) for _ in range(2))
+    if t1 < 0.2:                                   # aim at ~0.5 ms per spin, whatever clock `_sleep` counts in
+        cycles = int(cycles * min(0.5 / max(t1, 1e-3), 50.0))
+        t1 = min(timed(cycles, None) for _ in range(2))
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        t2 = min(timed(cycles, cand) for _ in range(2))
+        if os.environ.get("OCTA_STREAM_PROBE") == "2":
+            print(f"overlapping_stream: spin alone {t1:.3f} ms, beside candidate {_} {t2:.3f} ms -> {'runs beside' if t2 < 1.5 * t1 else 'SERIALISED'}", flush=True)
+        if t2 < 1.5 * t1:
+            return cand
+    import warnings
+    warnings.warn(f"overlapping_stream: none of {tries} new streams ran beside the reference stream (spin {t1:.2f} ms alone, {t2:.2f} ms with the last "
+                  "candidate): side-stream work will serialise with the main stream")
+    return cand
+
+
 FORCE_ALLREDUCE = os.environ.get("OCTA_DIST_ALWAYS") == "1"     # exercise the RCCL path with a single rank (tests)
 
 # top-level modules of ResnestUNet in the order their parameter gradients COMPLETE in the backward pass; each entry is
@@ -628,7 +676,7 @@ class TrainStep:
 
     def _comm(self):
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
+            self._comm_stream = overlapping_stream() if _dist_on(self.world) else torch.cuda.Stream()
         return self._comm_stream
 
     def __call__(self, x: Tensor, ys: Tensor, real_pyramid: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
@@ -892,7 +940,8 @@ class TrainStep:
                     # the discriminator's step beside the backward pass: it reads the attention maps and the spectral-norm state the
                     # forward graph left, and writes only its own gradient arena
                     if self._disc_stream is None:
-                        self._disc_stream = torch.cuda.Stream()       # default priority: a high-priority stream gave the whole gain back (28.45 -> 29.2 ms)
+                        # default priority (a high-priority stream gave the whole gain back: 28.45 -> 29.2 ms), on a hardware queue of its own
+                        self._disc_stream = overlapping_stream(cur)
                     self._disc_stream.wait_stream(cur)
                     with torch.cuda.stream(self._disc_stream):
                         g2.replay()

@@ -156,19 +156,24 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
     # weight gradient: the batched 8-wave kernel (what a TrainStep flush launches) and the immediate per-layer kernel
     taps = sorted({(0, 0), (k // 2, k // 2), (k - 1, k // 2)})
     refs = {t: _ref_wgrad_tap(x64, dy64, t[0], t[1], s, p, g) for t in taps}
-    for mode in ("batched", "immediate"):
+    # (the ungrouped 3x3 layers with >= 1024 input channels leave the batch for the 2-D patch kernel, wgrad2d: both kernels are checked there)
+    for mode in ("batched", "batched-no-wgrad2d", "immediate"):
         dw = torch.zeros(Cout, Cin // g, k, k, device=dev).contiguous(memory_format=torch.channels_last)
-        if mode == "batched":
+        if mode.startswith("batched"):
             F_.defer_wgrads(True)
+            L.octa_tuning_set(10, 2 if mode == "batched" else 0)
             try:
                 F_.raw_conv_wgrad(xn, dyn, wq, s, p, g, dw=dw, defer=True)
                 assert F_.pending_wgrads() == 1
                 job = F_._WGRAD_Q[0][0]
-                assert int(L.octa_wgrad_job_class(ctypes.byref(job))) in (1, 2, 3), "this layer must run on the batched 8-wave kernels"
+                cls = int(L.octa_wgrad_job_class(ctypes.byref(job)))
+                patch = mode == "batched" and k == 3 and s == 1 and g == 1 and Cin >= 1024 and Cout >= 256 and H % 5 == 0 and W % 25 == 0
+                assert cls == 4 if patch else cls in (1, 2, 3), (cls, "this layer must run on the batched 8-wave kernels" if not patch else "... on wgrad2d")
                 F_.flush_wgrads()
             finally:
                 F_.defer_wgrads(False)
-            assert any(k in L.octa_last_conv_kernel().decode() for k in ("wgrad8", "wgrad9")), L.octa_last_conv_kernel().decode()
+                L.octa_tuning_set(10, 2)
+            assert any(k in L.octa_last_conv_kernel().decode() for k in (("wgrad2d",) if patch else ("wgrad8", "wgrad9"))), L.octa_last_conv_kernel().decode()
         else:
             F_.raw_conv_wgrad(xn, dyn, wq, s, p, g, dw=dw)
         for (kh, kw), ref in refs.items():

@@ -1427,4 +1427,4 @@ def test_wgrad2d_patch_kernel_vs_torch(dev, dtype):
             torch.nn.functional.conv2d(x, wr, None, 1, 1, 1, g).backward(dy)
             check(f"wgrad2d {(B, Cin, H, W, Cout, g)}", dw, wr.grad, 0, 3e-4 * float(wr.grad.abs().max()))
     finally:
-        L.octa_tuning_set(10, 0)
+        L.octa_tuning_set(10, 2)

@@ -11,7 +11,7 @@ from octave_amd import functional as F_
 from octave_amd._lib import lib
 from octave_amd.train import TrainStep, mask_pyramid
 
-DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0, 9: 0, 10: 0}
+DEFAULTS = {1: 3, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0, 9: 0, 10: 2}
 cfgs = [a for a in sys.argv[1:] if not a.isdigit()]
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 dev = torch.device("cuda", 0)

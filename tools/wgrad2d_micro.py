@@ -27,7 +27,7 @@ for name in ("d2_3x3", "d3_3x3", "d4_3x3", "d3_splat_nb", "e3_splat_nb"):
             e1.record(); e1.synchronize()
             res[m].append(e0.elapsed_time(e1) * 1e3)
             kn[m] = L.octa_last_conv_kernel().decode()
-    L.octa_tuning_set(10, 0)
+    L.octa_tuning_set(10, 2)
     out = []
     for m in (0, 1):
         v = sorted(res[m])
