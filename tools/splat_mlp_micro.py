@@ -1,50 +1,63 @@
-"""Split-attention micro-net kernels (fc1 -> bn1 -> relu -> fc2 on (B, C) vectors) on the model's configurations: us per call of
-octa_splat_mlp_fwd / octa_splat_mlp_bwd.  Usage: python tools/splat_mlp_micro.py"""
-import collections, os, sys
+"""Split-attention micro-net backward (octa_splat_mlp_bwd: two launches) at the step's sizes: 30 back-to-back calls between two events.
+Usage (GPU box): python tools/splat_mlp_micro.py"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from architectures.models.octa import OctaScribbleNet
+from octave_amd import functional as F_
 from octave_amd._lib import lib
-from octave_amd.functional import _p, _st
 
-B, H = 16, 400
-dev = torch.device("cuda:0")
-net = OctaScribbleNet(torch.Size((B, 3, H, H)), torch.Size((B, 2, H, H)), True, False).to(dev).train()
-cfgs = collections.Counter()
-for m in net.modules():
-    if type(m).__name__ == "SplAtConv2d":
-        inter, cg = m.fc1.weight.shape[0], m.fc1.weight.shape[1]
-        card = m.cardinality
-        cfgs[(cg * card, inter, card)] += 1
 L = lib()
-
-
-def timeit(fn, reps=50):
-    fn(); torch.cuda.synchronize()
+dev = torch.device("cuda:0")
+p = F_._p
+B = 16
+evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+SIZES = [(64, 32, 1), (128, 64, 1), (256, 128, 1), (512, 256, 1), (64, 32, 2), (128, 64, 2), (256, 128, 2), (512, 256, 2), (1024, 512, 2)]
+for C, inter, card in SIZES:
+    g = torch.Generator(device="cpu").manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dlogits, gap = r(B, 2 * C), r(B, C)
+    w1, w2 = r(inter, C // card), r(2 * C, inter // card)
+    h1 = r(B, inter); h2 = torch.relu(r(B, inter))
+    mean, invstd, gamma = r(inter), r(inter).abs() + 0.5, r(inter)
+    dh1 = torch.empty(B, inter, device=dev); dgap = torch.zeros(B, C, device=dev)
+    dw1, db1, dg, dbe, dw2, db2 = torch.zeros_like(w1), torch.zeros(inter, device=dev), torch.zeros(inter, device=dev), torch.zeros(inter, device=dev), torch.zeros_like(w2), torch.zeros(2 * C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    fn = lambda: L.octa_splat_mlp_bwd(p(dlogits), p(gap), p(w1), p(w2), p(h1), p(h2), p(mean), p(invstd), p(gamma), p(dh1), p(dgap), p(dw1), p(db1), p(dg), p(dbe), p(dw2), p(db2),
+                                      B, C, inter, card, 0, st)
+    b1, beta, rm, rv = r(inter), r(inter), torch.zeros(inter, device=dev), torch.ones(inter, device=dev)
+    b2, logits = r(2 * C), torch.empty(B, 2 * C, device=dev)
+    ffn = lambda: L.octa_splat_mlp_fwd(p(gap), p(w1), p(b1), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, p(w2), p(b2), p(h1), p(h2), p(mean), p(invstd), p(logits),
+                                       B, C, inter, card, st)
+    fcold = []
+    for _ in range(7):
+        evict.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ffn(); e1.record(); e1.synchronize()
+        fcold.append(e0.elapsed_time(e1) * 1e3)
+    fcold.sort()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(30):
+        ffn()
     e1.record(); e1.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
-
-
-tf = tb = 0.0
-for (C, inter, card), n in sorted(cfgs.items()):
-    f = lambda *s: torch.randn(*s, device=dev)
-    gap, w1, b1 = f(B, C), f(inter, C // card) * 0.05, f(inter)
-    g1, be1, rm, rv = f(inter), f(inter), torch.zeros(inter, device=dev), torch.ones(inter, device=dev)
-    w2, b2 = f(2 * C, inter // card) * 0.05, f(2 * C)
-    h1, h2 = torch.empty(B, inter, device=dev), torch.empty(B, inter, device=dev)
-    mean, invstd, logits = torch.empty(inter, device=dev), torch.empty(inter, device=dev), torch.empty(B, 2 * C, device=dev)
-    st = _st()
-    fwd = lambda: L.octa_splat_mlp_fwd(_p(gap), _p(w1), _p(b1), _p(g1), _p(be1), _p(rm), _p(rv), 0.1, 1e-5, 1, _p(w2), _p(b2), _p(h1), _p(h2),
-                                       _p(mean), _p(invstd), _p(logits), B, C, inter, card, st)
-    dl, dh1, dgap = f(B, 2 * C), torch.empty(B, inter, device=dev), torch.zeros(B, C, device=dev)
-    dw1, db1, dg, dbe, dw2, db2 = torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(g1), torch.zeros_like(be1), torch.zeros_like(w2), torch.zeros_like(b2)
-    bwd = lambda: L.octa_splat_mlp_bwd(_p(dl), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean), _p(invstd), _p(g1), _p(dh1), _p(dgap), _p(dw1),
-                                       _p(db1), _p(dg), _p(dbe), _p(dw2), _p(db2), B, C, inter, card, 0, st)
-    a, b = timeit(fwd), timeit(bwd)
-    tf += a * n; tb += b * n
-    print(f"C {C:5d} inter {inter:4d} card {card} x{n}: fwd {a:6.1f} us (2 kernels)  bwd {b:6.1f} us (2-3 kernels)")
-print(f"per step: fwd {tf / 1e3:.2f} ms, bwd {tb / 1e3:.2f} ms")
+    fwarm = e0.elapsed_time(e1) * 1e3 / 30
+    h2.clamp_(min=0)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            fn()
+        e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / 30)
+    cold = []
+    for _ in range(7):
+        evict.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        cold.append(e0.elapsed_time(e1) * 1e3)
+    cold.sort()
+    print(f"C {C:5d} inter {inter:4d} card {card}: {best:6.1f} us per call back to back, {cold[3]:6.1f} us behind a 512 MB sweep (AB + zero fill + CD); forward (2 launches) behind the sweep {fcold[3]:6.1f} us (all 7: {' '.join(f'{v:.0f}' for v in fcold)}), back to back {fwarm:5.1f} us; W2 {2 * C * inter // card * 4 / 1e6:.2f} MB, W1 {inter * C // card * 4 / 1e6:.2f} MB", flush=True)
