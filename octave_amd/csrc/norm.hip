@@ -411,17 +411,28 @@ __device__ __forceinline__ void bn_small_merge(const float* __restrict__ partial
     const int ch = threadIdx.x % CH, part = threadIdx.x / CH, NP = 256 / CH;
     const int c = c0 + ch;
     double s1 = 0.0, s2 = 0.0;
-    if (MODE == 0) {
-        const double r = (double)partial[c];
-        for (int b = part; b < nbp; b += NP) {
-            const int64_t lo = (int64_t)b * rpbp;
-            const double nb = (double)((rows - lo) < rpbp ? (rows - lo) : rpbp);
-            const double d = (double)partial[((size_t)b * 2) * C + c] - r;
-            s1 += nb * d;
-            s2 += (double)partial[((size_t)b * 2 + 1) * C + c] + nb * d * d;
+    // the partials of eight slabs in flight at once (and the reference beside them): one slab per trip was a chain of up to eight memory round trips at
+    // the head of a 13 us kernel.  Same sums in the same order.
+    const float rf = MODE == 0 ? partial[c] : 0.f;
+    for (int b0 = part; b0 < nbp; b0 += 8 * NP) {
+        float p1[8], p2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * NP, bb = b < nbp ? b : part;
+            p1[k] = partial[((size_t)bb * 2) * C + c]; p2[k] = partial[((size_t)bb * 2 + 1) * C + c];
         }
-    } else {
-        for (int b = part; b < nbp; b += NP) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * NP;
+            if (b >= nbp) continue;
+            if (MODE == 0) {
+                const int64_t lo = (int64_t)b * rpbp;
+                const double nb = (double)((rows - lo) < rpbp ? (rows - lo) : rpbp);
+                const double d = (double)p1[k] - (double)rf;
+                s1 += nb * d;
+                s2 += (double)p2[k] + nb * d * d;
+            } else { s1 += (double)p1[k]; s2 += (double)p2[k]; }
+        }
     }
     fred[threadIdx.x][0] = s1; fred[threadIdx.x][1] = s2;
     __syncthreads();
@@ -445,6 +456,23 @@ __global__ __launch_bounds__(256) void bn_small_apply_kernel(const T* __restrict
     __shared__ float coef[64][3];                      // mean, gamma * invstd, beta
     const int RY = 256 / TX, CH = TX * EPC;
     const int c0 = blockIdx.x * CH;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    // the per-channel operands and the first row pair travel beside the merge of the partials (everything but the partials is cold in the step)
+    float gv = 0.f, bv = 0.f, rmv = 0.f, rvv = 0.f;
+    if (threadIdx.x < CH) {
+        gv = gamma[c0 + threadIdx.x]; bv = beta[c0 + threadIdx.x];
+        if (blockIdx.y == 0) { if (rm) rmv = rm[c0 + threadIdx.x]; if (rv) rvv = rv[c0 + threadIdx.x]; }
+    }
+    const bool pre = r0 + RY < r1;
+    uint4 pxa = make_uint4(0, 0, 0, 0), pxc = pxa, psa = pxa, psc = pxa;
+    if (pre) {
+        const int64_t ra = r0 + ry, rc = r0 + RY + ry;
+        const int64_t qa = ra < r1 ? ra : r0, qc = rc < r1 ? rc : r0;
+        pxa = *(const uint4*)(x + qa * ldx + xoff + col * EPC); pxc = *(const uint4*)(x + qc * ldx + xoff + col * EPC);
+        if (res) { psa = *(const uint4*)(res + qa * ldr + roff + col * EPC); psc = *(const uint4*)(res + qc * ldr + roff + col * EPC); }
+    }
     bn_small_merge<0>(partial, nbp, rpbp, rows, C, CH, c0, fred, S);
     if (threadIdx.x < CH) {
         const int ch = threadIdx.x, c = c0 + ch;
@@ -453,30 +481,29 @@ __global__ __launch_bounds__(256) void bn_small_apply_kernel(const T* __restrict
         double var = (s2 - s1 * s1 / n) / n;
         if (var < 0.0) var = 0.0;
         const float isd = (float)(1.0 / sqrt(var + (double)eps));
-        coef[ch][0] = (float)m; coef[ch][1] = gamma[c] * isd; coef[ch][2] = beta[c];
+        coef[ch][0] = (float)m; coef[ch][1] = gv * isd; coef[ch][2] = bv;
         if (blockIdx.y == 0) {
             mean_out[c] = (float)m;
             invstd_out[c] = isd;
-            if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
-            if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+            if (rm) rm[c] = (1.f - momentum) * rmv + momentum * (float)m;
+            if (rv) rv[c] = (1.f - momentum) * rvv + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
         }
     }
     __syncthreads();
-    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
-    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
     float mu[EPC], sc[EPC], be[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { mu[e] = coef[cx * EPC + e][0]; sc[e] = coef[cx * EPC + e][1]; be[e] = coef[cx * EPC + e][2]; }
-    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
     // block-uniform trip count (the DPP mask combine below needs every lane of a quad in the loop)
     int64_t rb = r0;
     for (; rb + RY < r1; rb += 2 * RY) {                 // two row groups per iteration, their loads issued together
         const int64_t ra = rb + ry, rc = rb + RY + ry;
         const bool la = ra < r1, lc = rc < r1;
         const int64_t qa = la ? ra : r0, qc = lc ? rc : r0;
-        const uint4 xa = *(const uint4*)(x + qa * ldx + xoff + col * EPC), xc = *(const uint4*)(x + qc * ldx + xoff + col * EPC);
-        uint4 sa = make_uint4(0, 0, 0, 0), sc2 = sa;
-        if (res) { sa = *(const uint4*)(res + qa * ldr + roff + col * EPC); sc2 = *(const uint4*)(res + qc * ldr + roff + col * EPC); }
+        uint4 xa = pxa, xc = pxc, sa = psa, sc2 = psc;
+        if (rb != r0) {
+            xa = *(const uint4*)(x + qa * ldx + xoff + col * EPC); xc = *(const uint4*)(x + qc * ldx + xoff + col * EPC);
+            if (res) { sa = *(const uint4*)(res + qa * ldr + roff + col * EPC); sc2 = *(const uint4*)(res + qc * ldr + roff + col * EPC); }
+        }
         float va[EPC], vc[EPC], ea[EPC], ec[EPC];
         unpack16<T>(xa, va); unpack16<T>(xc, vc);
         if (res) { unpack16<T>(sa, ea); unpack16<T>(sc2, ec); }
@@ -543,39 +570,61 @@ __global__ __launch_bounds__(256) void bn_small_bwd_apply_kernel(const T* __rest
     __shared__ float coef[64][5];                      // mean, invstd, gamma * invstd, sum dy' / N, sum dy' xhat / N
     const int RY = 256 / TX, CH = TX * EPC;
     const int c0 = blockIdx.x * CH;
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
+    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    int64_t rbeg = r0 + ry;
+    const bool um = relu && rmask, uy = relu && !rmask;
+    // the per-channel operands and the first row pair travel beside the merge of the partials (see bn_small_apply_kernel)
+    float mv = 0.f, iv = 0.f, gv = 0.f, dbv = 0.f, dgv = 0.f;
+    if (threadIdx.x < CH) {
+        const int c = c0 + threadIdx.x;
+        mv = mean[c]; iv = invstd[c]; gv = gamma[c];
+        if (blockIdx.y == 0) { if (dbeta) dbv = dbeta[c]; if (dgamma) dgv = dgamma[c]; }
+    }
+    const bool pre = rbeg + RY < r1;
+    uint4 pxa = make_uint4(0, 0, 0, 0), pxb = pxa, pda = pxa, pdb = pxa, pya = pxa, pyb = pxa;
+    unsigned pma = 0xffu, pmb = 0xffu;
+    if (pre) {
+        const int64_t ra = rbeg, rb2 = rbeg + RY;
+        pxa = *(const uint4*)(x + ra * ldx + xoff + col * EPC); pxb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
+        pda = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC); pdb = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
+        if (um) { pma = rmask[ra * cpr + col]; pmb = rmask[rb2 * cpr + col]; }
+        if (uy) { pya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); pyb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+    }
     bn_small_merge<1>(partial, nbp, 0, rows, C, CH, c0, fred, S);
     if (threadIdx.x < CH) {
         const int ch = threadIdx.x, c = c0 + ch;
         const double n = (double)rows, s = S[ch][0], ss = S[ch][1];
-        const float isd = invstd[c];
-        coef[ch][0] = mean[c]; coef[ch][1] = isd; coef[ch][2] = gamma[c] * isd;
+        coef[ch][0] = mv; coef[ch][1] = iv; coef[ch][2] = gv * iv;
         coef[ch][3] = (float)(s / n); coef[ch][4] = (float)(ss / n);
         if (blockIdx.y == 0) {
-            if (dbeta) dbeta[c] += (float)s;
-            if (dgamma) dgamma[c] += (float)ss;
+            if (dbeta) dbeta[c] = dbv + (float)s;
+            if (dgamma) dgamma[c] = dgv + (float)ss;
         }
     }
     __syncthreads();
-    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
-    const int col = blockIdx.x * TX + cx, cpr = C / EPC;
     float mu[EPC], isd[EPC], gi[EPC], f0[EPC], f1[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float* k = coef[cx * EPC + e];
         mu[e] = k[0]; isd[e] = k[1]; gi[e] = k[2]; f0[e] = k[3]; f1[e] = k[4];
     }
-    const int64_t r0 = (int64_t)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
-    int64_t rbeg = r0 + ry;
     {   // two rows per iteration, loads first (see bn_small_reduce_kernel)
-        const bool um = relu && rmask, uy = relu && !rmask;
+        const int64_t rfirst = rbeg;
         for (; rbeg + RY < r1; rbeg += 2 * RY) {
             const int64_t ra = rbeg, rb2 = rbeg + RY;
-            const uint4 xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC), xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
-            const uint4 da = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC), db = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
-            unsigned ma = 0xffu, mb = 0xffu;
-            uint4 ya = make_uint4(0, 0, 0, 0), yb = ya;
-            if (um) { ma = rmask[ra * cpr + col]; mb = rmask[rb2 * cpr + col]; }
-            if (uy) { ya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); yb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+            uint4 xa = pxa, xb = pxb, da = pda, db = pdb;
+            if (rbeg != rfirst) {
+                xa = *(const uint4*)(x + ra * ldx + xoff + col * EPC); xb = *(const uint4*)(x + rb2 * ldx + xoff + col * EPC);
+                da = *(const uint4*)(dy + ra * lddy + dyoff + col * EPC); db = *(const uint4*)(dy + rb2 * lddy + dyoff + col * EPC);
+            }
+            unsigned ma = pma, mb = pmb;
+            uint4 ya = pya, yb = pyb;
+            if (rbeg != rfirst) {
+                if (um) { ma = rmask[ra * cpr + col]; mb = rmask[rb2 * cpr + col]; }
+                if (uy) { ya = *(const uint4*)(y + ra * ldy + yoff + col * EPC); yb = *(const uint4*)(y + rb2 * ldy + yoff + col * EPC); }
+            }
             float x0[EPC], x1[EPC], d0[EPC], d1[EPC], y0[EPC], y1[EPC], o0[EPC], o1[EPC];
             unpack16<T>(xa, x0); unpack16<T>(xb, x1); unpack16<T>(da, d0); unpack16<T>(db, d1);
             if (uy) { unpack16<T>(ya, y0); unpack16<T>(yb, y1); }
