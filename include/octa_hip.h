@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 313
+#define OCTA_HIP_ABI_VERSION 314
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -459,6 +459,15 @@ int octa_lsgan_fwd(const float* real, const float* fake, int n_real, int n_fake,
 int octa_lsgan_bwd(const float* real, const float* fake, int n_real, int n_fake, int mode,
                    const float* g, float* d_real, float* d_fake, octa_stream_t stream);
 
+/* The segmentor's loss from its terms (train.py; reference: the sums in segmentor/compose.py's training step): a = (2,) tensor
+ * [wpce, dice], b = (2,) tensor [divergence, its NaN flag], c = the generator's adversarial term; any of them may be NULL.
+ * total[0] = ((a0 wa0 + a1 wa1) + b0 wb0 + b1 wb1) + c0 wc0 with zero-weight terms skipped; scaled[0] = total x (scale_dev ? scale_dev[0] :
+ * scale_host).  Backward: da / db / dc = g[0] x scale x weight.  One launch each way instead of ~18 scalar ATen launches. */
+int octa_loss_combine_fwd(const float* a, const float* b, const float* c, float wa0, float wa1, float wb0, float wb1, float wc0,
+                          const float* scale_dev, float scale_host, float* total, float* scaled, octa_stream_t stream);
+int octa_loss_combine_bwd(const float* g, float wa0, float wa1, float wb0, float wb1, float wc0, const float* scale_dev,
+                          float scale_host, float* da, float* db, float* dc, octa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Discriminator pieces.
  * ---------------------------------------------------------------------------------------- */
@@ -571,8 +580,8 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * 0 = v_mfma_f32_32x32x16 (wgrad9), 1 = v_mfma_f32_16x16x32 at the same wave tile (wgrad9s), 2 = 32x32x16 with FOUR waves of 128 x 128 per
  * workgroup, 256 accumulator registers per lane (wgrad9a: a quarter fewer LDS fragment reads per FLOP).  key 10: bias-free 3x3 stride-1
  * layers with H % 5 == 0, W % 25 == 0, Cin / groups % 32 == 0 on the 2-D patch weight-gradient kernel (wgrad2d: one input patch shared by the
- * nine taps): 0 = never, 1 = every such layer, 2 (default) = the ungrouped ones with >= 256 channels on either side, where it is measured ahead of
- * wgrad9. */
+ * nine taps): 0 = never, 1 = every such layer, 2 (default) = the ungrouped ones with >= 1024 input and >= 256 output channels, where taking them out of
+ * the batched wgrad9 launch is measured to pay. */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

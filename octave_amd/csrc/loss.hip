@@ -335,6 +335,50 @@ extern "C" int octa_lsgan_bwd(const float* real, const float* fake, int n_real, 
     return OCTA_OK;
 }
 
+// ------------------------------------------------------------------------------------------ combining the loss terms
+// total = ((a0 wa0 + a1 wa1) + b0 wb0 + b1 wb1) + c0 wc0 (terms of weight 0 are skipped, not multiplied: a NaN flag rides in such a slot), scaled = total x scale:
+// what `l[0] + l[1] + kl_w * kl[0] + adv_w * g_adv` and `* loss_scale` did in six ATen launches forward and a dozen backward (selects, fills, copies, adds
+// of 4-byte tensors, each a 5 us slot on the critical path between the forward and the backward pass).  Same operations in the same order, unfused.
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float wa0, float wa1, float wb0,
+                                        float wb1, float wc0, const float* __restrict__ scale_dev, float scale_host, float* __restrict__ total,
+                                        float* __restrict__ scaled) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t = 0.f;
+    bool any = false;
+    auto add = [&](const float* p, int i, float w) {
+        if (!p || w == 0.f) return;
+        const float v = w == 1.f ? p[i] : __fmul_rn(w, p[i]);
+        t = any ? __fadd_rn(t, v) : v;
+        any = true;
+    };
+    add(a, 0, wa0); add(a, 1, wa1); add(b, 0, wb0); add(b, 1, wb1); add(c, 0, wc0);
+    total[0] = t;
+    scaled[0] = __fmul_rn(t, scale_dev ? scale_dev[0] : scale_host);
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, float wa0, float wa1, float wb0, float wb1, float wc0, const float* __restrict__ scale_dev,
+                                        float scale_host, float* __restrict__ da, float* __restrict__ db, float* __restrict__ dc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float gs = __fmul_rn(g[0], scale_dev ? scale_dev[0] : scale_host);
+    auto w_ = [&](float w) { return w == 1.f ? gs : (w == 0.f ? 0.f : __fmul_rn(gs, w)); };
+    if (da) { da[0] = w_(wa0); da[1] = w_(wa1); }
+    if (db) { db[0] = w_(wb0); db[1] = w_(wb1); }
+    if (dc) dc[0] = w_(wc0);
+}
+extern "C" int octa_loss_combine_fwd(const float* a, const float* b, const float* c, float wa0, float wa1, float wb0, float wb1, float wc0,
+                                     const float* scale_dev, float scale_host, float* total, float* scaled, octa_stream_t stream) {
+    OCTA_REQUIRE(total && scaled && (a || b || c), "octa_loss_combine_fwd: bad arguments");
+    loss_combine_fwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(a, b, c, wa0, wa1, wb0, wb1, wc0, scale_dev, scale_host, total, scaled);
+    OCTA_CHECK_LAUNCH("loss_combine_fwd");
+    return OCTA_OK;
+}
+extern "C" int octa_loss_combine_bwd(const float* g, float wa0, float wa1, float wb0, float wb1, float wc0, const float* scale_dev, float scale_host,
+                                     float* da, float* db, float* dc, octa_stream_t stream) {
+    OCTA_REQUIRE(g && (da || db || dc), "octa_loss_combine_bwd: bad arguments");
+    loss_combine_bwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(g, wa0, wa1, wb0, wb1, wc0, scale_dev, scale_host, da, db, dc);
+    OCTA_CHECK_LAUNCH("loss_combine_bwd");
+    return OCTA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ per-pixel class softmax
 // nn.Softmax(dim=1) on the (B, classes, H, W) logits (segmentor/compose.py:192): strided in, dense NCHW out.
 template <int K>

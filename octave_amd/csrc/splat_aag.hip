@@ -854,7 +854,13 @@ __global__ __launch_bounds__(256) void splat_mlp_fwd1_kernel(const float* __rest
     const float* gr = gap + (size_t)(bl < B ? bl : 0) * C + grp * Cg;
     float acc = 0.f;
     if (bl < B)
-        for (int c = sl; c < Cg; c += NS) acc += wr[c] * gr[c];
+        for (int cb = sl; cb < Cg; cb += 8 * NS) {           // eight steps' operands in flight at once (cold in the step); same sum order
+            float wv[8], gv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int c = cb + k * NS, cc = c < Cg ? c : sl; wv[k] = wr[cc]; gv[k] = gr[cc]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (cb + k * NS < Cg) acc += wv[k] * gv[k];
+        }
     const float hsum = splat_slice_sum<BT>(acc, red);
     if (tid >= BT) return;                                  // threads 0 .. BT-1 (one row of wave 0) finish the channel
     const bool live = bl < B;
@@ -892,7 +898,13 @@ __global__ __launch_bounds__(256) void splat_mlp_fwd2_kernel(const float* __rest
     const float* hr = h2 + (size_t)(bl < B ? bl : 0) * inter + grp * Ig;
     float acc = 0.f;
     if (bl < B)
-        for (int j = sl; j < Ig; j += NS) acc += wr[j] * hr[j];
+        for (int jb = sl; jb < Ig; jb += 8 * NS) {
+            float wv[8], hv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = jb + k * NS, jj = j < Ig ? j : sl; wv[k] = wr[jj]; hv[k] = hr[jj]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (jb + k * NS < Ig) acc += wv[k] * hv[k];
+        }
     const float v = splat_slice_sum<BT>(acc, red);
     if (tid < BT && bl < B) logits[(size_t)bl * N + n] = v + (b2 ? b2[n] : 0.f);
 }
@@ -996,11 +1008,18 @@ __device__ __forceinline__ void splat_mlp_bwdC_body(int bx, int by, int ny, floa
     const int per = (Ig + ny - 1) / ny;
     const int j0 = by * per, j1 = min(Ig, j0 + per);
     if (live)
-        for (int jj = j0 + wave; jj < j1; jj += 4) {
-            const int j = grp * Ig + jj;
-            const float wv = w1[(size_t)j * Cg + cl];
+        for (int jb = j0 + wave; jb < j1; jb += 16) {            // four rows of W1 in flight at once; same sum order
+            float wv[4];
 #pragma unroll
-            for (int b = 0; b < BT; ++b) acc[b] += wv * dh1[(size_t)(b < B ? b : 0) * inter + j];
+            for (int k = 0; k < 4; ++k) { const int jj = jb + 4 * k; wv[k] = w1[(size_t)(grp * Ig + (jj < j1 ? jj : jb)) * Cg + cl]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jj = jb + 4 * k;
+                if (jj >= j1) continue;
+                const int j = grp * Ig + jj;
+#pragma unroll
+                for (int b = 0; b < BT; ++b) acc[b] += wv[k] * dh1[(size_t)(b < B ? b : 0) * inter + j];
+            }
         }
 #pragma unroll
     for (int b = 0; b < BT; ++b) red[wave][b][lane] = acc[b];

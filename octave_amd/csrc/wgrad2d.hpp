@@ -259,7 +259,8 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 // octa_tuning_set(10, v): 3x3 stride-1 weight gradients of exact 5 x 25 geometries on wgrad2d: 0 = never, 1 = every geometry the kernel takes,
-// 2 (default) = where it is measured ahead of wgrad9 (ungrouped, >= 256 channels either side: the decoder's 3x3 layers, profiles/r05_wgrad2d.txt)
+// 2 (default) = where taking the layer out of the batched wgrad9 launch is measured to pay (ungrouped, >= 1024 input channels, OCTA_WG2D_MINC, and
+// >= 256 output channels: two of the decoder's 3x3 layers, profiles/r05_wgrad2d_ring.txt (f))
 static int g_wg2d = 2;
 static int wg2d_on() {
     static const int env = getenv("OCTA_WGRAD2D") ? atoi(getenv("OCTA_WGRAD2D")) : -1;

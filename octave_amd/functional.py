@@ -1756,6 +1756,55 @@ def lsgan_generator(fake):
     return LsganFn.apply(0, fake, None)
 
 
+class LossCombineFn(Function):
+    """total = ((a[0] wa0 + a[1] wa1) + b[0] wb0 + b[1] wb1) + c wc0 and scaled = total x loss scale in ONE launch each way (octa_loss_combine_*): the
+    sums of the reference's training step written with tensor operators cost six 4-byte ATen launches forward and a dozen backward (select backward =
+    fill + copy, accumulations), all of them on the critical path between the two passes.  Zero-weight slots are skipped.  Returns (total, scaled);
+    only `scaled` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, weights, scale_dev, scale_host, a, b, c):
+        ref = next(t for t in (a, b, c) if t is not None)
+        _require_gpu(ref)
+        for t, n in ((a, 2), (b, 2), (c, 1)):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous()):
+                raise OctaError("loss_combine: terms are contiguous fp32 tensors of 2, 2 and 1 elements")
+        wa0, wa1, wb0, wb1, wc0 = [float(w) for w in weights]
+        total = torch.empty((), dtype=torch.float32, device=ref.device)
+        scaled = torch.empty((), dtype=torch.float32, device=ref.device)
+        lib().octa_loss_combine_fwd(_p(a), _p(b), _p(c), wa0, wa1, wb0, wb1, wc0, _p(scale_dev), float(scale_host), _p(total), _p(scaled), _st())
+        ctx.cfg = (wa0, wa1, wb0, wb1, wc0, float(scale_host), a is not None, b is not None, c is not None, None if c is None else c.shape)
+        ctx.scale_dev = scale_dev
+        ctx.mark_non_differentiable(total)
+        return total, scaled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _g_total, g):
+        wa0, wa1, wb0, wb1, wc0, scale_host, ha, hb, hc, cshape = ctx.cfg
+        g = g.float().contiguous()
+        buf = torch.empty((5,), dtype=torch.float32, device=g.device)
+        da, db, dc = (buf[0:2] if ha else None), (buf[2:4] if hb else None), (buf[4:5] if hc else None)
+        lib().octa_loss_combine_bwd(_p(g), wa0, wa1, wb0, wb1, wc0, _p(ctx.scale_dev), scale_host, _p(da), _p(db), _p(dc), _st())
+        return None, None, None, da, db, (dc.reshape(cshape) if hc else None)
+
+
+def loss_combine(a, b, c, weights, scale_dev=None, scale_host=1.0):
+    """-> (total, scaled); see LossCombineFn."""
+    return LossCombineFn.apply(tuple(weights), scale_dev, scale_host, a, b, c)
+
+
+_ONES = {}
+
+
+def one_like_seed(t: Tensor) -> Tensor:
+    """A persistent fp32 scalar 1 on t's device: `loss.backward(gradient=one_like_seed(loss))` spares the fill launch of the implicit seed."""
+    k = (t.device, t.dtype)
+    if k not in _ONES:
+        _ONES[k] = torch.ones((), dtype=t.dtype, device=t.device)
+    return _ONES[k]
+
+
 def lsgan_discriminator(real, fake):
     return LsganFn.apply(1, fake, real)
 

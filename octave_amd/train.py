@@ -587,11 +587,11 @@ class TrainStep:
         try:
             att, agg, _ = self.seg(x)
             l = F_.wpce_dice(agg, ys, from_logits=True)
-            loss = l[0] + l[1] if self.use_dice else l[0]
             out["wpce"], out["dice"] = l[0].detach(), l[1].detach()
+            kl2 = g_adv = None
             if self.adversarial:
                 p = F_.class_softmax(agg)
-                kl = F_.interlayer_kl([p, *att], [1] * len(att))[0]
+                kl2 = F_.interlayer_kl([p, *att], [1] * len(att))
                 # the generator pass only needs dL/d(att) through D: D's own weight gradients of this pass are discarded
                 # (zeroed before D's step, here and in the reference), so they are not computed at all
                 frozen = True
@@ -601,8 +601,10 @@ class TrainStep:
                 # backward pass writes the discriminator's gradient arena, which that graph zeroes and fills on its own stream)
                 g_adv = F_.lsgan_generator(disc(att))
                 assert not any(q.requires_grad for q in self.disc_arena.params)
-                loss = loss + self.kl_weight * kl + self.adv_weight * g_adv
-                out["kl"], out["g_adv"] = kl.detach(), g_adv.detach()
+                out["kl"], out["g_adv"] = kl2[0].detach(), g_adv.detach()
+            # ((wpce + dice) + kl_w kl) + adv_w g_adv and its loss-scaled copy: one launch each way (functional.LossCombineFn)
+            loss, scaled = F_.loss_combine(l, kl2, g_adv, (1.0, 1.0 if self.use_dice else 0.0, self.kl_weight, 0.0, self.adv_weight),
+                                           self.ls_state[0:1] if self.device_scale else None, 1.0 if self.device_scale else self.loss_scale)
             att_out = [a.detach() for a in att]
             if between is not None:
                 between(att_out)                  # capture(): the forward graph ends here (the discriminator's step only needs att_out)
@@ -612,7 +614,7 @@ class TrainStep:
                     F_.add_mark_hook(hooks, getattr(hooks, "tags", None) or self._tag_to_bucket.keys())     # capture(): cuts the graph at the bucket-completing marks
                 else:
                     F_.add_mark_hook(self._on_mark, self._tag_to_bucket.keys())
-            self._scaled(loss).backward()
+            scaled.backward(gradient=F_.one_like_seed(scaled))
             F_.flush_wgrads()
         finally:
             if hooked:
@@ -642,7 +644,9 @@ class TrainStep:
                 d_real = disc(real_pyramid)
                 d_fake = disc(att)
                 l_d = F_.lsgan_discriminator(d_real, d_fake)
-                self._scaled(l_d).backward()
+                _, scaled_d = F_.loss_combine(None, None, l_d, (0.0, 0.0, 0.0, 0.0, 1.0), self.ls_state[0:1] if self.device_scale else None,
+                                              1.0 if self.device_scale else self.loss_scale)
+                scaled_d.backward(gradient=F_.one_like_seed(scaled_d))
                 F_.flush_wgrads()
             finally:
                 F_.set_wgrad_fold_workspace(None)
@@ -650,11 +654,6 @@ class TrainStep:
                     F_.ZERO_SLAB.end()
                 F_.ZERO_SLAB = seg_slab
             out["loss_disc"] = l_d.detach()
-
-    def _scaled(self, loss: Tensor) -> Tensor:
-        if self.device_scale:
-            return loss * self.ls_state[0:1].reshape(())        # device scalar: the captured graph follows the scale
-        return loss * self.loss_scale if self.loss_scale != 1.0 else loss
 
     def _grad_scale(self) -> float:
         return 1.0 / (self.world * self.loss_scale)

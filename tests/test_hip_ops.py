@@ -1428,3 +1428,32 @@ def test_wgrad2d_patch_kernel_vs_torch(dev, dtype):
             check(f"wgrad2d {(B, Cin, H, W, Cout, g)}", dw, wr.grad, 0, 3e-4 * float(wr.grad.abs().max()))
     finally:
         L.octa_tuning_set(10, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dice,adv,dev_scale", [(True, True, True), (False, True, False), (True, False, False)])
+def test_loss_combine_matches_the_tensor_expression(dev, use_dice, adv, dev_scale):
+    """functional.loss_combine (one launch each way) against the sums it replaces, `l[0] + l[1] + kl_w * kl[0] + adv_w * g_adv` times the loss
+    scale: bit-identical total, scaled loss and gradients; a NaN in a zero-weight slot (the divergence's NaN flag) must not leak."""
+    from octave_amd import functional as F_
+    torch.manual_seed(5)
+    l = torch.rand(2, device=dev).requires_grad_(True)
+    kl2 = torch.tensor([0.37, float("nan")], device=dev).requires_grad_(True) if adv else None
+    g_adv = torch.rand((), device=dev).requires_grad_(True) if adv else None
+    klw, advw, scale = 0.1, 0.01, 1024.0
+    sdev = torch.tensor([scale], device=dev) if dev_scale else None
+    total, scaled = F_.loss_combine(l, kl2, g_adv, (1.0, 1.0 if use_dice else 0.0, klw, 0.0, advw), sdev, 1.0 if dev_scale else scale)
+    scaled.backward(gradient=F_.one_like_seed(scaled))
+    got = [l.grad.clone(), None if kl2 is None else kl2.grad.clone(), None if g_adv is None else g_adv.grad.clone()]
+    l2 = l.detach().clone().requires_grad_(True)
+    k2 = kl2.detach().clone().requires_grad_(True) if adv else None
+    g2 = g_adv.detach().clone().requires_grad_(True) if adv else None
+    ref = l2[0] + l2[1] if use_dice else l2[0]
+    if adv:
+        ref = ref + klw * k2[0] + advw * g2
+    ref_scaled = ref * (sdev[0:1].reshape(()) if dev_scale else scale)
+    ref_scaled.backward()
+    assert not total.requires_grad and torch.equal(total, ref.detach()) and torch.equal(scaled.detach(), ref_scaled.detach())
+    assert torch.equal(got[0], l2.grad)
+    if adv:
+        assert torch.equal(got[1], k2.grad) and torch.equal(got[2], g2.grad) and got[2].shape == g2.grad.shape
