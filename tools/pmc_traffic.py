@@ -34,6 +34,9 @@ def short(name):
     m9 = re.match(r"void wgrad9_kernel<(\d+), (\d+), (\d+)>", name)
     if m9:
         return f"wgrad9_kernel<{'f16' if int(m9.group(1)) else 'bf16'},256x256>"
+    m2 = re.match(r"void wgrad2d_kernel<(\d+)>", name)
+    if m2:
+        return f"wgrad2d_kernel<{'f16' if int(m2.group(1)) else 'bf16'},256x9x32>"
     mw = re.match(r"void wgrad8_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if mw:
         return f"wgrad8_kernel<{'f16' if int(mw.group(3)) else 'bf16'},{int(mw.group(1)) * 64}x{int(mw.group(2)) * 64}>"
