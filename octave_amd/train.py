@@ -26,18 +26,19 @@ from ._lib import lib
 from .layers import defer_bn_counters, flush_bn_counters
 
 
-def overlapping_stream(ref: Optional[torch.cuda.Stream] = None, tries: int = 6) -> torch.cuda.Stream:
+def overlapping_stream(ref: Optional[torch.cuda.Stream] = None, tries: int = 6, also: Sequence[torch.cuda.Stream] = ()) -> torch.cuda.Stream:
     """A new stream whose kernels really run BESIDE `ref`'s (default: the current stream).  HIP spreads its streams over a few hardware
     queues (four by default) in creation order, and two streams that share a queue are served in order: a side stream drawn blindly
     serialises with the main stream one time in four (measured on the captured B = 16, 400 x 400 step: 24.8 ms, and 25.5 ms for every fourth
     TrainStep built in one process -- the discriminator's graph then waits behind the backward pass; profiles/r05_stream_probe.txt).
     Probe: one spin kernel on each stream at the same time must take about as long as one alone; the first candidate that passes is
-    returned, the last one (with a warning) if none does.  OCTA_STREAM_PROBE=0 returns a plain new stream."""
+    returned, the last one (with a warning) if none does.  `also`: further streams the new one must run beside (the discriminator's stream and
+    the gradient-exchange stream at N > 1 must not share a queue either).  OCTA_STREAM_PROBE=0 returns a plain new stream."""
     if os.environ.get("OCTA_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
         return torch.cuda.Stream()
     ref = ref if ref is not None else torch.cuda.current_stream()
 
-    def timed(cycles: int, other: Optional[torch.cuda.Stream]) -> float:
+    def timed(cycles: int, other: Optional[torch.cuda.Stream], ref: torch.cuda.Stream = ref) -> float:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(ref):
             e0.record(ref)
@@ -63,7 +64,7 @@ def overlapping_stream(ref: Optional[torch.cuda.Stream] = None, tries: int = 6) 
     cand = None
     for _ in range(tries):
         cand = torch.cuda.Stream()
-        t2 = min(timed(cycles, cand) for _ in range(2))
+        t2 = max(min(timed(cycles, cand, r_) for _ in range(2)) for r_ in (ref, *also))
         if os.environ.get("OCTA_STREAM_PROBE") == "2":
             print(f"overlapping_stream: spin alone {t1:.3f} ms, beside candidate {_} {t2:.3f} ms -> {'runs beside' if t2 < 1.5 * t1 else 'SERIALISED'}", flush=True)
         if t2 < 1.5 * t1:
@@ -469,6 +470,7 @@ class TrainStep:
         defer_bn_counters(True)
         self._caps: Dict[int, _Capture] = {}
         self._comm_stream = None
+        self._probed_for = None
         self._disc_stream = None
         # 64 MB of fp32 scratch for the 8-wave conv kernel's tail split (octa_conv_desc.ws): the 25 x 25 / 50 x 50 decoder
         # layers launch 316 / 626 tiles on 256 CUs
@@ -925,9 +927,16 @@ class TrainStep:
         if self.adversarial:
             cap.feed.refill()
         g1, g2, g2b, g3 = cap.graphs
+        cur = torch.cuda.current_stream()
+        if self._probed_for != cur.cuda_stream:
+            # the side streams must run beside THIS stream (overlapping_stream): what the eager warm-up steps drew was probed against the capture's
+            # side stream, not against the stream the graphs replay on
+            self._probed_for = cur.cuda_stream
+            self._disc_stream = None
+            if _dist_on(self.world):
+                self._comm_stream = overlapping_stream(cur)
         comm = self._comm()
         started: List[int] = []
-        cur = torch.cuda.current_stream()
         side_d = self.concurrent_disc and self.adversarial
         d_done = None
         # the segmentor phase in pieces: the forward graph, then the backward pass cut where a gradient bucket completes: bucket k
@@ -940,7 +949,7 @@ class TrainStep:
                     # forward graph left, and writes only its own gradient arena
                     if self._disc_stream is None:
                         # default priority (a high-priority stream gave the whole gain back: 28.45 -> 29.2 ms), on a hardware queue of its own
-                        self._disc_stream = overlapping_stream(cur)
+                        self._disc_stream = overlapping_stream(cur, also=[comm] if _dist_on(self.world) else ())
                     self._disc_stream.wait_stream(cur)
                     with torch.cuda.stream(self._disc_stream):
                         g2.replay()
