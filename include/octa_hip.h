@@ -580,8 +580,8 @@ int octa_step_end(float* ls_state, int nflags, float growth, float backoff, int 
  * 0 = v_mfma_f32_32x32x16 (wgrad9), 1 = v_mfma_f32_16x16x32 at the same wave tile (wgrad9s), 2 = 32x32x16 with FOUR waves of 128 x 128 per
  * workgroup, 256 accumulator registers per lane (wgrad9a: a quarter fewer LDS fragment reads per FLOP).  key 10: bias-free 3x3 stride-1
  * layers with H % 5 == 0, W % 25 == 0, Cin / groups % 32 == 0 on the 2-D patch weight-gradient kernel (wgrad2d: one input patch shared by the
- * nine taps): 0 = never, 1 = every such layer, 2 (default) = the ungrouped ones with >= 1024 input and >= 256 output channels, where taking them out of
- * the batched wgrad9 launch is measured to pay. */
+ * nine taps): 0 = never, 1 = every such layer, 2 (default) = the ungrouped ones with >= 256 input and >= 256 output channels (one launch for up to
+ * four of them), where taking them out of the batched wgrad9 launch is measured to pay. */
 int octa_tuning_set(int key, int value);
 
 /* Debug / self-test: raw MFMA + transposed LDS read layout probes (tests only). */

@@ -31,13 +31,23 @@ struct Wg2dArgs {
     int rot, rot2;             // start offset (patches) per ci-tile / per co-tile inside the part
 };
 
+// up to four layers per launch: blocks [start[j], start[j] + nblk of job j) work on job j (start[j] is a multiple of 8, so blockIdx & 7 labels the
+// same XCD inside every job); one resident workgroup per CU means a second launch could only begin when the first one's last workgroup had ended --
+// in one launch the next job's workgroups follow on each CU as it frees up
+#define WG2D_MAXJOBS 4
+struct Wg2dBatch { int n; int start[WG2D_MAXJOBS + 1]; int nblk[WG2D_MAXJOBS]; Wg2dArgs job[WG2D_MAXJOBS]; };
 template <int F16>
-__global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
+__global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dBatch batch) {
+    int jb = 0;
+#pragma unroll
+    for (int k = 1; k < WG2D_MAXJOBS; ++k) if (k < batch.n && (int)blockIdx.x >= batch.start[k]) jb = k;
+    const Wg2dArgs& a = batch.job[jb];
     constexpr int PH = 5, PW = 25, NPIX = PH * PW, PR = PW + 2, PROWS = (PH + 2) * PR;     // 125 tile pixels, 27-pixel patch rows, 189 patch rows
     constexpr int DYHALF = 64 * 512, PIMG = 192 * 64, POFF = 4 * DYHALF;                   // ring of four 32 KB half-images of dy, then two 12 KB patch slots
     __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * DYHALF + 2 * PIMG];
 
-    const int total = gridDim.x, Lb = blockIdx.x;
+    const int total = batch.nblk[jb], Lb = (int)blockIdx.x - batch.start[jb];
+    if (Lb >= total) return;                                           // (padding blocks between two jobs)
     const int xcd = Lb & 7, jq = Lb >> 3, qn = total >> 3, rn = total & 7;
     int bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jq;
     const int tc = bid % a.tilesC; bid /= a.tilesC;
@@ -259,8 +269,8 @@ __global__ __launch_bounds__(768) void wgrad2d_kernel(const Wg2dArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 // octa_tuning_set(10, v): 3x3 stride-1 weight gradients of exact 5 x 25 geometries on wgrad2d: 0 = never, 1 = every geometry the kernel takes,
-// 2 (default) = where taking the layer out of the batched wgrad9 launch is measured to pay (ungrouped, >= 1024 input channels, OCTA_WG2D_MINC, and
-// >= 256 output channels: two of the decoder's 3x3 layers, profiles/r05_wgrad2d_ring.txt (f))
+// 2 (default) = where taking the layer out of the batched wgrad9 launch is measured to pay (ungrouped, >= 256 input channels, OCTA_WG2D_MINC, and
+// >= 256 output channels: the decoder's three big 3x3 layers, in ONE launch of their own; profiles/r05_wgrad2d_ring.txt (f), (h))
 static int g_wg2d = 2;
 static int wg2d_on() {
     static const int env = getenv("OCTA_WGRAD2D") ? atoi(getenv("OCTA_WGRAD2D")) : -1;
@@ -270,7 +280,7 @@ static bool wg2d_eligible(const octa_wgrad_job& j) {
     const octa_conv_desc& d = j.d;
     const int mode = wg2d_on();
     if (!mode || octa_deterministic()) return false;
-    static const int minc = getenv("OCTA_WG2D_MINC") ? atoi(getenv("OCTA_WG2D_MINC")) : 1024;
+    static const int minc = getenv("OCTA_WG2D_MINC") ? atoi(getenv("OCTA_WG2D_MINC")) : 256;
     if (mode == 2 && (d.groups != 1 || d.Cout < 256 || d.Cin < minc)) return false;
     if (d.dtype != OCTA_BF16 && d.dtype != OCTA_F16) return false;
     if (d.upshuffle || !j.x || !j.dy || !j.dw || j.dbias) return false;
@@ -284,9 +294,8 @@ static bool wg2d_eligible(const octa_wgrad_job& j) {
     for (int i = 0; i < 4; ++i) if (j.dw_strides[i] < 0) return false;
     return true;
 }
-static int wg2d_launch(const octa_wgrad_job& j, hipStream_t st) {
+static int wg2d_plan(const octa_wgrad_job& j, Wg2dArgs& a, int& nblk_out) {
     const octa_conv_desc& d = j.d;
-    Wg2dArgs a;
     a.x = (const unsigned short*)j.x; a.dy = (const unsigned short*)j.dy; a.dw = j.dw;
     a.B = d.B; a.H = d.H; a.W = d.W;
     a.groups = d.groups; a.Cg = d.Cin / d.groups; a.Ng = d.Cout / d.groups;
@@ -313,10 +322,30 @@ static int wg2d_launch(const octa_wgrad_job& j, hipStream_t st) {
     a.ppp = cdiv(a.npatch, best_parts);
     a.parts = cdiv(a.npatch, a.ppp);
     const int64_t nblk = tiles * a.parts;
-    if (nblk <= 0 || nblk >= (1ll << 30)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "wgrad2d: bad grid %lld", (long long)nblk);
-    if (d.dtype == OCTA_F16) wgrad2d_kernel<1><<<(unsigned)nblk, 768, 0, st>>>(a);
-    else wgrad2d_kernel<0><<<(unsigned)nblk, 768, 0, st>>>(a);
-    OCTA_CHECK_LAUNCH("wgrad2d");
-    octa_note_conv_kernel(d.dtype == OCTA_F16 ? "wgrad2d_kernel<f16,256x9x32>" : "wgrad2d_kernel<bf16,256x9x32>");
+    if (nblk <= 0 || nblk >= (1ll << 26)) OCTA_FAIL(OCTA_ERR_BAD_ARG, "wgrad2d: bad grid %lld", (long long)nblk);
+    nblk_out = (int)nblk;
+    return OCTA_OK;
+}
+// the eligible jobs of a batch (one dtype), WG2D_MAXJOBS per launch
+static int wg2d_launch(const octa_wgrad_job* const* jobs, int n, int f16, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += WG2D_MAXJOBS) {
+        Wg2dBatch b;
+        b.n = n - i0 < WG2D_MAXJOBS ? n - i0 : WG2D_MAXJOBS;
+        int at = 0;
+        for (int k = 0; k < WG2D_MAXJOBS; ++k) {
+            b.start[k] = at;
+            b.nblk[k] = 0;
+            if (k < b.n) {
+                const int rc = wg2d_plan(*jobs[i0 + k], b.job[k], b.nblk[k]);
+                if (rc) return rc;
+                at += (b.nblk[k] + 7) & ~7;
+            } else b.job[k] = b.job[0];
+        }
+        b.start[WG2D_MAXJOBS] = at;
+        if (f16) wgrad2d_kernel<1><<<(unsigned)at, 768, 0, st>>>(b);
+        else wgrad2d_kernel<0><<<(unsigned)at, 768, 0, st>>>(b);
+        OCTA_CHECK_LAUNCH("wgrad2d");
+    }
+    octa_note_conv_kernel(f16 ? "wgrad2d_kernel<f16,256x9x32>" : "wgrad2d_kernel<bf16,256x9x32>");
     return OCTA_OK;
 }

@@ -1968,13 +1968,10 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, float*
         ~FoldSession() { if (mine) octa_wgrad_fold_end(); }
         int close() { const bool m = mine; mine = false; return m ? octa_wgrad_fold_end() : OCTA_OK; }
     } fold(st, ws_bytes > 0 ? ws : nullptr, ws_bytes / 4);
+    std::vector<const octa_wgrad_job*> patch2d[2];          // [f16]: the jobs of the 2-D patch kernel, one launch per four
     for (int i = 0; i < n; ++i) {
         const octa_wgrad_job& j = jobs[i];
-        if (!off && wg2d_eligible(j)) {
-            const int rc = wg2d_launch(j, st);
-            if (rc) return rc;
-            continue;
-        }
+        if (!off && wg2d_eligible(j)) { patch2d[j.d.dtype == OCTA_F16 ? 1 : 0].push_back(&j); continue; }
         if (off || !wg8_eligible(j)) {
             const int rc = octa_conv2d_wgrad(&j.d, j.x, j.dy, j.dw, j.dw_strides, j.dbias, stream);
             if (rc) return rc;
@@ -1999,6 +1996,8 @@ extern "C" int octa_conv2d_wgrad_batch(const octa_wgrad_job* jobs, int n, float*
         p.splitM = 1; p.mPerSplit = 0; p.blockStart = 0; p.part = nullptr; p.part_slice = 0;
         plans[d.dtype == OCTA_F16 ? 1 : 0][pl.variant].push_back(pl);
     }
+    for (int f = 0; f < 2; ++f)
+        if (!patch2d[f].empty()) { const int rc = wg2d_launch(patch2d[f].data(), (int)patch2d[f].size(), f, st); if (rc) return rc; }
     for (int v = 0; v < 2; ++v) {
         if (!plans[0][v].empty()) { const int rc = wg8_launch<0>(plans[0][v], v, st); if (rc) return rc; }
         if (!plans[1][v].empty()) { const int rc = wg8_launch<1>(plans[1][v], v, st); if (rc) return rc; }

@@ -156,7 +156,7 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
     # weight gradient: the batched 8-wave kernel (what a TrainStep flush launches) and the immediate per-layer kernel
     taps = sorted({(0, 0), (k // 2, k // 2), (k - 1, k // 2)})
     refs = {t: _ref_wgrad_tap(x64, dy64, t[0], t[1], s, p, g) for t in taps}
-    # (the ungrouped 3x3 layers with >= 1024 input channels leave the batch for the 2-D patch kernel, wgrad2d: both kernels are checked there)
+    # (the ungrouped 3x3 layers with >= 256 channels on both sides leave the batch for the 2-D patch kernel, wgrad2d: both kernels are checked there)
     for mode in ("batched", "batched-no-wgrad2d", "immediate"):
         dw = torch.zeros(Cout, Cin // g, k, k, device=dev).contiguous(memory_format=torch.channels_last)
         if mode.startswith("batched"):
@@ -167,7 +167,7 @@ def test_big_layer_kernels_at_baseline_geometry(dev, case):
                 assert F_.pending_wgrads() == 1
                 job = F_._WGRAD_Q[0][0]
                 cls = int(L.octa_wgrad_job_class(ctypes.byref(job)))
-                patch = mode == "batched" and k == 3 and s == 1 and g == 1 and Cin >= 1024 and Cout >= 256 and H % 5 == 0 and W % 25 == 0
+                patch = mode == "batched" and k == 3 and s == 1 and g == 1 and Cin >= 256 and Cout >= 256 and H % 5 == 0 and W % 25 == 0
                 assert cls == 4 if patch else cls in (1, 2, 3), (cls, "this layer must run on the batched 8-wave kernels" if not patch else "... on wgrad2d")
                 F_.flush_wgrads()
             finally:

@@ -1408,6 +1408,7 @@ def test_wgrad2d_patch_kernel_vs_torch(dev, dtype):
     cases = [(2, 64, 10, 25, 256, 1), (4, 64, 25, 50, 256, 1), (1, 32, 5, 50, 128, 1), (2, 128, 10, 25, 512, 2), (2, 96, 5, 25, 384, 1), (3, 64, 15, 100, 256, 1)]
     gen = torch.Generator().manual_seed(21)
     L.octa_tuning_set(10, 1)
+    keep = []
     try:
         for (B, Cin, H, W, Cout, g) in cases:
             x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
@@ -1426,6 +1427,20 @@ def test_wgrad2d_patch_kernel_vs_torch(dev, dtype):
             wr = torch.zeros(Cout, Cin // g, 3, 3, requires_grad=True)
             torch.nn.functional.conv2d(x, wr, None, 1, 1, 1, g).backward(dy)
             check(f"wgrad2d {(B, Cin, H, W, Cout, g)}", dw, wr.grad, 0, 3e-4 * float(wr.grad.abs().max()))
+            keep.append((xd, dyd, d, wr.grad))
+        # all six layers in ONE call: two launches of the batched kernel (four jobs per launch), a job's blocks starting at a multiple of 8
+        jobs = (WgradJob * len(keep))()
+        dws = []
+        for i, (xd, dyd, d, _) in enumerate(keep):
+            dw = torch.zeros_like(keep[i][3]).to(dev).contiguous(memory_format=torch.channels_last)
+            ctypes.memmove(ctypes.byref(jobs[i].d), ctypes.byref(d), ctypes.sizeof(d))
+            jobs[i].x, jobs[i].dy, jobs[i].dw, jobs[i].dbias = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None
+            for a in range(4):
+                jobs[i].dw_strides[a] = dw.stride(a)
+            dws.append(dw)
+        L.octa_conv2d_wgrad_batch(jobs, len(keep), None, 0, torch.cuda.current_stream().cuda_stream)
+        for i, (_, _, _, want) in enumerate(keep):
+            check(f"wgrad2d batched job {i} {cases[i]}", dws[i], want, 0, 3e-4 * float(want.abs().max()))
     finally:
         L.octa_tuning_set(10, 2)
 
