@@ -825,3 +825,43 @@ def test_eval_fold_cache_follows_eager_training():
         assert (f1 - u1).abs().max().item() <= 2e-4 * u1.abs().max().item() + 1e-5, ((f1 - u1).abs().max().item(), (f1 - f0).abs().max().item())
     finally:
         st.close()
+
+
+@pytest.mark.gpu
+def test_side_streams_get_a_hardware_queue_of_their_own():
+    """train.overlapping_stream: HIP deals streams onto a few hardware queues in creation order and two streams on one queue run in order, so a side
+    stream drawn blindly serialises with the main stream about one time in four (profiles/r05_stream_probe.txt).  Streams drawn through the probe
+    must really overlap the reference stream -- and each other when asked: a spin kernel on both at once takes about as long as one alone."""
+    from octave_amd.train import overlapping_stream
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("torch.cuda._sleep is not available")
+    cur = torch.cuda.current_stream()
+
+    def both(a, b, cycles):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(a)
+        if b is not None:
+            b.wait_event(e0)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        if b is not None:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(cycles)
+                done = torch.cuda.Event()
+                done.record(b)
+            a.wait_event(done)
+        e1.record(a)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    cycles = 400_000
+    both(cur, None, cycles)
+    alone = min(both(cur, None, cycles) for _ in range(3))
+    made = []
+    for _ in range(6):                       # more streams than hardware queues: a blind draw would collide at least once
+        s1 = overlapping_stream(cur)
+        s2 = overlapping_stream(cur, also=[s1])
+        made += [s1, s2]
+        assert min(both(cur, s1, cycles) for _ in range(3)) < 1.5 * alone
+        assert min(both(cur, s2, cycles) for _ in range(3)) < 1.5 * alone
+        assert min(both(s1, s2, cycles) for _ in range(3)) < 1.5 * alone
