@@ -144,7 +144,9 @@ class _AvgDown(nn.Module):
     def forward(self, x):
         if self.k == 1:
             return x
-        return F_.avg_pool(x, self.k, self.k, 0, ceil_mode=True, count_include_pad=False)
+        # (a stage's first block pools the previous stage's output, which the decoder's cat consumes as well: the pool's backward
+        # kernel adds the cat's gradient slice when the encoder offered a holder for it -- functional.offer_fanout)
+        return F_.avg_pool(x, self.k, self.k, 0, ceil_mode=True, count_include_pad=False, fanout=F_.take_fanout())
 
 
 class _ConvBN(nn.Sequential):
@@ -224,7 +226,7 @@ class MaxPool3s2(nn.Module):
     kernel_size, stride, padding = 3, 2, 1
 
     def forward(self, x):
-        return F_.max_pool3s2(x)
+        return F_.max_pool3s2(x, F_.take_fanout())       # (the stem output also feeds decoder_1's cat: see _AvgDown)
 
 
 class ResNestDecoder(nn.Module):
@@ -279,6 +281,10 @@ class Upsampling(nn.Module):
 
     def forward(self, x):
         return self.up(x)
+
+    def cat_after(self, skip, x):
+        """torch.cat((skip, self(x)), dim=1) (compose.py:141-147 without a crop): the transposed conv stores into its slice of the cat."""
+        return F_.upsample_cat(skip, x, self.up.weight, self.up.bias)
 
 
 def resnest50(pretrained=False, **kwargs):

@@ -34,15 +34,25 @@ def _encode(net, x: Tensor):
     x = conv_bn(conv1[0], conv1[1], x, relu=True)
     x = conv_bn(conv1[3], conv1[4], x, relu=True)
     x_0_0 = conv_bn(conv1[6], bn1, x, relu=True)
+    # x_0_0 .. x_3 each feed the next encoder stage AND a decoder's cat.  The stage's first pooling op on the tensor (the stem's
+    # max-pool, the avg_down shortcut's pool) takes the holder offered here and adds the cat's gradient slice in its backward
+    # kernel; the decoders get the tensor through stash_grad, which parks that slice (no separate gradient-sum launch).
+    h0 = F_.offer_fanout(x_0_0)
     x_0_1 = net.encoder_0_2_2(x_0_0)
+    F_.withdraw_fanout()
     x_1 = net.encoder_1(mark(x_0_1, "encoder_1"))
+    h1 = F_.offer_fanout(x_1)
     x_2 = net.encoder_2(mark(x_1, "encoder_2"))
+    h2 = F_.offer_fanout(x_2)
     x_3 = net.encoder_3(mark(x_2, "encoder_3"))
     pad_h, pad_w = x_3.shape[2] % 2, x_3.shape[3] % 2
     if pad_h or pad_w:                                   # ref :125-130
         x_3 = F_.pad_bottom_right(x_3, pad_h, pad_w)
+    h3 = F_.offer_fanout(x_3)
     x_4 = net.encoder_4(mark(x_3, "encoder_4"))
-    return x_0_0, x_1, x_2, x_3, x_4, pad_h, pad_w
+    F_.withdraw_fanout()
+    return (F_.skip_with_fanout(x_0_0, h0), F_.skip_with_fanout(x_1, h1), F_.skip_with_fanout(x_2, h2), F_.skip_with_fanout(x_3, h3),
+            x_4, pad_h, pad_w)
 
 
 def _check_input(x: Tensor, who: str):
@@ -136,15 +146,15 @@ class ResnestUNet(nn.Module):
         if self.gating_level >= 4:
             d_4, y_4 = self.aag_4(d_4)
             attentions.append(y_4)
-        d_3 = self.decoder_3(mark(F_.cat_crop(x_2, self.upsampling_3(d_4)), "decoder_3"))
+        d_3 = self.decoder_3(mark(self.upsampling_3.cat_after(x_2, d_4), "decoder_3"))
         if self.gating_level >= 3:
             d_3, y_3 = self.aag_3(d_3)
             attentions.append(y_3)
-        d_2 = self.decoder_2(mark(F_.cat_crop(x_1, self.upsampling_2(d_3)), "decoder_2"))
+        d_2 = self.decoder_2(mark(self.upsampling_2.cat_after(x_1, d_3), "decoder_2"))
         if self.gating_level >= 2:
             d_2, y_2 = self.aag_2(d_2)
             attentions.append(y_2)
-        d_1 = self.decoder_1(mark(F_.cat_crop(x_0_0, self.upsampling_1(d_2)), "decoder_1"))
+        d_1 = self.decoder_1(mark(self.upsampling_1.cat_after(x_0_0, d_2), "decoder_1"))
         if self.gating_level >= 1:
             d_1, y_1 = self.aag_1(d_1)
             attentions.append(y_1)
@@ -261,11 +271,11 @@ class _ParallelHeadBase(nn.Module):
             return d
         d_4 = self.decoder_4(F_.cat_crop(x_3, self.upsampling_4(x_4), x_3.shape[2] - pad_h, x_3.shape[3] - pad_w))
         d_4 = gate("aag_4", d_4, 3, att, strict=True)          # ref :473: `> 3`
-        d_3 = gate("aag_3", self.decoder_3(F_.cat_crop(x_2, self.upsampling_3(d_4))), 3, att)
-        d_2 = gate("aag_2", self.decoder_2(F_.cat_crop(x_1, self.upsampling_2(d_3))), 2, att)
-        d_1 = gate("aag_1", self.decoder_1(F_.cat_crop(x_0_0, self.upsampling_1(d_2))), 1, att)
+        d_3 = gate("aag_3", self.decoder_3(self.upsampling_3.cat_after(x_2, d_4)), 3, att)
+        d_2 = gate("aag_2", self.decoder_2(self.upsampling_2.cat_after(x_1, d_3)), 2, att)
+        d_1 = gate("aag_1", self.decoder_1(self.upsampling_1.cat_after(x_0_0, d_2)), 1, att)
         d_0 = gate("aag_0", self.decoder_0(self.upsampling_0(d_1)), 0, att)
-        d_1_c = gate("aag_1_c", self.decoder_1_c(F_.cat_crop(x_0_0, self.upsampling_1_c(x_1))), 1, att_c)
+        d_1_c = gate("aag_1_c", self.decoder_1_c(self.upsampling_1_c.cat_after(x_0_0, x_1)), 1, att_c)
         d_0_c = gate("aag_0_c", self.decoder_0_c(self.upsampling_0_c(d_1_c)), 0, att_c)
         att.reverse()
         att_c.reverse()

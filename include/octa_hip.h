@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 314
+#define OCTA_HIP_ABI_VERSION 315
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -282,6 +282,15 @@ int octa_avgpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH,
                      int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
 int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int OH, int OW, int k,
                      int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
+/* The same backward passes with a FAN-OUT ADDEND: dx = pool^T(dy) + addend, where addend (NULL = none) is the gradient another
+ * consumer of the pooled tensor produced -- the U-Net skip connections (compose.py:141-147: x_k feeds the decoder's cat AND the
+ * next encoder stage, whose first op on it is the avg_down shortcut's pool, resnest.py:383 / the stem's max-pool, compose.py:45) --
+ * read with its own per-pixel stride ld_addend (elements, % 8 == 0, >= C; a channel slice of the cat's gradient), summed in fp32
+ * before the one rounding of dx.  Replaces autograd's separate add kernel over the two gradients. */
+int octa_maxpool3s2_bwd_add(const void* dy, const uint8_t* argmax, void* dx, const void* addend, int ld_addend, int B, int H, int W,
+                            int C, int OH, int OW, int dtype, octa_stream_t stream);
+int octa_avgpool_bwd_add(const void* dy, void* dx, const void* addend, int ld_addend, int B, int H, int W, int C, int OH, int OW,
+                         int k, int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The rest of the reference's public surface around the hot path, extras.hip.

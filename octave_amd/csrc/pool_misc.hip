@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ am, T* __restrict__ dx, int B,
-                                                          int H, int W, int C, int OH, int OW) {
+                                                          int H, int W, int C, int OH, int OW, const T* __restrict__ add, int ldadd) {
     constexpr int EPC = DT<T>::EPC;
     const int cpr = C / EPC;
     const int64_t total = (int64_t)B * H * W * cpr;
@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        // fan-out gradient sum: the other consumer's gradient of the pooled tensor (any per-pixel stride) starts the accumulator
+        if (add) unpack16<T>(*(const uint4*)(add + ((int64_t)(b * H + ih) * W + iw) * ldadd + c0), acc);
         // windows (oh, ow) with ih = 2*oh - 1 + kh
         for (int kh = 0; kh < 3; ++kh) {
             const int th = ih + 1 - kh;
@@ -90,10 +92,18 @@ extern "C" int octa_maxpool3s2_fwd(const void* x, void* y, uint8_t* argmax, int 
     OCTA_CHECK_LAUNCH("maxpool_fwd");
     return OCTA_OK;
 }
+extern "C" int octa_maxpool3s2_bwd_add(const void* dy, const uint8_t* argmax, void* dx, const void* addend, int ld_addend, int B, int H, int W, int C,
+                                       int OH, int OW, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(dy && dx && argmax && C % 8 == 0, "octa_maxpool3s2_bwd_add: bad arguments");
+    OCTA_REQUIRE(!addend || (ld_addend >= C && ld_addend % 8 == 0 && ((uintptr_t)addend & 15) == 0), "octa_maxpool3s2_bwd_add: addend stride / alignment");
+    DISPATCH_T(dtype, "octa_maxpool3s2_bwd_add", maxpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, argmax, (T*)dx, B, H, W, C, OH, OW, (const T*)addend, ld_addend);)
+    OCTA_CHECK_LAUNCH("maxpool_bwd");
+    return OCTA_OK;
+}
 extern "C" int octa_maxpool3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C, int OH, int OW, int dtype,
                                    octa_stream_t stream) {
     OCTA_REQUIRE(dy && dx && argmax && C % 8 == 0, "octa_maxpool3s2_bwd: bad arguments");
-    DISPATCH_T(dtype, "octa_maxpool3s2_bwd", maxpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, argmax, (T*)dx, B, H, W, C, OH, OW);)
+    DISPATCH_T(dtype, "octa_maxpool3s2_bwd", maxpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, argmax, (T*)dx, B, H, W, C, OH, OW, (const T*)nullptr, 0);)
     OCTA_CHECK_LAUNCH("maxpool_bwd");
     return OCTA_OK;
 }
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW,
-                                                          int k, int s, int p, int cip) {
+                                                          int k, int s, int p, int cip, const T* __restrict__ add, int ldadd) {
     constexpr int EPC = DT<T>::EPC;
     const int cpr = C / EPC;
     const int64_t total = (int64_t)B * H * W * cpr;
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        if (add) unpack16<T>(*(const uint4*)(add + ((int64_t)(b * H + ih) * W + iw) * ldadd + c0), acc);     // (see maxpool_bwd_kernel)
         // windows containing (ih, iw): oh in [ceil((ih+p-k+1)/s), floor((ih+p)/s)]
         const int oh_hi = min((ih + p) / s, OH - 1), ow_hi = min((iw + p) / s, OW - 1);
         const int th = ih + p - k + 1, tw = iw + p - k + 1;
@@ -180,10 +191,18 @@ extern "C" int octa_avgpool_fwd(const void* x, void* y, int B, int H, int W, int
     OCTA_CHECK_LAUNCH("avgpool_fwd");
     return OCTA_OK;
 }
+extern "C" int octa_avgpool_bwd_add(const void* dy, void* dx, const void* addend, int ld_addend, int B, int H, int W, int C, int OH, int OW, int k,
+                                    int stride, int pad, int count_include_pad, int dtype, octa_stream_t stream) {
+    OCTA_REQUIRE(dy && dx && C % 8 == 0 && k > 0 && stride > 0, "octa_avgpool_bwd_add: bad arguments");
+    OCTA_REQUIRE(!addend || (ld_addend >= C && ld_addend % 8 == 0 && ((uintptr_t)addend & 15) == 0), "octa_avgpool_bwd_add: addend stride / alignment");
+    DISPATCH_T(dtype, "octa_avgpool_bwd_add", avgpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)dx, B, H, W, C, OH, OW, k, stride, pad, count_include_pad, (const T*)addend, ld_addend);)
+    OCTA_CHECK_LAUNCH("avgpool_bwd");
+    return OCTA_OK;
+}
 extern "C" int octa_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
                                 int count_include_pad, int dtype, octa_stream_t stream) {
     OCTA_REQUIRE(dy && dx && C % 8 == 0 && k > 0 && stride > 0, "octa_avgpool_bwd: bad arguments");
-    DISPATCH_T(dtype, "octa_avgpool_bwd", avgpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)dx, B, H, W, C, OH, OW, k, stride, pad, count_include_pad);)
+    DISPATCH_T(dtype, "octa_avgpool_bwd", avgpool_bwd_kernel<T><<<ew_blocks((int64_t)B * H * W * C / DT<T>::EPC), 256, 0, (hipStream_t)stream>>>((const T*)dy, (T*)dx, B, H, W, C, OH, OW, k, stride, pad, count_include_pad, (const T*)nullptr, 0);)
     OCTA_CHECK_LAUNCH("avgpool_bwd");
     return OCTA_OK;
 }

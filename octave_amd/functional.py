@@ -5,6 +5,7 @@ is NHWC (channels-last) with a per-pixel stride `ld` that is a multiple of 8.
 """
 import ctypes
 import os
+import threading
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -1103,12 +1104,13 @@ def _gate_operand(gate, dy_dtype):
 class GradHolder:
     """Carries the gradient of one consumer of a tensor to the conv that consumes the same tensor, so that the conv's data
     gradient can add it in its epilogue (fan-out gradient sum without autograd's separate add kernel)."""
-    __slots__ = ("grad", "consumed", "event")
+    __slots__ = ("grad", "consumed", "event", "taken")
 
     def __init__(self):
         self.grad = None
         self.consumed = False
         self.event = None           # recorded behind the parked gradient: the consumer may run on another stream (side branches)
+        self.taken = False          # a backward pass that adds the parked gradient has been wired to this holder (offer_fanout)
 
 
 class StashGradFn(Function):
@@ -1135,6 +1137,59 @@ class StashGradFn(Function):
 
 def stash_grad(x: Tensor, holder: GradHolder) -> Tensor:
     return StashGradFn.apply(x, holder)
+
+
+# U-Net skip connections (compose.py:141-147): x_k feeds the decoder's cat and the next encoder stage.  The encoder builds the stage
+# first, so it OFFERS a holder before calling the stage; the stage's first pooling op on x_k (the avg_down shortcut's pool, the stem's
+# max-pool) takes the offer and adds whatever is parked there in its backward kernel (octa_*pool*_bwd_add); the decoder then parks the
+# cat's gradient slice through stash_grad -- only if the offer was taken (holder.taken), otherwise it uses x_k as is.
+_FUSE_FANOUT_SKIP = os.environ.get("OCTA_FUSE_FANOUT_SKIP", "1") != "0"
+_FANOUT_TLS = threading.local()
+
+
+def offer_fanout(x: Tensor) -> Optional[GradHolder]:
+    """A holder for the gradient of another consumer of `x`, offered to the next pooling op that asks (take_fanout); None when
+    nothing would be differentiated."""
+    if not (_FUSE_FANOUT_SKIP and torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+        _FANOUT_TLS.offer = None
+        return None
+    h = GradHolder()
+    _FANOUT_TLS.offer = h
+    return h
+
+
+def take_fanout() -> Optional[GradHolder]:
+    h = getattr(_FANOUT_TLS, "offer", None)
+    _FANOUT_TLS.offer = None
+    if h is not None and _IN_SIDE:
+        return None                    # (a pool on a side stream: the parked gradient would need an event of its own -- not wired)
+    if h is not None:
+        h.taken = True
+    return h
+
+
+def withdraw_fanout():
+    _FANOUT_TLS.offer = None
+
+
+def skip_with_fanout(x: Tensor, holder: Optional[GradHolder]) -> Tensor:
+    """x as the decoder's cat should consume it: through stash_grad when a pooling backward adds the parked gradient."""
+    return stash_grad(x, holder) if (holder is not None and holder.taken) else x
+
+
+def _fanout_addend(holder: Optional[GradHolder], dy: Tensor, shape):
+    """(addend usable by the *_bwd_add kernels or None, gradient to add afterwards with ATen or None)"""
+    if holder is None:
+        return None, None
+    holder.consumed = True
+    g, holder.grad = holder.grad, None
+    if g is None:
+        return None, None
+    if holder.event is not None:
+        torch.cuda.current_stream().wait_event(holder.event)
+    if g.dtype == dy.dtype and tuple(g.shape) == tuple(shape) and nhwc_ld(g) is not None:
+        return g, None
+    return None, g
 
 
 class Conv2dFn(Function):
@@ -1216,12 +1271,7 @@ class ConvTranspose2x2Fn(Function):
         CinT, CoutT = w.shape[0], w.shape[1]
         if Cin != CinT or tuple(w.shape[2:]) != (2, 2):
             raise OctaError("conv_transpose2x2: weight must be (Cin, Cout, 2, 2)")
-        x, ldx = _conv_input(x, round8(Cin), 1)
-        y = nhwc_empty(B, CoutT, 2 * H, 2 * W, x.dtype, x.device)
-        d = _desc(B, H, W, H, W, Cin, 4 * CoutT, 1, 1, 1, 0, 1, ldx, nhwc_ld(y), x.dtype, ACT_NONE, upshuffle=1)
-        wp = _packed(w, "convT", x.dtype, 1, d.cin_g_pad)
-        _launch_fwd(d, x, wp, bias, y)
-        _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
+        x, y = _conv_transpose2x2_into(x, w, bias, None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -1231,20 +1281,91 @@ class ConvTranspose2x2Fn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        # the adjoint is a plain conv k2 s2 p0 from the (2H,2W,CoutT) image to (H,W,CinT) whose OIHW weight is w itself
-        dx = raw_conv_fwd(dy, w, None, 2, 0, 1) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            sw = _sink(w)
-            dw = _ret(w, raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1, sw, defer=sw is not None))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            b = ctx.bias_ref
-            db = _ret(b, raw_colsum(dy, _sink(b)))
-        return dx, dw, db
+        return _conv_transpose2x2_bwd(x, w, ctx.bias_ref if ctx.has_bias else None, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2])
+
+
+def _conv_transpose2x2_into(x, w, bias, y):
+    """The up-shuffle GEMM of a ConvTranspose2d(k=2, s=2); `y`: NHWC (B, CoutT, 2H, 2W) destination (may be a channel slice of a wider
+    buffer: the kernels take its per-pixel stride), allocated here when None.  Returns (x as launched, y)."""
+    B, Cin, H, W = x.shape
+    CoutT = w.shape[1]
+    x, ldx = _conv_input(x, round8(Cin), 1)
+    if y is None:
+        y = nhwc_empty(B, CoutT, 2 * H, 2 * W, x.dtype, x.device)
+    d = _desc(B, H, W, H, W, Cin, 4 * CoutT, 1, 1, 1, 0, 1, ldx, nhwc_ld(y), x.dtype, ACT_NONE, upshuffle=1)
+    wp = _packed(w, "convT", x.dtype, 1, d.cin_g_pad)
+    _launch_fwd(d, x, wp, bias, y)
+    _record("fwd", d, (_p(x), _p(wp), _p(bias), _p(y)), (x, wp, bias, y))
+    return x, y
+
+
+def _conv_transpose2x2_bwd(x, w, bias, dy, need_x, need_w, need_b):
+    # the adjoint is a plain conv k2 s2 p0 from the (2H,2W,CoutT) image to (H,W,CinT) whose OIHW weight is w itself
+    dx = raw_conv_fwd(dy, w, None, 2, 0, 1) if need_x else None
+    dw = db = None
+    if need_w:
+        sw = _sink(w)
+        dw = _ret(w, raw_conv_wgrad(to_nhwc(dy, dtype=x.dtype), x, w, 2, 0, 1, sw, defer=sw is not None))
+    if need_b:
+        db = _ret(bias, raw_colsum(dy, _sink(bias)))
+    return dx, dw, db
 
 
 def conv_transpose2x2(x, w, bias):
     return ConvTranspose2x2Fn.apply(x, w, bias)
+
+
+class UpCatFn(Function):
+    """torch.cat((skip, ConvTranspose2d(k=2, s=2)(x)), dim=1) without a crop (compose.py:141-147 with extra/resnest.py:50): the up-shuffle
+    GEMM stores straight into its channel slice of the cat buffer (per-pixel stride = the cat's channel count), so the copy of the
+    up-sampled half -- 41 / 82 / 82 MB each way at 50 x 50 / 100 x 100 / 200 x 200 of the B = 16, 400 x 400 step -- does not happen.
+    The backward pass is CatFn's (zero-copy channel slices) followed by ConvTranspose2x2Fn's."""
+
+    @staticmethod
+    def forward(ctx, skip, x, w, bias):
+        _require_gpu(x)
+        B, Cin, H, W = x.shape
+        if Cin != w.shape[0] or tuple(w.shape[2:]) != (2, 2):
+            raise OctaError("conv_transpose2x2: weight must be (Cin, Cout, 2, 2)")
+        Cb = w.shape[1]
+        a = to_nhwc(skip)
+        Ca = a.shape[1]
+        if tuple(a.shape[2:]) != (2 * H, 2 * W) or Ca % 8 or Cb % 8:
+            raise OctaError("upsample_cat: the skip tensor must be (B, 8k, 2H, 2W) and the up-sampled channel count a multiple of 8")
+        out = nhwc_empty(B, Ca + Cb, 2 * H, 2 * W, a.dtype, a.device)
+        lib().octa_copy_channels(_p(a), 2 * H, 2 * W, nhwc_ld(a), 0, _p(out), 2 * H, 2 * W, Ca + Cb, 0, B, Ca, _dt(a), 0, _st())
+        xl, _ = _conv_transpose2x2_into(x, w, bias, out[:, Ca:])
+        ctx.save_for_backward(xl, w)
+        ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
+        ctx.Ca = Ca
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        x, w = ctx.saved_tensors
+        d = to_nhwc(d)
+        Ca = ctx.Ca
+        dx, dw, db = _conv_transpose2x2_bwd(x, w, ctx.bias_ref if ctx.has_bias else None, d[:, Ca:], ctx.needs_input_grad[1],
+                                            ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3])
+        return (d[:, :Ca] if ctx.needs_input_grad[0] else None), dx, dw, db
+
+
+_FUSE_UPCAT = os.environ.get("OCTA_FUSE_UPCAT", "1") != "0"
+
+
+def upsample_cat(skip, x, w, bias, Hc=None, Wc=None):
+    """cat_crop(skip, conv_transpose2x2(x, w, bias), Hc, Wc); one launch fewer and no copy of the up-sampled half when nothing is
+    cropped (OCTA_FUSE_UPCAT=0: the two separate ops, the parity twin)."""
+    Hc = skip.shape[2] if Hc is None else Hc
+    Wc = skip.shape[3] if Wc is None else Wc
+    fits = (_FUSE_UPCAT and x.is_cuda and (Hc, Wc) == tuple(skip.shape[2:]) == (2 * x.shape[2], 2 * x.shape[3])
+            and skip.shape[1] % 8 == 0 and w.shape[1] % 8 == 0 and skip.dtype == x.dtype and nhwc_ld(skip) is not None)
+    if not fits:
+        return cat_crop(skip, conv_transpose2x2(x, w, bias), Hc, Wc)
+    return UpCatFn.apply(skip, x, w, bias)
 
 
 class BatchNormFn(Function):
@@ -1280,7 +1401,8 @@ def batch_norm(x, gamma, beta, rm, rv, momentum=0.1, eps=1e-5, training=True, re
 
 class MaxPool3s2Fn(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder=None):
+        ctx.holder = holder
         x = dense_nhwc(x)
         B, C, H, W = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -1298,17 +1420,20 @@ class MaxPool3s2Fn(Function):
         B, C, H, W = ctx.shape
         dy = dense_nhwc(dy)
         dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
-        lib().octa_maxpool3s2_bwd(_p(dy), _p(am), _p(dx), B, H, W, C, dy.shape[2], dy.shape[3], _dt(dy), _st())
-        return dx
+        add, late = _fanout_addend(ctx.holder, dy, (B, C, H, W))
+        lib().octa_maxpool3s2_bwd_add(_p(dy), _p(am), _p(dx), _p(add), nhwc_ld(add) if add is not None else 0, B, H, W, C, dy.shape[2], dy.shape[3],
+                                      _dt(dy), _st())
+        return (dx if late is None else dx + late), None
 
 
-def max_pool3s2(x):
-    return MaxPool3s2Fn.apply(x)
+def max_pool3s2(x, fanout: Optional[GradHolder] = None):
+    return MaxPool3s2Fn.apply(x, fanout)
 
 
 class AvgPoolFn(Function):
     @staticmethod
-    def forward(ctx, x, k, stride, pad, ceil_mode, count_include_pad):
+    def forward(ctx, x, k, stride, pad, ceil_mode, count_include_pad, holder=None):
+        ctx.holder = holder
         x = dense_nhwc(x)
         B, C, H, W = x.shape
 
@@ -1330,12 +1455,14 @@ class AvgPoolFn(Function):
         B, C, H, W, OH, OW, k, stride, pad, cip = ctx.cfg
         dy = dense_nhwc(dy)
         dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
-        lib().octa_avgpool_bwd(_p(dy), _p(dx), B, H, W, C, OH, OW, k, stride, pad, cip, _dt(dy), _st())
-        return dx, None, None, None, None, None
+        add, late = _fanout_addend(ctx.holder, dy, (B, C, H, W))
+        lib().octa_avgpool_bwd_add(_p(dy), _p(dx), _p(add), nhwc_ld(add) if add is not None else 0, B, H, W, C, OH, OW, k, stride, pad, cip,
+                                   _dt(dy), _st())
+        return (dx if late is None else dx + late), None, None, None, None, None, None
 
 
-def avg_pool(x, k, stride, pad=0, ceil_mode=False, count_include_pad=True):
-    return AvgPoolFn.apply(x, k, stride, pad, ceil_mode, count_include_pad)
+def avg_pool(x, k, stride, pad=0, ceil_mode=False, count_include_pad=True, fanout: Optional[GradHolder] = None):
+    return AvgPoolFn.apply(x, k, stride, pad, ceil_mode, count_include_pad, fanout)
 
 
 class CatFn(Function):

@@ -251,6 +251,47 @@ def test_pools(dev, dtype):
             check(f"{name} bwd {B,C,H,W}", xd.grad, xr.grad, **t)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_backward_adds_a_parked_fanout_gradient(dev, dtype):
+    """octa_maxpool3s2_bwd_add / octa_avgpool_bwd_add (round 5): x feeds a pool AND a second consumer (a channel slice of a wider
+    cat, the U-Net skip of compose.py:141-147); the second consumer's gradient is parked by stash_grad and added by the pool's
+    backward kernel.  Against torch on CPU, and against autograd's own sum with the holder withheld."""
+    from octave_amd import functional as F_
+    t = TOL[dtype]
+    for (B, C, H, W) in [(2, 16, 8, 8), (2, 8, 9, 7), (1, 64, 13, 13)]:
+        x = rnd((B, C, H, W), 40, -1, 1)
+        x[:, :, ::3, ::2] = 0.0
+        other = rnd((B, 8, H, W), 41)
+        if dtype != torch.float32:
+            x, other = x.to(dtype).float(), other.to(dtype).float()
+        for name, fr, fg in [
+            ("maxpool3s2", lambda a: F.max_pool2d(a, 3, 2, 1), lambda a, h: F_.max_pool3s2(a, h)),
+            ("avgpool2s2ceil", lambda a: F.avg_pool2d(a, 2, 2, ceil_mode=True, count_include_pad=False),
+             lambda a, h: F_.avg_pool(a, 2, 2, 0, True, False, h)),
+        ]:
+            xr = x.clone().requires_grad_(True)
+            yr, cr = fr(xr), torch.cat((xr, other), 1)
+            gy, gc = rnd(tuple(yr.shape), 42), rnd(tuple(cr.shape), 43)
+            ((yr * gy).sum() + (cr * gc).sum()).backward()
+            grads = []
+            for fused in (True, False):
+                xd = F_.to_nhwc(x.to(dev), dtype=dtype).requires_grad_(True)
+                od = F_.to_nhwc(other.to(dev), dtype=dtype)
+                h = F_.offer_fanout(xd) if fused else None
+                assert (h is not None) == fused
+                if fused:
+                    h = F_.take_fanout()
+                y = fg(xd, h)
+                c = F_.cat_crop(F_.skip_with_fanout(xd, h), od)        # the slice of c's gradient is a strided view
+                assert (type(c.grad_fn.next_functions[0][0]).__name__ == "StashGradFnBackward") == fused
+                ((y.float() * gy.to(dev)).sum() + (c.float() * gc.to(dev)).sum()).backward()
+                assert h is None or (h.consumed and h.grad is None)
+                check(f"{name}+fanout bwd {B,C,H,W} fused={fused}", xd.grad, xr.grad, **t)
+                grads.append(xd.grad.float().cpu())
+            if dtype == torch.float32:
+                check(f"{name}+fanout fused vs autograd's add", grads[0], grads[1], 1e-6, 1e-6)
+
+
 def test_cat_pad_crop(dev):
     from octave_amd import functional as F_
     a = rnd((2, 16, 4, 4), 22)
@@ -602,6 +643,45 @@ def test_pwgemm_conv_transpose_upshuffle_vs_torch(dev, algo):
         F_._ALGO_OVERRIDE = 0
     t = TOL[torch.bfloat16]
     check(f"pwgemm up-shuffle algo {algo}", y, want, t["rtol"], t["atol"] * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 128, 11, 13, 72, 64), (1, 64, 25, 25, 256, 256), (2, 256, 6, 9, 64, 64)])
+def test_upsample_cat_matches_cat_of_conv_transpose(dev, case, dtype):
+    """functional.upsample_cat (round 5: the up-shuffle GEMM stores into its channel slice of the cat buffer) against
+    torch.cat((skip, conv_transpose2d(x))) on CPU, and against the two separate ops of this library (cat_crop of conv_transpose2x2:
+    same kernels, only the output's per-pixel stride differs -> bit-identical forward and data gradients)."""
+    from octave_amd import functional as F_
+    B, Cin, H, W, Cout, Cs = case
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dtype).float()
+    skip = torch.randn(B, Cs, 2 * H, 2 * W, generator=gen).to(dtype).float()
+    w = (torch.randn(Cin, Cout, 2, 2, generator=gen) * 0.1).to(dtype).float()
+    bias = torch.randn(Cout, generator=gen)
+    dout = torch.randn(B, Cs + Cout, 2 * H, 2 * W, generator=gen).to(dtype).float()
+    xr, sr, wr, br = (t.clone().requires_grad_(True) for t in (x, skip, w, bias))
+    want = torch.cat((sr, F.conv_transpose2d(xr, wr, br, stride=2)), dim=1)
+    want.backward(dout)
+
+    def run(fused):
+        xs = F_.to_nhwc(x.to(dev), dtype=dtype).requires_grad_(True)
+        ss = F_.to_nhwc(skip.to(dev), dtype=dtype).requires_grad_(True)
+        wd, bd = w.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+        old = F_._FUSE_UPCAT
+        F_._FUSE_UPCAT = fused
+        try:
+            y = F_.upsample_cat(ss, xs, wd, bd)
+        finally:
+            F_._FUSE_UPCAT = old
+        assert (type(y.grad_fn).__name__ == "UpCatFnBackward") == fused, type(y.grad_fn).__name__
+        y.backward(F_.to_nhwc(dout.to(dev), dtype=dtype))
+        return y, xs.grad, ss.grad, wd.grad, bd.grad
+    got, twin = run(True), run(False)
+    t = TOL[dtype]
+    for name, g, tw, wnt in zip(("y", "dx", "dskip", "dw", "dbias"), got, twin, (want, xr.grad, sr.grad, wr.grad, br.grad)):
+        check(f"upsample_cat {name} {case}", g, wnt, t["rtol"], t["atol"] * float(wnt.abs().max()))
+        if name in ("y", "dx", "dskip"):        # (the weight / bias gradients may add their partial sums in launch order)
+            assert torch.equal(g.float().cpu(), tw.float().cpu()), f"upsample_cat {name}: fused and separate ops differ"
 
 
 HALO8_CASES = [
