@@ -284,6 +284,12 @@ class Upsampling(nn.Module):
 
     def cat_after(self, skip, x):
         """torch.cat((skip, self(x)), dim=1) (compose.py:141-147 without a crop): the transposed conv stores into its slice of the cat."""
+        hooked = any(getattr(m, a, None) for m in (self, self.up)
+                     for a in ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks"))
+        gm = torch.nn.modules.module
+        hooked = hooked or bool(getattr(gm, "_global_forward_hooks", None)) or bool(getattr(gm, "_global_forward_pre_hooks", None))
+        if hooked:                       # a module hook must see this module's own output: the two separate ops
+            return F_.cat_crop(skip, self(x))
         return F_.upsample_cat(skip, x, self.up.weight, self.up.bias)
 
 

@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 315
+#define OCTA_HIP_ABI_VERSION 316
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -459,6 +459,15 @@ int octa_interlayer_kl_bwd(const float* basis, const float* const* maps_host, co
                            const float* weights_host, int n_maps, float wsum, int B, int K, int H,
                            int W, const float* g, float* dbasis, float* const* dmaps_host,
                            octa_stream_t stream);
+/* The same with FAN-OUT ADDENDS: dbasis += basis_addend, dmaps[i] += map_addends_host[i] (each NULL = none; dense fp32, the
+ * map's own shape): the gradient the other consumer of an attention map produced -- the discriminator's generator pass
+ * (models/octa.py training step: the maps feed InterlayerDivergence AND the discriminator) -- added where the KL gradient
+ * is written instead of by autograd's separate add launch per map. */
+int octa_interlayer_kl_bwd_add(const float* basis, const float* const* maps_host, const int* shifts_host,
+                               const float* weights_host, int n_maps, float wsum, int B, int K, int H,
+                               int W, const float* g, float* dbasis, float* const* dmaps_host,
+                               const float* basis_addend, const float* const* map_addends_host,
+                               octa_stream_t stream);
 
 /* LS-GAN losses (discriminator/losses.py:11-14, 22-24).  mode 0: 0.5*mean((f-1)^2) (generator);
  * mode 1: 0.5*mean((r-1)^2) + 0.5*mean((f+1)^2).  Forward writes out[0]; backward writes

@@ -177,6 +177,7 @@ extern "C" int octa_wpce_dice_bwd(const float* in, const int64_t* is, const floa
 // ------------------------------------------------------------------------------------------ interlayer KL
 #define KL_MAX_MAPS 8
 struct KlMaps { const float* p[KL_MAX_MAPS]; float* d[KL_MAX_MAPS]; int shift[KL_MAX_MAPS]; float w[KL_MAX_MAPS]; int n; float wsum; };
+// (optional fan-out addends of the backward kernels: the gradient another consumer of a map produced, same dense fp32 layout)
 
 template <int K>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, float* __restrict__ partial) {
@@ -241,7 +242,7 @@ extern "C" int octa_interlayer_kl_fwd(const float* basis, const float* const* ma
 // d basis: g/N * (log(P+eps) - m + P/(P+eps))
 template <int K>
 __global__ __launch_bounds__(256) void kl_bwd_basis_kernel(const float* __restrict__ basis, KlMaps mp, int B, int H, int W, const float* __restrict__ g,
-                                                           float* __restrict__ dbasis) {
+                                                           float* __restrict__ dbasis, const float* __restrict__ add) {
     const int total = B * K * H * W, HW = H * W;          // (< 2^31: checked by the host; 32-bit pixel decode as in kl_fwd_kernel)
     const float gs = g[0] / (float)((int64_t)B * H * W);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -253,12 +254,14 @@ __global__ __launch_bounds__(256) void kl_bwd_basis_kernel(const float* __restri
             const int s = mp.shift[j];
             m += logf(mp.p[j][((size_t)bk * (H >> s) + (h >> s)) * (W >> s) + (w >> s)] * mp.w[j] + 1e-12f);
         }
-        dbasis[i] = gs * (logf(P + 1e-12f) - m / mp.wsum + P / (P + 1e-12f));
+        const float d = gs * (logf(P + 1e-12f) - m / mp.wsum + P / (P + 1e-12f));
+        dbasis[i] = add ? d + add[i] : d;
     }
 }
 // d map j (gather form, one thread per source pixel): -g/N * w/(w Q + eps)/wsum * sum_{block} P
 __global__ __launch_bounds__(256) void kl_bwd_map_kernel(const float* __restrict__ basis, const float* __restrict__ q, float wgt, float wsum, int shift,
-                                                         int64_t BK, int H, int W, int64_t npix, const float* __restrict__ g, float* __restrict__ dq) {
+                                                         int64_t BK, int H, int W, int64_t npix, const float* __restrict__ g, float* __restrict__ dq,
+                                                         const float* __restrict__ add) {
     // f = 2^shift adjacent lanes per source pixel, one basis row of the f x f block each, then a butterfly over the f lanes (the
     // coarse maps were 20 000 threads walking 256 strided values each: 30 us for the 25 x 25 map)
     const int hs = H >> shift, wsz = W >> shift, f = 1 << shift;
@@ -275,12 +278,15 @@ __global__ __launch_bounds__(256) void kl_bwd_map_kernel(const float* __restrict
         float s = 0.f;
         for (int dx = 0; dx < f; ++dx) s += row[dx];
         for (int o = 1; o < f; o <<= 1) s += __shfl_xor(s, o);          // f <= 64 divides the wave: the f lanes of a pixel are adjacent
-        if (live && dy == 0) dq[i] = gs * s * wgt / (q[i] * wgt + 1e-12f);
+        if (live && dy == 0) {
+            const float d = gs * s * wgt / (q[i] * wgt + 1e-12f);
+            dq[i] = add ? d + add[i] : d;
+        }
     }
 }
-extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
-                                      float wsum, int B, int K, int H, int W, const float* g, float* dbasis, float* const* dmaps,
-                                      octa_stream_t stream) {
+extern "C" int octa_interlayer_kl_bwd_add(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
+                                          float wsum, int B, int K, int H, int W, const float* g, float* dbasis, float* const* dmaps,
+                                          const float* basis_addend, const float* const* map_addends, octa_stream_t stream) {
     OCTA_REQUIRE(basis && maps && shifts && weights && g && dmaps && n_maps >= 1 && n_maps <= KL_MAX_MAPS, "octa_interlayer_kl_bwd: bad arguments");
     KlMaps mp;
     mp.n = n_maps; mp.wsum = wsum;
@@ -290,7 +296,7 @@ extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* ma
     OCTA_REQUIRE(total < (1ll << 31), "octa_interlayer_kl_bwd: B*K*H*W must be below 2^31");
     if (dbasis) {
         int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
-        LOSS_K_SWITCH(K, kl_bwd_basis_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, g, dbasis); OCTA_CHECK_LAUNCH("kl_bwd_basis");)
+        LOSS_K_SWITCH(K, kl_bwd_basis_kernel<KK><<<blocks, 256, 0, st>>>(basis, mp, B, H, W, g, dbasis, basis_addend); OCTA_CHECK_LAUNCH("kl_bwd_basis");)
     }
     for (int j = 0; j < n_maps; ++j) {
         if (!dmaps[j]) continue;
@@ -298,10 +304,16 @@ extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* ma
         const int64_t tj = (total >> (2 * shifts[j])) << shifts[j];            // 2^shift lanes per source pixel
         int blocks = (int)(cdiv64(tj, 256) > 4096 ? 4096 : cdiv64(tj, 256));
         if (blocks < 1) blocks = 1;
-        kl_bwd_map_kernel<<<blocks, 256, 0, st>>>(basis, maps[j], weights[j], wsum, shifts[j], (int64_t)B * K, H, W, (int64_t)B * H * W, g, dmaps[j]);
+        kl_bwd_map_kernel<<<blocks, 256, 0, st>>>(basis, maps[j], weights[j], wsum, shifts[j], (int64_t)B * K, H, W, (int64_t)B * H * W, g, dmaps[j],
+                                                     map_addends ? map_addends[j] : nullptr);
         OCTA_CHECK_LAUNCH("kl_bwd_map");
     }
     return OCTA_OK;
+}
+extern "C" int octa_interlayer_kl_bwd(const float* basis, const float* const* maps, const int* shifts, const float* weights, int n_maps,
+                                      float wsum, int B, int K, int H, int W, const float* g, float* dbasis, float* const* dmaps,
+                                      octa_stream_t stream) {
+    return octa_interlayer_kl_bwd_add(basis, maps, shifts, weights, n_maps, wsum, B, K, H, W, g, dbasis, dmaps, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------ LS-GAN

@@ -1807,8 +1807,9 @@ class InterlayerKLFn(Function):
     """InterlayerDivergence KLD/mean (segmentor/losses.py:111-147) with the nearest up-sampling fused."""
 
     @staticmethod
-    def forward(ctx, weights, stop_gradient, basis, *maps):
+    def forward(ctx, weights, stop_gradient, holders, basis, *maps):
         _require_gpu(basis)
+        ctx.holders = holders        # per (basis, *maps): GradHolder of another consumer's gradient (added by the backward kernels) or None
         basis = basis.float().contiguous()
         B, K, H, W = basis.shape
         use = [(m.float().contiguous(), float(w)) for m, w in zip(maps, weights) if w != 0]
@@ -1844,16 +1845,51 @@ class InterlayerKLFn(Function):
         sh = (ctypes.c_int * n)(*shifts)
         wt = (ctypes.c_float * n)(*wts)
         dbasis = None if stop_gradient else torch.empty_like(basis)
-        lib().octa_interlayer_kl_bwd(_p(basis), ptrs, sh, wt, n, wsum, B, K, H, W, _p(g0), _p(dbasis), dptrs, _st())
+        # fan-out: what the maps' other consumer (the discriminator's generator pass, whose backward ran first) parked for them
+        holders = ctx.holders or [None] * (nmaps + 1)
+        parked = [_take_parked(h) for h in holders]
+
+        def addend_of(i, like):
+            g_ = parked[i]
+            if g_ is not None and like is not None and g_.dtype == torch.float32 and g_.shape == like.shape and g_.is_contiguous():
+                parked[i] = None
+                return g_
+            return None
+        badd = addend_of(0, dbasis)
+        madds = [addend_of(1 + i, d) for i, d in zip(idx, dmaps)]
+        aptrs = (ctypes.c_void_p * n)(*[_p(a) for a in madds])
+        lib().octa_interlayer_kl_bwd_add(_p(basis), ptrs, sh, wt, n, wsum, B, K, H, W, _p(g0), _p(dbasis), dptrs, _p(badd), aptrs, _st())
         grads: List[Optional[Tensor]] = [None] * nmaps
         for i, d in zip(idx, dmaps):
             grads[i] = d
-        return (None, None, dbasis, *grads)
+        # whatever could not ride as an addend (a map without a KL weight, stop_gradient, another layout) is added / returned here
+        if parked[0] is not None:
+            dbasis = parked[0] if dbasis is None else dbasis + parked[0]
+        for i in range(nmaps):
+            if parked[1 + i] is not None:
+                grads[i] = parked[1 + i] if grads[i] is None else grads[i] + parked[1 + i]
+        return (None, None, None, dbasis, *grads)
 
 
-def interlayer_kl(attentions: Sequence[Tensor], weights, stop_gradient=False) -> Tensor:
-    """returns a (2,) tensor: [loss, nan_flag]."""
-    return InterlayerKLFn.apply(list(weights), stop_gradient, attentions[0], *attentions[1:])
+def _take_parked(h: Optional["GradHolder"]):
+    if h is None:
+        return None
+    h.consumed = True
+    g, h.grad = h.grad, None
+    if g is not None and h.event is not None:
+        torch.cuda.current_stream().wait_event(h.event)
+    return g
+
+
+_FUSE_KL_FANOUT = os.environ.get("OCTA_FUSE_KL_FANOUT", "1") != "0"
+
+
+def interlayer_kl(attentions: Sequence[Tensor], weights, stop_gradient=False, holders=None) -> Tensor:
+    """returns a (2,) tensor: [loss, nan_flag].  `holders`: one GradHolder (or None) per attention -- the gradient another consumer of
+    that map parks there (stash_grad, created AFTER this call so that its backward runs first) is added by the backward kernels."""
+    if holders is not None and len(holders) != len(attentions):
+        raise OctaError("interlayer_kl: one holder (or None) per attention")
+    return InterlayerKLFn.apply(list(weights), stop_gradient, list(holders) if holders is not None else None, attentions[0], *attentions[1:])
 
 
 class LsganFn(Function):

@@ -593,7 +593,10 @@ class TrainStep:
             kl2 = g_adv = None
             if self.adversarial:
                 p = F_.class_softmax(agg)
-                kl2 = F_.interlayer_kl([p, *att], [1] * len(att))
+                # every attention map feeds the divergence AND the discriminator: the discriminator's gradient (its backward runs first:
+                # the stash nodes are created after the divergence's) is parked and added by the divergence's backward kernels
+                hs = [F_.GradHolder() for _ in att] if F_._FUSE_KL_FANOUT else None
+                kl2 = F_.interlayer_kl([p, *att], [1] * len(att), holders=[None, *hs] if hs else None)
                 # the generator pass only needs dL/d(att) through D: D's own weight gradients of this pass are discarded
                 # (zeroed before D's step, here and in the reference), so they are not computed at all
                 frozen = True
@@ -601,7 +604,7 @@ class TrainStep:
                     q.requires_grad_(False)
                 # (this is also what makes the concurrent discriminator graph safe: with requires_grad off nothing in the segmentor's
                 # backward pass writes the discriminator's gradient arena, which that graph zeroes and fills on its own stream)
-                g_adv = F_.lsgan_generator(disc(att))
+                g_adv = F_.lsgan_generator(disc([F_.stash_grad(a, h) for a, h in zip(att, hs)] if hs else att))
                 assert not any(q.requires_grad for q in self.disc_arena.params)
                 out["kl"], out["g_adv"] = kl2[0].detach(), g_adv.detach()
             # ((wpce + dice) + kl_w kl) + adv_w g_adv and its loss-scaled copy: one launch each way (functional.LossCombineFn)

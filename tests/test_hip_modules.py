@@ -109,6 +109,31 @@ def scribble(seed, shape=(B, C, H, W), empty_class=None):
     return ys
 
 
+@pytest.mark.parametrize("case", ["all", "stopgrad", "zero_weight"])
+def test_interlayer_kl_backward_adds_parked_fanout_gradients(dev, case):
+    """octa_interlayer_kl_bwd_add (round 5): every attention map feeds InterlayerDivergence AND a second consumer (the discriminator in the
+    training step, models/octa.py); the second consumer's gradient is parked by stash_grad and added where the KL gradient is written.
+    Against autograd's own sums without holders.  `stopgrad`: no basis gradient from the KL term -- the parked one must still arrive;
+    `zero_weight`: a map the divergence skips (weight 0) still gets its parked gradient."""
+    from octave_amd import functional as F_
+    weights = [1, 0.5, 0, 2, 1] if case == "zero_weight" else [1] * 5
+    other_w = [hash_input((B, C, 32 >> max(i - 1, 0), 32 >> max(i - 1, 0)), 70 + i, -1, 1).to(dev) for i in range(6)]
+
+    def run(fused):
+        att = [probs(60 + i, (B, C, 32 >> max(i - 1, 0), 32 >> max(i - 1, 0))).to(dev).requires_grad_(True) for i in range(6)]
+        hs = [F_.GradHolder() for _ in att] if fused else None
+        kl = F_.interlayer_kl(att, weights, case == "stopgrad", holders=hs)[0]
+        second = [F_.stash_grad(a, h) for a, h in zip(att, hs)] if fused else att          # created AFTER the divergence's node
+        other = sum((a * a * w).sum() for a, w in zip(second, other_w))
+        (kl + 0.3 * other).backward()
+        if fused:
+            assert all(h.consumed and h.grad is None for h in hs)
+        return [a.grad.clone() for a in att]
+    got, want = run(True), run(False)
+    for i, (g, w) in enumerate(zip(got, want)):
+        check(f"kl fan-out {case} grad{i}", g, w, 1e-6, 1e-7 * float(w.abs().max()) + 1e-12)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(64, 64, 1, 4, 24, 20, False), (128, 64, 2, 3, 33, 17, True), (32, 256, 1, 16, 13, 13, False)])
 def test_splat_with_bn0_on_the_fly_vs_separate_batchnorm(dev, dtype, cfg):
@@ -432,8 +457,11 @@ def test_side_branch_shortcuts_match_the_main_stream_path(dev, dtype):
     ys = _scribble(Bn, Hn).to(dev)
 
     def run(side):
-        old = (RN._SIDE_SHORTCUT, RN._SIDE_SHORTCUT_DEC)
+        old = (RN._SIDE_SHORTCUT, RN._SIDE_SHORTCUT_DEC, F_._FUSE_FANOUT_SKIP)
         RN._SIDE_SHORTCUT = RN._SIDE_SHORTCUT_DEC = side
+        # (a pool on the side stream does not take the skip connection's fan-out addend -- functional.take_fanout -- so the comparison
+        # runs both orders with autograd's own add there: the bit-identity below is about the stream order, not about that fusion)
+        F_._FUSE_FANOUT_SKIP = False
         F_.defer_wgrads(True)
         try:
             net, _ = _build(Bn, Hn, dev)
@@ -446,7 +474,7 @@ def test_side_branch_shortcuts_match_the_main_stream_path(dev, dtype):
             return agg.detach().clone(), {k: q.grad.detach().clone() for k, q in net.segmentor.named_parameters() if q.grad is not None}
         finally:
             F_.defer_wgrads(False)
-            RN._SIDE_SHORTCUT, RN._SIDE_SHORTCUT_DEC = old
+            RN._SIDE_SHORTCUT, RN._SIDE_SHORTCUT_DEC, F_._FUSE_FANOUT_SKIP = old
 
     F_.set_deterministic(True)
     try:
