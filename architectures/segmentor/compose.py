@@ -37,20 +37,22 @@ def _encode(net, x: Tensor):
     # x_0_0 .. x_3 each feed the next encoder stage AND a decoder's cat.  The stage's first pooling op on the tensor (the stem's
     # max-pool, the avg_down shortcut's pool) takes the holder offered here and adds the cat's gradient slice in its backward
     # kernel; the decoders get the tensor through stash_grad, which parks that slice (no separate gradient-sum launch).
-    h0 = F_.offer_fanout(x_0_0)
-    x_0_1 = net.encoder_0_2_2(x_0_0)
-    F_.withdraw_fanout()
-    x_1 = net.encoder_1(mark(x_0_1, "encoder_1"))
-    h1 = F_.offer_fanout(x_1)
-    x_2 = net.encoder_2(mark(x_1, "encoder_2"))
-    h2 = F_.offer_fanout(x_2)
-    x_3 = net.encoder_3(mark(x_2, "encoder_3"))
-    pad_h, pad_w = x_3.shape[2] % 2, x_3.shape[3] % 2
-    if pad_h or pad_w:                                   # ref :125-130
-        x_3 = F_.pad_bottom_right(x_3, pad_h, pad_w)
-    h3 = F_.offer_fanout(x_3)
-    x_4 = net.encoder_4(mark(x_3, "encoder_4"))
-    F_.withdraw_fanout()
+    try:
+        h0 = F_.offer_fanout(x_0_0)
+        x_0_1 = net.encoder_0_2_2(x_0_0)
+        F_.withdraw_fanout()
+        x_1 = net.encoder_1(mark(x_0_1, "encoder_1"))
+        h1 = F_.offer_fanout(x_1)
+        x_2 = net.encoder_2(mark(x_1, "encoder_2"))
+        h2 = F_.offer_fanout(x_2)
+        x_3 = net.encoder_3(mark(x_2, "encoder_3"))
+        pad_h, pad_w = x_3.shape[2] % 2, x_3.shape[3] % 2
+        if pad_h or pad_w:                                   # ref :125-130
+            x_3 = F_.pad_bottom_right(x_3, pad_h, pad_w)
+        h3 = F_.offer_fanout(x_3)
+        x_4 = net.encoder_4(mark(x_3, "encoder_4"))
+    finally:
+        F_.withdraw_fanout()                                 # (an offer nobody took -- or an exception -- must not reach another network's pool)
     return (F_.skip_with_fanout(x_0_0, h0), F_.skip_with_fanout(x_1, h1), F_.skip_with_fanout(x_2, h2), F_.skip_with_fanout(x_3, h3),
             x_4, pad_h, pad_w)
 

@@ -97,6 +97,54 @@ def test_group_merge_factor_host_logic():
     assert F_._densify(4, 64, 128, 3, 3, 2, 1, 200, 200, bf) == 0
 
 
+def test_fanout_offer_host_logic():
+    """functional.offer_fanout / take_fanout / skip_with_fanout / _take_parked (round 5, host logic only): an offer is made only for a
+    differentiable GPU tensor, taken at most once, never inside a side branch, and the decoder side stashes only when it was taken."""
+    import torch
+    from octave_amd import functional as F_
+    x = torch.zeros(1, 8, 2, 2, requires_grad=True)
+    assert F_.offer_fanout(x) is None and F_.take_fanout() is None          # CPU tensor: nothing to fuse (and no stale offer left)
+    h = F_.GradHolder()
+    F_._FANOUT_TLS.offer = h
+    assert F_.take_fanout() is h and h.taken and F_.take_fanout() is None  # taken once
+    h2 = F_.GradHolder()
+    F_._FANOUT_TLS.offer = h2
+    old = F_._IN_SIDE
+    F_._IN_SIDE = True
+    try:
+        assert F_.take_fanout() is None and not h2.taken                    # a pool on a side stream leaves the sum to autograd
+    finally:
+        F_._IN_SIDE = old
+    assert F_.skip_with_fanout(x, h2) is x and F_.skip_with_fanout(x, None) is x
+    y = F_.skip_with_fanout(x, h)                                           # taken -> the gradient is parked, not returned
+    assert y is not x and type(y.grad_fn).__name__ == "StashGradFnBackward"
+    y.sum().backward()
+    assert x.grad is None and h.grad is not None and float(h.grad.sum()) == 32.0
+    g = F_._take_parked(h)
+    assert h.consumed and h.grad is None and float(g.sum()) == 32.0 and F_._take_parked(None) is None
+    F_._FANOUT_TLS.offer = h2
+    F_.withdraw_fanout()
+    assert F_.take_fanout() is None
+
+
+def test_upsampling_cat_after_respects_module_hooks():
+    """Upsampling.cat_after (round 5) bypasses nn.Module.__call__ for the fused path: with a hook on the module (or on its transposed conv)
+    it must call the module, so that the hook sees the module's own output (here: the call reaches the op, which refuses CPU tensors)."""
+    import pytest
+    import torch
+    from architectures.extra.resnest import Upsampling
+    from octave_amd._lib import OctaError
+    u = Upsampling(16, 8)
+    seen = []
+    u.register_forward_pre_hook(lambda m, i: seen.append("pre"))
+    with pytest.raises(OctaError):
+        u.cat_after(torch.zeros(1, 8, 4, 4), torch.zeros(1, 16, 2, 2))
+    assert seen == ["pre"]                                                  # the module was called: the separate-ops path
+    v = Upsampling(16, 8)
+    with pytest.raises(OctaError):
+        v.cat_after(torch.zeros(1, 8, 4, 4), torch.zeros(1, 16, 2, 2))     # no hook: functional.upsample_cat, same refusal on the CPU
+
+
 def test_scratch_argument_checks(L):
     """The per-call scratch (octa_conv_desc.ws, octa_conv2d_wgrad_batch's ws): a misaligned or negative-size buffer is refused before any
     launch; NULL / 0 = none.  (No registration entry points exist any more: the library keeps no device pointer between calls.)"""
