@@ -38,7 +38,7 @@ enum octa_act { OCTA_ACT_NONE = 0, OCTA_ACT_RELU = 1, OCTA_ACT_LEAKY02 = 2, OCTA
 
 /* ABI revision: bumped whenever a struct layout or a signature below changes.  octa_version() returns the value the library
  * was BUILT with; the loader (octave_amd/_lib.py) refuses a library whose value differs from this header's. */
-#define OCTA_HIP_ABI_VERSION 316
+#define OCTA_HIP_ABI_VERSION 317
 int octa_version(void);
 const char* octa_last_error(void);
 
@@ -382,6 +382,11 @@ int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const float* mean
 int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, const float* logits, const void* out, const float* dgap, const float* aux, void* dx,
                           float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int dtype, int relu, octa_stream_t stream);
+/* Round 5: octa_splat_bn_bwd_logits2 WITHOUT its second launch (the radix-2 softmax backward of resnest.py:126-127 applied in place to the B x 2C
+ * sums): `da` leaves with the raw attention gradients and octa_splat_mlp_bwd_da (below) applies the softmax backward where it reads them. */
+int octa_splat_bn_bwd_da2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, const float* logits, const void* out, float* da, float* aux, int B, int HW, int C,
+                          int dtype, int relu, int prezeroed, octa_stream_t stream);
 
 
 /* The attention micro-net on (B, C) vectors (resnest.py:118-125), exact fp32, 2 <= B <= 32:
@@ -397,6 +402,13 @@ int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, 
                        const float* gamma, float* dh1_workspace /* B*inter */, float* dgap, float* dw1,
                        float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C,
                        int inter, int groups, int prezeroed /* dgap */, octa_stream_t stream);
+/* The same from the RAW attention gradients da[b][2C] and the logits (dlogits = rSoftmax backward of da, radix 2, computed on the fly):
+ * one launch fewer per split-attention block and direction (21 per training step). */
+int octa_splat_mlp_bwd_da(const float* da, const float* logits, const float* gap, const float* w1, const float* w2,
+                          const float* h1, const float* h2, const float* mean, const float* invstd,
+                          const float* gamma, float* dh1_workspace /* B*inter */, float* dgap, float* dw1,
+                          float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C,
+                          int inter, int groups, int prezeroed /* dgap */, octa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention gate / head (segmentor/blocks.py:38-46; compose.py:79,181): per-pixel K-class linear

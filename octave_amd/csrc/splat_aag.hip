@@ -720,9 +720,9 @@ extern "C" int octa_splat_bn_bwd_logits(const void* dout, const void* x, const f
     OCTA_CHECK_LAUNCH("splat_softmax_bwd");
     return OCTA_OK;
 }
-extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+static int splat_bn_bwd_logits2_impl(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                          const float* logits, const void* out, float* dlogits, float* aux, int B, int HW, int C, int dtype, int relu,
-                                         int prezeroed, octa_stream_t stream) {
+                                         int prezeroed, int raw_da, octa_stream_t stream) {
     OCTA_SPLAT_BN_ARGS;
     OCTA_REQUIRE(dout && logits && dlogits && aux && (!relu || out), "octa_splat_bn_bwd_logits2: null pointer (relu needs the forward output)");
     if (!prezeroed) {
@@ -741,9 +741,21 @@ extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const 
     else if (dtype == OCTA_BF16) splat_bwd_reduce_bn2_kernel<bf16_t><<<grid, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)x, bn, (const bf16_t*)out, dlogits, aux, HW, C, TX, rpb, relu, octa_rev_walk());
     else splat_bwd_reduce_bn2_kernel<f16_t><<<grid, 256, sh, st>>>((const f16_t*)dout, (const f16_t*)x, bn, (const f16_t*)out, dlogits, aux, HW, C, TX, rpb, relu, octa_rev_walk());
     OCTA_CHECK_LAUNCH("splat_bwd_reduce_bn2");
-    splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
-    OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    if (!raw_da) {
+        splat_softmax_bwd_kernel<<<cdiv(B * C, 256), 256, 0, st>>>(logits, dlogits, B, C);
+        OCTA_CHECK_LAUNCH("splat_softmax_bwd");
+    }
     return OCTA_OK;
+}
+extern "C" int octa_splat_bn_bwd_logits2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         const float* logits, const void* out, float* dlogits, float* aux, int B, int HW, int C, int dtype, int relu,
+                                         int prezeroed, octa_stream_t stream) {
+    return splat_bn_bwd_logits2_impl(dout, x, mean, invstd, gamma, beta, logits, out, dlogits, aux, B, HW, C, dtype, relu, prezeroed, 0, stream);
+}
+extern "C" int octa_splat_bn_bwd_da2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     const float* logits, const void* out, float* da, float* aux, int B, int HW, int C, int dtype, int relu,
+                                     int prezeroed, octa_stream_t stream) {
+    return splat_bn_bwd_logits2_impl(dout, x, mean, invstd, gamma, beta, logits, out, da, aux, B, HW, C, dtype, relu, prezeroed, 1, stream);
 }
 extern "C" int octa_splat_bn_bwd_dx2(const void* dout, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      const float* logits, const void* out, const float* dgap, const float* aux, void* dx, float* dgamma, float* dbeta,
@@ -930,8 +942,23 @@ extern "C" int octa_splat_mlp_fwd(const float* gap, const float* w1, const float
 // against dl[.][n] of all the batch entries (coalesced over t); the BT accumulators per thread meet through an LDS transpose (thread (bl, sl) sums
 // the BT rows of slice sl for batch entry bl) and the usual slice sum.  The operands of the BatchNorm part travel with the first round trip.
 // (Before: thread = (batch entry, slice of n), 32-64 dependent-latency iterations per thread: 16.4 us per launch in situ.)
-template <int BT>
-__device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+// dl[b][n] of the micro-net backward.  RAW: `dl` holds the raw attention gradients da (what splat_bwd_reduce_bn2 summed) and the radix-2 softmax
+// backward of splat_softmax_bwd_kernel -- dl0 = a0 (1 - a0) (da0 - da1), dl1 = -dl0, a0 = 1 / (1 + exp(l1 - l0)) -- is applied where the value is
+// read (round 5: that kernel was a 4.7 us launch of B x C threads in front of every micro-net backward, 21 per step; here it is three more
+// loads of the same round trip and one exp per value)
+template <bool RAW>
+__device__ __forceinline__ float splat_dl_at(const float* __restrict__ dl, const float* __restrict__ logits, int b, int n, int N) {
+    if (!RAW) return dl[(size_t)b * N + n];
+    const int C = N >> 1, c = n < C ? n : n - C;
+    const float* lr = logits + (size_t)b * N;
+    const float* dr = dl + (size_t)b * N;
+    const float l0 = lr[c], l1 = lr[C + c], d0 = dr[c], d1 = dr[C + c];
+    const float a0 = 1.f / (1.f + expf(l1 - l0));
+    const float g = a0 * (1.f - a0) * (d0 - d1);
+    return n < C ? g : -g;
+}
+template <int BT, bool RAW>
+__device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ w2, const float* __restrict__ h1,
                                                             const float* __restrict__ h2, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ dh1,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1, int B,
@@ -943,14 +970,13 @@ __device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restri
     if (fin) { mu = mean[j]; is = invstd[j]; g = gamma[j]; }
     if (live) { h1v = h1[(size_t)bl * inter + j]; h2v = h2[(size_t)bl * inter + j]; }
     const float* wc = w2 + (size_t)grp * Ng * Ig + jl;
-    const float* dg = dl + grp * Ng;
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
     for (int nn = tid; nn < Ng; nn += 256) {
         const float w = wc[(size_t)nn * Ig];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) acc[b] += b < B ? w * dg[(size_t)b * N + nn] : 0.f;
+        for (int b = 0; b < BT; ++b) acc[b] += b < B ? w * splat_dl_at<RAW>(dl, logits, b, grp * Ng + nn, N) : 0.f;
     }
 #pragma unroll
     for (int b = 0; b < BT; ++b) tr[tid * (BT + 1) + b] = acc[b];
@@ -973,14 +999,14 @@ __device__ __forceinline__ void splat_mlp_bwdA_body(int j, const float* __restri
     }
 }
 // backward B: block per n.  dW2[n][j] += sum_b dl[b][n] h2[b][j];  db2[n] += sum_b dl[b][n]
-template <int BT>
-__device__ __forceinline__ void splat_mlp_bwdB_body(int n, const float* __restrict__ dl, const float* __restrict__ h2, float* __restrict__ dw2,
+template <int BT, bool RAW>
+__device__ __forceinline__ void splat_mlp_bwdB_body(int n, const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ h2, float* __restrict__ dw2,
                                                             float* __restrict__ db2, int B, int inter, int N, int groups) {
     const int Ig = inter / groups, grp = n / (N / groups);
     float d[BT];
     float sb = 0.f;
 #pragma unroll
-    for (int b = 0; b < BT; ++b) { d[b] = b < B ? dl[(size_t)b * N + n] : 0.f; sb += d[b]; }     // uniform addresses: scalar loads
+    for (int b = 0; b < BT; ++b) { d[b] = b < B ? splat_dl_at<RAW>(dl, logits, b, n, N) : 0.f; sb += d[b]; }     // uniform addresses: scalar loads
     for (int j = threadIdx.x; j < Ig; j += 256) {
         float a = 0.f;
 #pragma unroll
@@ -1042,16 +1068,16 @@ __device__ __forceinline__ void splat_mlp_bwdD_body(int j, const float* __restri
         dw1[(size_t)j * Cg + c] += a;
     }
 }
-template <int BT>
-__global__ __launch_bounds__(256) void splat_mlp_bwdAB_kernel(const float* __restrict__ dl, const float* __restrict__ w2, const float* __restrict__ h1,
+template <int BT, bool RAW>
+__global__ __launch_bounds__(256) void splat_mlp_bwdAB_kernel(const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ w2, const float* __restrict__ h1,
                                                              const float* __restrict__ h2, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, float* __restrict__ dh1, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ db1, float* __restrict__ dw2,
                                                              float* __restrict__ db2, int B, int inter, int N, int groups) {
     __shared__ float red[4][32];
     __shared__ float tr[256 * (BT + 1)];
-    if ((int)blockIdx.x < inter) splat_mlp_bwdA_body<BT>(blockIdx.x, dl, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups, red, tr);
-    else splat_mlp_bwdB_body<BT>(blockIdx.x - inter, dl, h2, dw2, db2, B, inter, N, groups);
+    if ((int)blockIdx.x < inter) splat_mlp_bwdA_body<BT, RAW>(blockIdx.x, dl, logits, w2, h1, h2, mean, invstd, gamma, dh1, dgamma, dbeta, db1, B, inter, N, groups, red, tr);
+    else splat_mlp_bwdB_body<BT, RAW>(blockIdx.x - inter, dl, logits, h2, dw2, db2, B, inter, N, groups);
 }
 template <int BT>
 __global__ __launch_bounds__(256) void splat_mlp_bwdCD_kernel(const float* __restrict__ dh1, const float* __restrict__ w1, const float* __restrict__ gap,
@@ -1062,7 +1088,7 @@ __global__ __launch_bounds__(256) void splat_mlp_bwdCD_kernel(const float* __res
     if ((int)blockIdx.x < nC) splat_mlp_bwdC_body<BT>(blockIdx.x % nx, blockIdx.x / nx, ny, red, dh1, w1, dgap, B, C, inter, groups);
     else splat_mlp_bwdD_body<BT>(blockIdx.x - nC, dh1, gap, dw1, B, C, inter, groups);
 }
-extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
+static int splat_mlp_bwd_impl(const float* dlogits, const float* raw_logits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
                                   const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1, float* db1,
                                   float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, int prezeroed,
                                   octa_stream_t stream) {
@@ -1072,8 +1098,11 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
     hipStream_t st = (hipStream_t)stream;
     // two launches instead of four (+ a zero fill): A and B only read dlogits, C and D only read dh1 -- each pair shares a grid,
     // the block index selects the role
-    if (B <= 16) splat_mlp_bwdAB_kernel<16><<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
-    else splat_mlp_bwdAB_kernel<32><<<inter + 2 * C, 256, 0, st>>>(dlogits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    if (raw_logits) {
+        if (B <= 16) splat_mlp_bwdAB_kernel<16, true><<<inter + 2 * C, 256, 0, st>>>(dlogits, raw_logits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+        else splat_mlp_bwdAB_kernel<32, true><<<inter + 2 * C, 256, 0, st>>>(dlogits, raw_logits, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    } else if (B <= 16) splat_mlp_bwdAB_kernel<16, false><<<inter + 2 * C, 256, 0, st>>>(dlogits, nullptr, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
+    else splat_mlp_bwdAB_kernel<32, false><<<inter + 2 * C, 256, 0, st>>>(dlogits, nullptr, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgamma, dbeta, db1, dw2, db2, B, inter, 2 * C, groups);
     OCTA_CHECK_LAUNCH("splat_mlp_bwdAB");
     if (!prezeroed && octa_zero_async(dgap, (size_t)B * C * sizeof(float), st) != hipSuccess) OCTA_FAIL(OCTA_ERR_LAUNCH, "octa_splat_mlp_bwd: memset failed");
     {
@@ -1088,6 +1117,21 @@ extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const 
     }
     OCTA_CHECK_LAUNCH("splat_mlp_bwdCD");
     return OCTA_OK;
+}
+extern "C" int octa_splat_mlp_bwd(const float* dlogits, const float* gap, const float* w1, const float* w2, const float* h1, const float* h2,
+                                  const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1, float* db1,
+                                  float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, int prezeroed,
+                                  octa_stream_t stream) {
+    return splat_mlp_bwd_impl(dlogits, nullptr, gap, w1, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgap, dw1, db1, dgamma, dbeta, dw2, db2, B, C, inter, groups,
+                              prezeroed, stream);
+}
+extern "C" int octa_splat_mlp_bwd_da(const float* da, const float* logits, const float* gap, const float* w1, const float* w2, const float* h1,
+                                     const float* h2, const float* mean, const float* invstd, const float* gamma, float* dh1_ws, float* dgap, float* dw1,
+                                     float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, int B, int C, int inter, int groups, int prezeroed,
+                                     octa_stream_t stream) {
+    OCTA_REQUIRE(logits, "octa_splat_mlp_bwd_da: null logits");
+    return splat_mlp_bwd_impl(da, logits, gap, w1, w2, h1, h2, mean, invstd, gamma, dh1_ws, dgap, dw1, db1, dgamma, dbeta, dw2, db2, B, C, inter, groups,
+                              prezeroed, stream);
 }
 
 // =========================================================================================== AAG / head

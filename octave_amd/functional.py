@@ -1551,6 +1551,10 @@ def _grad_buf(p: Optional[Tensor], dense2d: bool = False):
 
 
 _SPLAT_BWD_MERGE = os.environ.get("OCTA_SPLAT_BWD_MERGE", "1") != "0"      # bn0's backward sums ride along the logits pass (2 passes instead of 3)
+# radix softmax backward inside the micro-net backward (octa_splat_bn_bwd_da2 + octa_splat_mlp_bwd_da: no launch of its own, 21 launches fewer per
+# step).  Built and parity-tested at the end of round 5, measured +-0 on the replayed step (profiles/r05_ab_splat_softmax_inline.txt: the three extra
+# loads and the exp per value cost the micro-net backward what the 4.7 us launch cost): off by default
+_SPLAT_SOFTMAX_INLINE = os.environ.get("OCTA_SPLAT_SOFTMAX_INLINE", "0") == "1"
 
 
 class SplatTailFn(Function):
@@ -1629,17 +1633,21 @@ class SplatTailFn(Function):
         dout = dense_nhwc(to_nhwc(dout, dtype=xr.dtype))
         dlogits, pz = _zeroed_f32((B, 2 * C), dev)
         aux = None
+        raw_da = False
         if fused and _SPLAT_BWD_MERGE:
             # two passes over (dout, out, x) instead of three: the logits pass also takes bn0's backward sums along (aux), see splat_aag.hip
             aux, pza = _zeroed_f32((B, 8, C), dev)
+            # (_SPLAT_SOFTMAX_INLINE: the radix softmax backward is applied by the micro-net backward where it reads the sums -- no launch for it)
+            raw_da = _SPLAT_SOFTMAX_INLINE
+            logits_pass = L.octa_splat_bn_bwd_da2 if raw_da else L.octa_splat_bn_bwd_logits2
             if pz and pza:
-                L.octa_splat_bn_bwd_logits2(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
-                                            B, HW, C, _dt(xr), int(relu), 1, _st())
+                logits_pass(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
+                            B, HW, C, _dt(xr), int(relu), 1, _st())
             else:
                 if pz:
                     dlogits = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)      # (both buffers are cleared by the entry point)
-                L.octa_splat_bn_bwd_logits2(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
-                                            B, HW, C, _dt(xr), int(relu), 0, _st())
+                logits_pass(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), _p(aux),
+                            B, HW, C, _dt(xr), int(relu), 0, _st())
         elif fused:
             L.octa_splat_bn_bwd_logits(_p(dout), _p(xr), _p(mean0), _p(invstd0), _p(g0), _p(b0), _p(logits), _p(out), _p(dlogits), B, HW, C,
                                        _dt(xr), int(relu), pz, _st())
@@ -1653,8 +1661,12 @@ class SplatTailFn(Function):
         db2, r_b2 = _grad_buf(fc2_b)
         dh1 = torch.empty((B, inter), dtype=torch.float32, device=dev)
         dgap, pzg = _zeroed_f32((B, C), dev)
-        L.octa_splat_mlp_bwd(_p(dlogits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap), _p(dw1),
-                             _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, pzg, _st())
+        if raw_da:
+            L.octa_splat_mlp_bwd_da(_p(dlogits), _p(logits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap),
+                                    _p(dw1), _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, pzg, _st())
+        else:
+            L.octa_splat_mlp_bwd(_p(dlogits), _p(gap), _p(w1), _p(w2), _p(h1), _p(h2), _p(mean1), _p(invstd1), _p(g1), _p(dh1), _p(dgap), _p(dw1),
+                                 _p(db1f), _p(dg1), _p(dbe1), _p(dw2), _p(db2), B, C, inter, card, pzg, _st())
         dx = nhwc_empty(B, 2 * C, H, W, xr.dtype, dev)
         r_g0 = r_b0 = None
         if fused:

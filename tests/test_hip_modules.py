@@ -195,6 +195,46 @@ def test_splat_with_bn0_on_the_fly_vs_separate_batchnorm(dev, dtype, cfg):
                 assert float((ba[n] - bb[n]).abs().max()) <= (1e-5 if f32 else 2e-3) * (float(bb[n].abs().max()) + 1.0), (it, n)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(64, 64, 1, 4, 24, 20, False), (128, 64, 2, 3, 33, 17, True), (32, 256, 1, 16, 13, 13, False)])
+def test_splat_softmax_backward_inside_the_micro_net_backward(dev, dtype, cfg):
+    """octa_splat_bn_bwd_da2 + octa_splat_mlp_bwd_da (round 5: the radix-2 softmax backward of resnest.py:126-127 applied where the micro-net's
+    backward reads the attention gradients, no launch of its own) against the separate splat_softmax_bwd_kernel (OCTA_SPLAT_SOFTMAX_INLINE=0),
+    deterministic mode: the same fp32 formula on the same sums -- input gradient and every parameter gradient within 1e-5 of the tensor's scale
+    (an fma contracted differently is all that may differ)."""
+    import architectures.extra.resnest as R
+    from octave_amd import functional as F_
+    from octave_amd.layers import BatchNorm2d
+    cin, ch, card, B, H, W, relu_after = cfg
+    gen = torch.Generator(device="cpu").manual_seed(37)
+    x0 = (torch.randn(B, cin, H, W, generator=gen) * 1.5 + 0.3)
+    g0 = torch.randn(B, ch, H, W, generator=gen)
+
+    def run(inline):
+        old = F_._SPLAT_SOFTMAX_INLINE
+        F_._SPLAT_SOFTMAX_INLINE = inline
+        try:
+            torch.manual_seed(5)
+            m = R.SplAtConv2d(cin, ch, 3, padding=1, groups=card, bias=True, radix=2, norm_layer=BatchNorm2d).to(dev).train()
+            x = F_.to_nhwc(x0.to(dev), dtype=dtype).detach().requires_grad_(True)
+            y = m(x, relu_after)
+            (y.float() * g0.to(dev)).sum().backward()
+            return F_.to_nchw_f32(y.detach()), F_.to_nchw_f32(x.grad), {n: p_.grad.detach().float().clone() for n, p_ in m.named_parameters()}
+        finally:
+            F_._SPLAT_SOFTMAX_INLINE = old
+    F_.set_deterministic(True)
+    try:
+        (ya, dxa, ga), (yb, dxb, gb) = run(True), run(False)
+    finally:
+        F_.set_deterministic(False)
+    assert torch.equal(ya, yb)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # (16 bit: dx is rounded to the storage type after the fp32 arithmetic)
+    assert float((dxa - dxb).abs().max()) <= tol * float(dxb.abs().max()), float((dxa - dxb).abs().max())
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for n in gb:
+        assert float((ga[n] - gb[n]).abs().max()) <= 1e-5 * max(float(gb[n].abs().max()), 1e-3 * gmax) + 1e-9, (n, float((ga[n] - gb[n]).abs().max()), float(gb[n].abs().max()))
+
+
 def test_losses_vs_reference_golden(dev, golden):
     from architectures.discriminator.losses import LSDiscriminatorialLoss, LSGeneratorLoss
     from architectures.segmentor.losses import DiceLoss, InterlayerDivergence, WeightedPartialCE
