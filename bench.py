@@ -295,6 +295,11 @@ def cpu_baseline_leg(net_state, seconds_budget=25.0):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: whatever native libraries print there (RCCL writes a five-line version banner to stdout when
+    # its communicator is created) goes to stderr instead -- fd 1 is pointed at fd 2 for the run and the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -478,7 +483,8 @@ def main():
             step.close()                  # leave the fused-training mode: the Dice leg is a plain eval-mode forward
             res["dice_vs_ref"] = dice_vs_ref_leg(dev)
             log("dice-vs-reference leg done")
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
